@@ -1,0 +1,162 @@
+// Tri-modal (pose / audio / eye) cross-attention glue kernels.
+// Reference: CrossAttention.forward MT:516-559, called three times per ResnetBlock_ca_mul (MT:459-463).
+// Keys per query = 2 (learned null k/v + the frame's condition k/v), cosine-sim attention with scale 8:
+//   softmax([s_null, s_ctx]) . [v_null, v_ctx] == v_null + sigmoid(s_ctx - s_null) * (v_ctx - v_null)
+// The Q projection (3 branches batched, LayerNorm gain folded into the weights) and the three output
+// projections run on conv_gemm; these kernels are the HBM-bound pieces in between.
+#include "dawn_common.h"
+#include "../../include/dawn_hip.h"
+
+namespace {
+
+constexpr int XH = 8, XD = 8;  // heads, dim_head (MT:488-489)
+constexpr float XSCALE = 8.0f; // MT:491
+
+// kv (F,128) = to_kv(ctx) = [k 8x8 | v 8x8]  ->  kvtab[f][branch][128] = [l2norm(k_h)*k_scale | v]
+// nulltab[branch][16] = [l2norm(null_k)*k_scale | null_v]
+__global__ void xattn_prep_kernel(const float* __restrict__ kv, int F, const float* __restrict__ k_scale,
+                                  const float* __restrict__ null_kv, float* __restrict__ kvtab, int branch,
+                                  float* __restrict__ nulltab) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;  // (f, head)
+    if (t < F * XH) {
+        const int f = t / XH, h = t % XH;
+        const float* k = kv + (long)f * 128 + h * XD;
+        const float* v = kv + (long)f * 128 + 64 + h * XD;
+        float n2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < XD; ++d) n2 += k[d] * k[d];
+        const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);  // F.normalize eps (MT:222-223)
+        float* o = kvtab + ((long)f * 3 + branch) * 128;
+#pragma unroll
+        for (int d = 0; d < XD; ++d) {
+            o[h * XD + d] = k[d] * inv * k_scale[d];
+            o[64 + h * XD + d] = v[d];
+        }
+    }
+    if (t == 0) {
+        float n2 = 0.f;
+        for (int d = 0; d < XD; ++d) n2 += null_kv[d] * null_kv[d];
+        const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        for (int d = 0; d < XD; ++d) {
+            nulltab[branch * 16 + d] = null_kv[d] * inv * k_scale[d];
+            nulltab[branch * 16 + 8 + d] = null_kv[XD + d];
+        }
+    }
+}
+
+// one thread per (row, branch, head): 8 q values in, 8 o values out (in place allowed)
+__global__ __launch_bounds__(256) void xattn_core_kernel(const float* __restrict__ q, float* __restrict__ o, long rows,
+                                                         int HW, const float* __restrict__ kvtab,
+                                                         const float* __restrict__ nulltab,
+                                                         const float* __restrict__ q_scale) {
+    const long total = rows * 24;
+    for (long t = (long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long row = t / 24;
+        const int bh = (int)(t - row * 24);
+        const int br = bh >> 3, h = bh & 7;
+        const int f = (int)(row / HW);
+        const f32x4 q0 = *reinterpret_cast<const f32x4*>(q + row * 192 + bh * 8);
+        const f32x4 q1 = *reinterpret_cast<const f32x4*>(q + row * 192 + bh * 8 + 4);
+        float qv[8] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w};
+        float n2 = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) n2 += qv[d] * qv[d];
+        const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+        const float* kc = kvtab + ((long)f * 3 + br) * 128 + h * 8;
+        const float* vc = kc + 64;
+        const float* kn = nulltab + br * 16;
+        const float* vn = kn + 8;
+        const float* qs = q_scale + br * 8;
+        float sn = 0.f, sc = 0.f;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+            const float qn = qv[d] * inv * qs[d];
+            sn += qn * kn[d];
+            sc += qn * kc[d];
+        }
+        sn *= XSCALE;
+        sc *= XSCALE;
+        // softmax over [null, ctx] in fp32 (MT:554)
+        const float mx = fmaxf(sn, sc);
+        const float en = expf(sn - mx), ec = expf(sc - mx);
+        const float den = en + ec;
+        const float an = en / den, ac = ec / den;
+        float ov[8];
+#pragma unroll
+        for (int d = 0; d < 8; ++d) ov[d] = an * vn[d] + ac * vc[d];
+        *reinterpret_cast<f32x4*>(o + row * 192 + bh * 8) = f32x4{ov[0], ov[1], ov[2], ov[3]};
+        *reinterpret_cast<f32x4*>(o + row * 192 + bh * 8 + 4) = f32x4{ov[4], ov[5], ov[6], ov[7]};
+    }
+}
+
+// one wave per row: out[row][c] = sum_b LN(y3[row][b][:])[c] * g3[b][c]      (Co <= 512)
+__global__ __launch_bounds__(256) void xattn_ln_sum_kernel(const float* __restrict__ y3, const float* __restrict__ g3,
+                                                           float* __restrict__ out, long rows, int Co, float eps) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int lane = threadIdx.x & 63;
+    constexpr int MAXE = 8;
+    float acc[MAXE];
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) acc[i] = 0.f;
+    for (int b = 0; b < 3; ++b) {
+        const float* y = y3 + (row * 3 + b) * Co;
+        float v[MAXE];
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const int c = lane + 64 * i;
+            v[i] = c < Co ? y[c] : 0.f;
+            s += v[i];
+        }
+        s = wave_sum(s);
+        const float mu = s / (float)Co;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const int c = lane + 64 * i;
+            const float dl = c < Co ? v[i] - mu : 0.f;
+            ss += dl * dl;
+        }
+        ss = wave_sum(ss);
+        const float rs = rsqrtf(ss / (float)Co + eps);
+#pragma unroll
+        for (int i = 0; i < MAXE; ++i) {
+            const int c = lane + 64 * i;
+            if (c < Co) acc[i] += (v[i] - mu) * rs * g3[b * Co + c];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < MAXE; ++i) {
+        const int c = lane + 64 * i;
+        if (c < Co) out[row * Co + c] = acc[i];
+    }
+}
+
+}  // namespace
+
+extern "C" int dawn_xattn_prep(const float* kv, int F, const float* k_scale, const float* null_kv, float* kvtab,
+                               int branch, float* nulltab, void* stream) {
+    hipLaunchKernelGGL(xattn_prep_kernel, dim3(dawn_cdiv((long)F * XH, 256)), dim3(256), 0, (hipStream_t)stream, kv, F,
+                       k_scale, null_kv, kvtab, branch, nulltab);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_xattn_core(const float* q, float* o, long rows, int HW, const float* kvtab, const float* nulltab,
+                               const float* q_scale, void* stream) {
+    long total = rows * 24;
+    int grid = (int)((total + 255) / 256);
+    if (grid > 16384) grid = 16384;
+    hipLaunchKernelGGL(xattn_core_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, q, o, rows, HW, kvtab,
+                       nulltab, q_scale);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_xattn_ln_sum(const float* y3, const float* g3, float* out, long rows, int Co, float eps,
+                                 void* stream) {
+    if (Co > 512) return dawn_set_error_msg(-50, "dawn_xattn_ln_sum: Co > 512 not supported");
+    hipLaunchKernelGGL(xattn_ln_sum_kernel, dim3(dawn_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, y3, g3, out,
+                       rows, Co, eps);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}

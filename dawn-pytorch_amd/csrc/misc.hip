@@ -1,0 +1,140 @@
+// Small / boundary kernels: x-part of init_conv, output heads, tiny dense layers.
+#include "dawn_common.h"
+#include "../../include/dawn_hip.h"
+
+namespace {
+
+// init_conv (MT:776-777) split by linearity: the 272 fea/bbox channels are frame- and step-invariant and
+// are convolved once per clip (conv_gemm -> fea_pre, bias included); per step only the 3 latent channels
+// remain: out[f][y][x][co] = fea_pre[y][x][co] + sum_{ky,kx,c} x[c][f][y+ky-3][x+kx-3] * w3[(ky*7+kx)*3+c][co]
+// 16 threads per pixel, each 4 output channels (Co = 64) -- generic: Co/4 threads per pixel.
+__global__ __launch_bounds__(256) void init_conv_x_kernel(const float* __restrict__ x, const float* __restrict__ w3,
+                                                          const float* __restrict__ fea_pre, int F, int h, int w,
+                                                          int Co, float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float ws[];  // [147][Co]
+    for (int i = threadIdx.x; i < 147 * Co; i += 256) ws[i] = w3[i];
+    __syncthreads();
+    const int tpp = Co >> 2;
+    const long npix = (long)F * h * w;
+    const long total = npix * tpp;
+    const long plane = (long)F * h * w;
+    for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
+        const long pix = t / tpp;
+        const int cq = (int)(t - pix * tpp);
+        const int f = (int)(pix / (h * w));
+        const int rem = (int)(pix - (long)f * h * w);
+        const int y = rem / w, xx = rem - y * w;
+        f32x4 acc = *reinterpret_cast<const f32x4*>(fea_pre + (long)rem * Co + cq * 4);
+        for (int ky = 0; ky < 7; ++ky) {
+            const int yi = y + ky - 3;
+            if (yi < 0 || yi >= h) continue;
+            for (int kx = 0; kx < 7; ++kx) {
+                const int xi = xx + kx - 3;
+                if (xi < 0 || xi >= w) continue;
+                const long off = ((long)f * h + yi) * w + xi;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float xv = x[c * plane + off];
+                    const f32x4 wv = *reinterpret_cast<const f32x4*>(ws + ((ky * 7 + kx) * 3 + c) * Co + cq * 4);
+                    acc += xv * wv;
+                }
+            }
+        }
+        *reinterpret_cast<f32x4*>(out + pix * Co + cq * 4) = acc;
+    }
+}
+
+// heads (MT:863, 876, 956): eps[0:2] = Wg.hg + bg ; eps[2] = Wo.ho + bo ; output layout (3, rows)
+// 16 lanes per row.
+__global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ hg, const float* __restrict__ ho,
+                                                       const float* __restrict__ wg, const float* __restrict__ bg,
+                                                       const float* __restrict__ wo, const float* __restrict__ bo,
+                                                       long rows, int Co, float* __restrict__ eps_out) {
+    const int sub = threadIdx.x & 15;
+    const long row = (long)blockIdx.x * 16 + (threadIdx.x >> 4);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+    if (row < rows) {
+        for (int c = sub * 4; c < Co; c += 64) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(hg + row * Co + c);
+            const f32x4 o = *reinterpret_cast<const f32x4*>(ho + row * Co + c);
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wg + c);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wg + Co + c);
+            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wo + c);
+            a0 += g.x * w0.x + g.y * w0.y + g.z * w0.z + g.w * w0.w;
+            a1 += g.x * w1.x + g.y * w1.y + g.z * w1.z + g.w * w1.w;
+            a2 += o.x * w2.x + o.y * w2.y + o.z * w2.z + o.w * w2.w;
+        }
+    }
+    a0 = wave_sum(a0, 16); a1 = wave_sum(a1, 16); a2 = wave_sum(a2, 16);
+    if (row < rows && sub == 0) {
+        eps_out[row] = a0 + bg[0];
+        eps_out[rows + row] = a1 + bg[1];
+        eps_out[2 * rows + row] = a2 + bo[0];
+    }
+}
+
+// out[m][n] = bias[n] + sum_k act(in[m][k]) * W[n][k]; one wave per output element.
+__global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ in, int M, int K, int ld_in,
+                                                     const float* __restrict__ W, const float* __restrict__ bias, int N,
+                                                     int act_in, float* __restrict__ out, int ld_out) {
+    const long o = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (o >= (long)M * N) return;
+    const int lane = threadIdx.x & 63;
+    const int m = (int)(o / N), n = (int)(o - (long)m * N);
+    float acc = 0.f;
+    for (int k = lane; k < K; k += 64) {
+        float v = in[(long)m * ld_in + k];
+        if (act_in == 1) v = dawn_silu(v);
+        else if (act_in == 2) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+        acc += v * W[(long)n * K + k];
+    }
+    acc = wave_sum(acc);
+    if (lane == 0) out[(long)m * ld_out + n] = acc + (bias ? bias[n] : 0.f);
+}
+
+// SinusoidalPosEmb MT:150-162: out = [sin(t f_i) | cos(t f_i)], f_i = exp(-i ln(1e4)/(half-1))
+__global__ void sinusoidal_kernel(float t, int dim, float* __restrict__ out) {
+    const int i = threadIdx.x;
+    const int half = dim / 2;
+    if (i < half) {
+        const float e = 9.210340371976184f / (float)(half - 1);
+        const float f = expf((float)i * -e);
+        const float a = t * f;
+        out[i] = sinf(a);
+        out[half + i] = cosf(a);
+    }
+}
+
+}  // namespace
+
+extern "C" int dawn_init_conv_x(const float* x, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
+                                float* out, void* stream) {
+    if (Co % 4 != 0 || 147 * Co * 4 > 60000) return dawn_set_error_msg(-60, "dawn_init_conv_x: bad Co");
+    const long total = (long)F * h * w * (Co / 4);
+    int grid = (int)((total + 255) / 256);
+    if (grid > 4096) grid = 4096;
+    hipLaunchKernelGGL(init_conv_x_kernel, dim3(grid), dim3(256), 147 * Co * sizeof(float), (hipStream_t)stream, x, w3,
+                       fea_pre, F, h, w, Co, out);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_head_out(const float* hg, const float* ho, const float* wg, const float* bg, const float* wo,
+                             const float* bo, long rows, int Co, float* eps_out, void* stream) {
+    hipLaunchKernelGGL(head_out_kernel, dim3(dawn_cdiv(rows, 16)), dim3(256), 0, (hipStream_t)stream, hg, ho, wg, bg,
+                       wo, bo, rows, Co, eps_out);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_linear(const float* in, int M, int K, int ld_in, const float* W, const float* bias, int N,
+                           int act_in, float* out, int ld_out, void* stream) {
+    hipLaunchKernelGGL(linear_kernel, dim3(dawn_cdiv((long)M * N, 4)), dim3(256), 0, (hipStream_t)stream, in, M, K,
+                       ld_in, W, bias, N, act_in, out, ld_out);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_sinusoidal(float t, int dim, float* out, void* stream) {
+    if (dim > 256) return dawn_set_error_msg(-61, "dawn_sinusoidal: dim > 256");
+    hipLaunchKernelGGL(sinusoidal_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, t, dim, out);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,195 @@
+// GroupNorm(8) statistics / apply and per-pixel LayerNorm statistics (HBM-bound streaming kernels).
+//   GroupNorm over (C/8, F, H, W): nn.GroupNorm(8, C) on a 5-D tensor, MT:230,235 (Block.norm).
+//   LayerNorm over channels per pixel: MT:179-188 (PreNorm) and MT:190-203 (LayerNorm_img).
+#include "dawn_common.h"
+#include "../../include/dawn_hip.h"
+
+namespace {
+
+// Each thread owns one float4 channel quad (fixed, because C/4 divides 256) and strides over rows.
+// Block result: fp64 (sum, sumsq) per group -> part[block][g*2 + {0,1}].
+__global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict__ x, long rows, int C, int ld,
+                                                         double* __restrict__ part) {
+    __shared__ double red[16];
+    const int tid = threadIdx.x;
+    if (tid < 16) red[tid] = 0.0;
+    __syncthreads();
+    const int q = C >> 2;              // quads per row (4..128), divides 256
+    const int rpb = 256 / q;           // rows per block iteration
+    const int cq = tid % q;
+    const int r0 = tid / q;
+    const int cpg = C >> 3;            // channels per group
+    float s[4] = {0, 0, 0, 0}, ss[4] = {0, 0, 0, 0};
+    double ds[4] = {0, 0, 0, 0}, dss[4] = {0, 0, 0, 0};
+    int cnt = 0;
+    for (long r = (long)blockIdx.x * rpb + r0; r < rows; r += (long)gridDim.x * rpb) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(x + r * ld + cq * 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { s[k] += v[k]; ss[k] += v[k] * v[k]; }
+        if (++cnt == 64) {  // flush fp32 runs into fp64 to bound rounding growth
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { ds[k] += s[k]; dss[k] += ss[k]; s[k] = 0; ss[k] = 0; }
+            cnt = 0;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ds[k] += s[k]; dss[k] += ss[k]; }
+    if (cpg >= 4) {
+        const int g = (cq * 4) / cpg;
+        atomicAdd(&red[g * 2], ds[0] + ds[1] + ds[2] + ds[3]);
+        atomicAdd(&red[g * 2 + 1], dss[0] + dss[1] + dss[2] + dss[3]);
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int g = (cq * 4 + k) / cpg;
+            atomicAdd(&red[g * 2], ds[k]);
+            atomicAdd(&red[g * 2 + 1], dss[k]);
+        }
+    }
+    __syncthreads();
+    if (tid < 16) part[(long)blockIdx.x * 16 + tid] = red[tid];
+}
+
+__global__ void gn_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ sums) {
+    const int t = threadIdx.x;
+    if (t < 16) {
+        double a = 0.0;
+        for (int b = 0; b < nblk; ++b) a += part[(long)b * 16 + t];
+        sums[t] = a;
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const float* __restrict__ fs,
+                                   const float* __restrict__ fsh, int C, float eps, float* __restrict__ a,
+                                   float* __restrict__ b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const int g = c / (C >> 3);
+    const double mean = sums[g * 2] / count;
+    double var = sums[g * 2 + 1] / count - mean * mean;
+    if (var < 0) var = 0;
+    const float rstd = (float)(1.0 / sqrt(var + (double)eps));
+    const float mu = (float)mean;
+    float av = rstd * gamma[c];
+    float bv = beta[c] - mu * av;
+    if (fs) {
+        const float sc = fs[c] + 1.0f;
+        av *= sc;
+        bv = bv * sc + fsh[c];
+    }
+    a[c] = av;
+    b[c] = bv;
+}
+
+__global__ __launch_bounds__(256) void gn_apply_res_kernel(const float* __restrict__ x, const float* __restrict__ a,
+                                                           const float* __restrict__ b, const float* __restrict__ res,
+                                                           float* __restrict__ out, long n4, int q) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        const int cq = (int)(i % q);
+        const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+        const f32x4 a4 = reinterpret_cast<const f32x4*>(a)[cq];
+        const f32x4 b4 = reinterpret_cast<const f32x4*>(b)[cq];
+        f32x4 y = v * a4 + b4;
+        y.x = dawn_silu(y.x); y.y = dawn_silu(y.y); y.z = dawn_silu(y.z); y.w = dawn_silu(y.w);
+        if (res) y += reinterpret_cast<const f32x4*>(res)[i];
+        reinterpret_cast<f32x4*>(out)[i] = y;
+    }
+}
+
+// L lanes cooperate on one row (L = min(64, C/4) rounded down to a power of two); two-pass in registers.
+template <int L>
+__global__ __launch_bounds__(256) void ln_rowstats_kernel(const float* __restrict__ in0, int C0, int ld0,
+                                                          const float* __restrict__ in1, int C1, int ld1, long rows,
+                                                          float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+    constexpr int RPB = 256 / L;
+    const int tid = threadIdx.x;
+    const int sub = tid % L;
+    const long row = (long)blockIdx.x * RPB + tid / L;
+    const int C = C0 + C1;
+    const int nq = C >> 2;
+    constexpr int MAXQ = 4;  // quads per lane: C <= 4*L*MAXQ (L=64 -> C <= 1024)
+    f32x4 v[MAXQ];
+    float s = 0.f;
+    const bool ok = row < rows;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int qd = sub + i * L;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (ok && qd < nq) {
+            const int c = qd * 4;
+            v[i] = (c < C0) ? *reinterpret_cast<const f32x4*>(in0 + row * ld0 + c)
+                            : *reinterpret_cast<const f32x4*>(in1 + row * ld1 + (c - C0));
+            s += v[i].x + v[i].y + v[i].z + v[i].w;
+        }
+    }
+    s = wave_sum(s, L);
+    const float mu = s / (float)C;
+    float ssq = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int qd = sub + i * L;
+        if (ok && qd < nq) {
+            const f32x4 dlt = v[i] - mu;
+            ssq += dlt.x * dlt.x + dlt.y * dlt.y + dlt.z * dlt.z + dlt.w * dlt.w;
+        }
+    }
+    ssq = wave_sum(ssq, L);
+    if (ok && sub == 0) {
+        mean[row] = mu;
+        rstd[row] = 1.0f / sqrtf(ssq / (float)C + eps);
+    }
+}
+
+}  // namespace
+
+extern "C" int dawn_gn_partial(const float* x, long rows, int C, int ld, double* part, int nblk, void* stream) {
+    if (C % 8 != 0 || C % 4 != 0 || 256 % (C / 4) != 0 || C > 1024)
+        return dawn_set_error_msg(-20, "dawn_gn_partial: C must be a power-of-two multiple of 8, <= 1024");
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nblk), dim3(256), 0, (hipStream_t)stream, x, rows, C, ld, part);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_gn_reduce(const double* part, int nblk, double* sums16, void* stream) {
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, nblk, sums16);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_gn_finalize(const double* sums16, double count_per_group, const float* gamma, const float* beta,
+                                const float* film_scale, const float* film_shift, int C, float eps, float* a,
+                                float* b, void* stream) {
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3(dawn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums16,
+                       count_per_group, gamma, beta, film_scale, film_shift, C, eps, a, b);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_gn_apply_res(const float* x, const float* a, const float* b, const float* res, float* out,
+                                 long rows, int C, void* stream) {
+    const long n4 = rows * (C / 4);
+    int grid = (int)((n4 + 255) / 256);
+    if (grid > 8192) grid = 8192;
+    if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(gn_apply_res_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, a, b, res, out, n4,
+                       C / 4);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_ln_rowstats(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
+                                float eps, float* mean, float* rstd, void* stream) {
+    const int C = C0 + C1;
+    if (C % 4 != 0 || C0 % 4 != 0 || C > 1024 || C < 16)
+        return dawn_set_error_msg(-21, "dawn_ln_rowstats: need 16 <= C <= 1024, C % 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    const int nq = C / 4;
+#define LAUNCH_LN(L)                                                                                         \
+    hipLaunchKernelGGL(ln_rowstats_kernel<L>, dim3(dawn_cdiv(rows, 256 / L)), dim3(256), 0, s, in0, C0, ld0, \
+                       in1, C1, ld1, rows, eps, mean, rstd)
+    if (nq >= 64) LAUNCH_LN(64);
+    else if (nq >= 32) LAUNCH_LN(32);
+    else if (nq >= 16) LAUNCH_LN(16);
+    else if (nq >= 8) LAUNCH_LN(8);
+    else LAUNCH_LN(4);
+#undef LAUNCH_LN
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,123 @@
+"""`GaussianDiffusion` / `DynamicNfGaussianDiffusion`: the sampler contract of SURVEY.md §8b B1(ii)
+(`diffusion.sample(fea, bbox_mask, cond=..., batch_size, cond_scale)`, MT:1137-1153 -> `ddim_sample`
+MT:1156-1208) on the HIP op set.  Same constructor signature and the same 12 schedule buffers in the
+`state_dict` as the reference (MT:988-1055), so `model.diffusion.load_state_dict(ckpt['diffusion'])`
+(UVG:527-528) works unchanged.  Inference only: the ancestral sampler / training losses (MT:1087-1134,
+1226-1281) are out of scope."""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence
+
+import torch
+from torch import nn
+
+from .sampler import cosine_schedule_buffers, ddim_sample_clip, ddim_step_scalars
+
+Tensor = torch.Tensor
+
+
+class GaussianDiffusion(nn.Module):
+    def __init__(self, denoise_fn, *, image_size, num_frames, text_use_bert_cls=False, channels=3, timesteps=1000,
+                 sampling_timesteps=250, ddim_sampling_eta=1., loss_type='l1', use_dynamic_thres=False,
+                 dynamic_thres_percentile=0.9, null_cond_prob=0.1):
+        super().__init__()
+        self.null_cond_prob = null_cond_prob
+        self.channels = channels
+        self.image_size = image_size
+        self.num_frames = num_frames
+        self.denoise_fn = denoise_fn
+        for k, v in cosine_schedule_buffers(timesteps).items():
+            self.register_buffer(k, v)
+        self.num_timesteps = int(timesteps)
+        self.loss_type = loss_type
+        self.sampling_timesteps = sampling_timesteps if sampling_timesteps is not None else timesteps
+        self.is_ddim_sampling = self.sampling_timesteps < timesteps
+        self.ddim_sampling_eta = ddim_sampling_eta
+        self.text_use_bert_cls = text_use_bert_cls
+        self.use_dynamic_thres = use_dynamic_thres
+        self.dynamic_thres_percentile = dynamic_thres_percentile
+        if not use_dynamic_thres or dynamic_thres_percentile != 0.9:
+            raise NotImplementedError("HIP sampler implements the shipped setting: dynamic thresholding at 0.9 (FD:164)")
+        # reproducibility knobs (the reference draws from the global torch generator)
+        self.noise_seed: Optional[int] = None     # int -> shard-invariant Philox stream on device
+        self.last_trace: Optional[list] = None
+
+    # ------------------------------------------------------------------ reference call surface
+    @torch.inference_mode()
+    def sample(self, fea, bbox_mask, cond=None, cond_scale=1., batch_size=16, *, x_init: Optional[Tensor] = None,
+               noises: Optional[Sequence[Tensor]] = None, trace: bool = False, comm=None):
+        """fea (B,256,h,w), bbox_mask (B,16,h,w), cond (B,T,1032) -> (B,3,T,h,w)   (MT:1137-1153).
+
+        Extra keyword-only hooks (not in the reference): `x_init` / `noises` inject the random draws of
+        MT:1166 / MT:1201 for parity tests; `comm` = T-shard communicator (cond then holds this rank's
+        frames only)."""
+        if not self.is_ddim_sampling:
+            raise NotImplementedError("ancestral sampling (sampling_timesteps >= timesteps) is out of scope")
+        batch_size = cond.shape[0] if cond is not None else batch_size
+        fea = torch.cat([fea, bbox_mask], dim=1)                                     # MT:1151
+        shape = (batch_size, self.channels, self.num_frames, fea.shape[-1], fea.shape[-1])
+        return self.ddim_sample(fea, shape, cond=cond, cond_scale=cond_scale, x_init=x_init, noises=noises,
+                                trace=trace, comm=comm)
+
+    @torch.no_grad()
+    def ddim_sample(self, fea, shape, cond=None, cond_scale=1., clip_denoised=True, *, x_init=None, noises=None,
+                    trace=False, comm=None):
+        if not clip_denoised:
+            raise NotImplementedError("clip_denoised=False is not used by the reference pipeline")
+        unet = self.denoise_fn
+        ops = unet._ops()
+        if comm is not None:
+            ops = type(ops)(comm=comm)
+        P = unet.packed()
+        B, C, T, h, w = shape
+        S, eta = self.sampling_timesteps, self.ddim_sampling_eta
+        steps = ddim_step_scalars({k: getattr(self, k) for k in ("alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
+                                                                  "sqrt_recipm1_alphas_cumprod")}, S, eta,
+                                  self.num_timesteps)
+        device = fea.device
+        Ttotal, f0 = (T, 0) if comm is None else (comm.Ttotal, comm.f0)
+        if cond is not None and cond.shape[1] != T:
+            raise ValueError(f"cond has {cond.shape[1]} frames but num_frames={T}; call update_num_frames first (UVG:370)")
+        outs, traces = [], []
+        for b in range(B):
+            cs = unet.build_clip(fea[b].contiguous().float(), cond[b].contiguous().float(), comm=comm,
+                                 Ttotal=Ttotal, f0=f0)
+            cs_null = None
+            if cond_scale != 1.0:
+                cs_null = unet.build_clip(fea[b].contiguous().float(), torch.zeros_like(cond[b]).float(), comm=comm,
+                                          Ttotal=Ttotal, f0=f0)
+            seed = self.noise_seed
+
+            def noise_fn(i, b=b):
+                if noises is not None:
+                    return noises[i][b].contiguous()
+                if seed is not None:
+                    return ops.philox_normal(3, T, f0, Ttotal, h * w, seed + b, i + 1, device).reshape(3, T, h, w)
+                return torch.randn(3, T, h, w, device=device)                         # MT:1201
+
+            if x_init is not None:
+                x0 = x_init[b].contiguous().float()
+            elif seed is not None:
+                x0 = ops.philox_normal(3, T, f0, Ttotal, h * w, seed + b, 0, device).reshape(3, T, h, w)
+            else:
+                x0 = torch.randn(3, T, h, w, device=device)                           # MT:1166
+            tr = [] if trace else None
+            outs.append(ddim_sample_clip(ops, P, cs, x0, steps, noise_fn, cond_scale, cs_null, tr))
+            traces.append(tr)
+        self.last_trace = traces if trace else None
+        return torch.stack(outs, 0)
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("training (p_losses, MT:1234-1281) is out of scope of the HIP inference build")
+
+
+class DynamicNfGaussianDiffusion(GaussianDiffusion):
+    """MT:1307-1313."""
+
+    def __init__(self, default_num_frames=20, *args, **kwargs):
+        super().__init__(*args, **kwargs)
+        self.default_num_frames = default_num_frames
+        self.num_frames = default_num_frames
+
+    def update_num_frames(self, new_num_frames):
+        self.num_frames = new_num_frames

@@ -1,0 +1,267 @@
+"""`HipOps`: the op set of the denoising path, each method one (or a few) launches into libdawn_hip.so.
+
+Tensors are torch CUDA(=HIP) fp32 tensors used only as typed device buffers (allocation + stream come from
+PyTorch; no torch arithmetic happens here).  Activations are 2-D `(rows, C)` views of channels-last clips,
+rows = F*H*W, unit stride along C, arbitrary row stride (so channel slices of wider buffers are legal).
+
+The orchestration in :mod:`unet_forward` / :mod:`sampler` is written against this interface; tests inject
+a torch reference implementation with the same interface (oracle/ops_ref.py) to check the orchestration
+on CPU and to check every kernel individually on the GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import ConvDesc, check
+
+Tensor = torch.Tensor
+
+
+def _p(t: Optional[Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def _ld(t: Optional[Tensor]) -> int:
+    return 0 if t is None else (t.stride(0) if t.dim() >= 2 else t.numel())
+
+
+class HipOps:
+    """Launches on the current PyTorch stream of the tensors' device."""
+
+    name = "hip"
+
+    def __init__(self, comm=None):
+        self.L = _lib.lib()          # raises if the extension is missing: no fallback by design
+        self.comm = comm             # T-shard communicator (see tshard.py) or None
+
+    # ------------------------------------------------------------------ helpers
+    @staticmethod
+    def _require(*ts: Optional[Tensor]) -> None:
+        for t in ts:
+            if t is None:
+                continue
+            if not t.is_cuda:
+                raise _lib.DawnHipError("HipOps needs GPU tensors; there is no CPU fallback on the product path")
+            if t.dtype not in (torch.float32, torch.float64, torch.int32, torch.uint8) or t.stride(-1) != 1:
+                raise _lib.DawnHipError(f"bad tensor for HipOps: dtype={t.dtype} strides={t.stride()}")
+
+    @staticmethod
+    def _stream() -> int:
+        return torch.cuda.current_stream().cuda_stream
+
+    def empty(self, *shape, like: Tensor, dtype=torch.float32) -> Tensor:
+        return torch.empty(*shape, device=like.device, dtype=dtype)
+
+    # ------------------------------------------------------------------ conv / linear on MFMA
+    def conv_gemm(self, in0: Tensor, w: Tensor, N: int, *, F: int, Hi: int, Wi: int, Ho: Optional[int] = None,
+                  Wo: Optional[int] = None, KH: int = 1, KW: int = 1, stride: int = 1, pad: int = 0, mode: int = 0,
+                  in1: Optional[Tensor] = None, bias: Optional[Tensor] = None,
+                  row_stats: Optional[Tuple[Tensor, Tensor]] = None, ch_ab: Optional[Tuple[Tensor, Tensor]] = None,
+                  pro_act: int = 0, pro_add: Optional[Tensor] = None, res: Optional[Tensor] = None,
+                  tr: Optional[Tuple[Tensor, Tensor, Tensor]] = None, out: Optional[Tensor] = None) -> Tensor:
+        Ho = Hi if Ho is None else Ho
+        Wo = Wi if Wo is None else Wo
+        rows_out = F * Ho * Wo
+        if out is None:
+            out = self.empty(rows_out, N, like=in0)
+        self._require(in0, in1, w, bias, pro_add, res, out)
+        d = ConvDesc()
+        d.in0, d.in1 = _p(in0), _p(in1)
+        d.C0, d.C1 = in0.shape[1], (in1.shape[1] if in1 is not None else 0)
+        d.ld0, d.ld1 = _ld(in0), _ld(in1)
+        d.F, d.Hi, d.Wi, d.Ho, d.Wo = F, Hi, Wi, Ho, Wo
+        d.KH, d.KW, d.stride, d.pad, d.mode = KH, KW, stride, pad, mode
+        d.w, d.bias, d.N = _p(w), _p(bias), N
+        if row_stats is not None:
+            d.row_mean, d.row_rstd = _p(row_stats[0]), _p(row_stats[1])
+        if ch_ab is not None:
+            d.ch_a, d.ch_b = _p(ch_ab[0]), _p(ch_ab[1])
+        d.pro_act = pro_act
+        d.pro_add, d.ld_add = _p(pro_add), _ld(pro_add)
+        d.res, d.ld_res = _p(res), _ld(res)
+        if tr is not None:
+            d.tr, d.ld_tr, d.tr_a, d.tr_b = _p(tr[0]), _ld(tr[0]), _p(tr[1]), _p(tr[2])
+        d.out, d.ld_out = _p(out), _ld(out)
+        check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
+        return out
+
+    # ------------------------------------------------------------------ GroupNorm / LayerNorm
+    def gn_coeffs(self, x: Tensor, gamma: Tensor, beta: Tensor, film: Optional[Tuple[Tensor, Tensor]],
+                  total_rows: int, eps: float = 1e-5) -> Tuple[Tensor, Tensor]:
+        """Per-channel (a, b) with silu(x*a+b) == SiLU(FiLM(GroupNorm8(x))).  Statistics over all rows of the
+        WHOLE clip: with a T-shard communicator the fp64 partial sums are all-reduced."""
+        rows, Cc = x.shape
+        self._require(x, gamma, beta)
+        nblk = max(1, min(1024, (rows * (Cc // 4) + 255) // 256 // 8))
+        part = self.empty(nblk, 16, like=x, dtype=torch.float64)
+        sums = self.empty(16, like=x, dtype=torch.float64)
+        s = self._stream()
+        check(self.L.dawn_gn_partial(_p(x), rows, Cc, _ld(x), _p(part), nblk, s), "dawn_gn_partial")
+        check(self.L.dawn_gn_reduce(_p(part), nblk, _p(sums), s), "dawn_gn_reduce")
+        if self.comm is not None:
+            self.comm.all_reduce_sum(sums)
+        a = self.empty(Cc, like=x)
+        b = self.empty(Cc, like=x)
+        fs, fsh = (film if film is not None else (None, None))
+        check(self.L.dawn_gn_finalize(_p(sums), float(total_rows) * (Cc // 8), _p(gamma), _p(beta), _p(fs), _p(fsh),
+                                      Cc, eps, _p(a), _p(b), s), "dawn_gn_finalize")
+        return a, b
+
+    def gn_apply_res(self, x: Tensor, a: Tensor, b: Tensor, res: Optional[Tensor]) -> Tensor:
+        rows, Cc = x.shape
+        assert x.is_contiguous() and (res is None or res.is_contiguous())
+        out = self.empty(rows, Cc, like=x)
+        check(self.L.dawn_gn_apply_res(_p(x), _p(a), _p(b), _p(res), _p(out), rows, Cc, self._stream()),
+              "dawn_gn_apply_res")
+        return out
+
+    def ln_rowstats(self, in0: Tensor, in1: Optional[Tensor] = None, eps: float = 1e-5) -> Tuple[Tensor, Tensor]:
+        rows = in0.shape[0]
+        self._require(in0, in1)
+        mean = self.empty(rows, like=in0)
+        rstd = self.empty(rows, like=in0)
+        check(self.L.dawn_ln_rowstats(_p(in0), in0.shape[1], _ld(in0), _p(in1), 0 if in1 is None else in1.shape[1],
+                                      _ld(in1), rows, eps, _p(mean), _p(rstd), self._stream()), "dawn_ln_rowstats")
+        return mean, rstd
+
+    # ------------------------------------------------------------------ cross attention
+    def xattn_prep(self, kv: Tensor, k_scale: Tensor, null_kv: Tensor, kvtab: Tensor, branch: int,
+                   nulltab: Tensor) -> None:
+        self._require(kv, k_scale, null_kv, kvtab, nulltab)
+        check(self.L.dawn_xattn_prep(_p(kv), kv.shape[0], _p(k_scale), _p(null_kv), _p(kvtab), branch, _p(nulltab),
+                                     self._stream()), "dawn_xattn_prep")
+
+    def xattn_core(self, q: Tensor, HW: int, kvtab: Tensor, nulltab: Tensor, q_scale: Tensor) -> Tensor:
+        """In place on q (rows,192)."""
+        assert q.is_contiguous() and q.shape[1] == 192
+        self._require(q, kvtab, nulltab, q_scale)
+        check(self.L.dawn_xattn_core(_p(q), _p(q), q.shape[0], HW, _p(kvtab), _p(nulltab), _p(q_scale),
+                                     self._stream()), "dawn_xattn_core")
+        return q
+
+    def xattn_ln_sum(self, y3: Tensor, g3: Tensor, Co: int, eps: float = 1e-5) -> Tensor:
+        rows = y3.shape[0]
+        assert y3.is_contiguous() and y3.shape[1] == 3 * Co
+        out = self.empty(rows, Co, like=y3)
+        check(self.L.dawn_xattn_ln_sum(_p(y3), _p(g3), _p(out), rows, Co, eps, self._stream()), "dawn_xattn_ln_sum")
+        return out
+
+    # ------------------------------------------------------------------ attention cores
+    def temporal_attn(self, qkv: Tensor, Fext: int, HW: int, q0: int, Fq: int, win: int, rcos: Tensor, rsin: Tensor,
+                      band: Tensor) -> Tensor:
+        assert qkv.is_contiguous() and qkv.shape == (Fext * HW, 768)
+        self._require(qkv, rcos, rsin, band)
+        out = self.empty(Fq * HW, 256, like=qkv)
+        check(self.L.dawn_temporal_attn(_p(qkv), Fext, HW, q0, Fq, win, _p(rcos), _p(rsin), _p(band), _p(out),
+                                        self._stream()), "dawn_temporal_attn")
+        return out
+
+    def sla(self, qkv: Tensor, F: int, HW: int) -> Tensor:
+        assert qkv.is_contiguous() and qkv.shape == (F * HW, 768)
+        ctx = self.empty(F, 8, 32, 32, like=qkv)
+        out = self.empty(F * HW, 256, like=qkv)
+        s = self._stream()
+        check(self.L.dawn_sla_context(_p(qkv), F, HW, _p(ctx), s), "dawn_sla_context")
+        check(self.L.dawn_sla_apply(_p(qkv), _p(ctx), F, HW, _p(out), s), "dawn_sla_apply")
+        return out
+
+    def frame_attn(self, qkv: Tensor, F: int, N: int) -> Tensor:
+        assert qkv.is_contiguous() and qkv.shape == (F * N, 768)
+        out = self.empty(F * N, 256, like=qkv)
+        check(self.L.dawn_frame_attn(_p(qkv), F, N, _p(out), self._stream()), "dawn_frame_attn")
+        return out
+
+    # ------------------------------------------------------------------ boundary ops
+    def init_conv_x(self, x: Tensor, w3: Tensor, fea_pre: Tensor, F: int, h: int, w: int, Co: int) -> Tensor:
+        assert x.is_contiguous() and x.shape == (3, F, h, w)
+        self._require(x, w3, fea_pre)
+        out = self.empty(F * h * w, Co, like=x)
+        check(self.L.dawn_init_conv_x(_p(x), _p(w3), _p(fea_pre), F, h, w, Co, _p(out), self._stream()),
+              "dawn_init_conv_x")
+        return out
+
+    def head_out(self, hg: Tensor, ho: Tensor, wg: Tensor, bg: Tensor, wo: Tensor, bo: Tensor) -> Tensor:
+        rows, Co = hg.shape
+        assert hg.is_contiguous() and ho.is_contiguous()
+        out = self.empty(3, rows, like=hg)
+        check(self.L.dawn_head_out(_p(hg), _p(ho), _p(wg), _p(bg), _p(wo), _p(bo), rows, Co, _p(out),
+                                   self._stream()), "dawn_head_out")
+        return out
+
+    def linear(self, x: Tensor, W: Tensor, bias: Optional[Tensor], act_in: int = 0,
+               out: Optional[Tensor] = None) -> Tensor:
+        M, K = x.shape
+        N = W.shape[0]
+        assert W.is_contiguous() and W.shape[1] == K
+        self._require(x, W, bias, out)
+        if out is None:
+            out = self.empty(M, N, like=x)
+        check(self.L.dawn_linear(_p(x), M, K, _ld(x), _p(W), _p(bias), N, act_in, _p(out), _ld(out), self._stream()),
+              "dawn_linear")
+        return out
+
+    def sinusoidal(self, t: float, dim: int, like: Tensor) -> Tensor:
+        out = self.empty(1, dim, like=like)
+        check(self.L.dawn_sinusoidal(float(t), dim, _p(out), self._stream()), "dawn_sinusoidal")
+        return out
+
+    # ------------------------------------------------------------------ sampler
+    def ddim_x0(self, x: Tensor, eps: Tensor, recip: float, recipm1: float) -> Tuple[Tensor, Tensor]:
+        n = x.numel()
+        assert x.is_contiguous() and eps.is_contiguous()
+        x0 = torch.empty_like(x)
+        hist = torch.zeros(2048, device=x.device, dtype=torch.int32)
+        check(self.L.dawn_ddim_x0(_p(x), _p(eps), recip, recipm1, n, _p(x0), _p(hist), self._stream()), "dawn_ddim_x0")
+        return x0, hist
+
+    def quantile_threshold(self, x0: Tensor, hist1: Tensor, n_total: int, q: float = 0.9) -> Tensor:
+        """s = max(1, torch.quantile(|x0|, q)) over the WHOLE clip (histograms all-reduced when T-sharded).
+        Returns a 2-float device tensor [s, raw quantile]."""
+        import numpy as np
+        pos = np.float32(q) * np.float32(n_total - 1)          # torch.quantile ranks in the input dtype
+        lo = int(np.floor(pos))
+        weight = float(np.float32(pos) - np.float32(lo))
+        s = self._stream()
+        n = x0.numel()
+        state = torch.zeros(4, device=x0.device, dtype=torch.int32)
+        if self.comm is not None:
+            self.comm.all_reduce_sum(hist1)
+        check(self.L.dawn_select_scan(_p(hist1), 2048, lo, _p(state), 1, s), "dawn_select_scan")
+        for p in (2, 3):
+            h = torch.zeros(1024, device=x0.device, dtype=torch.int32)
+            check(self.L.dawn_select_hist(_p(x0), n, _p(state), p, _p(h), s), "dawn_select_hist")
+            if self.comm is not None:
+                self.comm.all_reduce_sum(h)
+            check(self.L.dawn_select_scan(_p(h), 1024, 0, _p(state), p, s), "dawn_select_scan")
+        hmin = torch.full((4,), 0x7fffffff, device=x0.device, dtype=torch.int32)
+        check(self.L.dawn_select_hist(_p(x0), n, _p(state), 4, _p(hmin), s), "dawn_select_hist")
+        if self.comm is not None:
+            self.comm.all_reduce_min(hmin)
+        out = torch.empty(2, device=x0.device, dtype=torch.float32)
+        check(self.L.dawn_select_finalize(_p(state), _p(hmin), weight, _p(out), s), "dawn_select_finalize")
+        return out
+
+    def ddim_update(self, x0: Tensor, eps: Tensor, s: Tensor, noise: Optional[Tensor], sqrt_alpha_next: float,
+                    c: float, sigma: float) -> Tensor:
+        x = torch.empty_like(x0)
+        assert noise is None or noise.is_contiguous()
+        check(self.L.dawn_ddim_update(_p(x0), _p(eps), _p(s), _p(noise), sqrt_alpha_next, c, sigma, x0.numel(),
+                                      _p(x), self._stream()), "dawn_ddim_update")
+        return x
+
+    def cfg_combine(self, e_null: Tensor, e_cond: Tensor, scale: float) -> Tensor:
+        out = torch.empty_like(e_cond)
+        check(self.L.dawn_cfg_combine(_p(e_null), _p(e_cond), float(scale), e_cond.numel(), _p(out), self._stream()),
+              "dawn_cfg_combine")
+        return out
+
+    def philox_normal(self, Cc: int, F: int, f0: int, Ftotal: int, hw: int, seed: int, stream_id: int,
+                      device) -> Tensor:
+        out = torch.empty(Cc, F, hw, device=device, dtype=torch.float32)
+        check(self.L.dawn_philox_normal(_p(out), Cc, F, f0, Ftotal, hw, seed, stream_id, self._stream()),
+              "dawn_philox_normal")
+        return out

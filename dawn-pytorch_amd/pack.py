@@ -1,0 +1,251 @@
+"""Weight packing: reference `state_dict` (checkpoint contract of UVG:527-528, 912 keys) -> kernel layouts.
+
+Done once per model load on the host side.  GEMM/conv weights become `[K/4][N][4]` (k = tap*Cin + c), the
+order the MFMA kernel stages its B operand in; LayerNorm gains that precede a projection are folded into
+the projection's rows (PreNorm gamma MT:183, CrossAttention norm.g MT:501) so the kernels only need
+per-pixel (mean, rstd).
+"""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional
+
+import torch
+
+Tensor = torch.Tensor
+BRANCHES = ("pose", "aud", "eye")           # summation order of MT:463
+BRANCH_MLP = {"pose": "pose_mlp", "aud": "audio_mlp", "eye": "eye_mlp"}
+
+
+def pack_kn(w_kn: Tensor) -> Tensor:
+    """(K, N) -> [K/4][N][4] contiguous fp32."""
+    K, N = w_kn.shape
+    assert K % 4 == 0, K
+    return w_kn.float().reshape(K // 4, 4, N).permute(0, 2, 1).contiguous()
+
+
+def unpack_kn(wp: Tensor) -> Tensor:
+    K4, N, _ = wp.shape
+    return wp.permute(0, 2, 1).reshape(K4 * 4, N)
+
+
+def conv_w_kn(w5: Tensor) -> Tensor:
+    """Conv3d weight (Co, Ci, 1, kh, kw) -> (kh*kw*Ci, Co), k = (ky*kw + kx)*Ci + ci."""
+    Co, Ci, _, kh, kw = w5.shape
+    return w5[:, :, 0].permute(2, 3, 1, 0).reshape(kh * kw * Ci, Co)
+
+
+def deconv_w_kn_phases(w5: Tensor) -> Tensor:
+    """ConvTranspose3d weight (Ci, Co, 1, 4, 4), stride 2, pad 1 -> 4 phase blocks of 2x2 taps.
+    Output pixel (2a+py, 2b+px) = sum over taps (ty,tx): in[a+dy][b+dx] * w[ky][kx] with
+    py=0: (ty=0: ky=1, dy=0), (ty=1: ky=3, dy=-1);  py=1: (ty=0: ky=2, dy=0), (ty=1: ky=0, dy=+1)."""
+    Ci, Co = w5.shape[:2]
+    ksel = ((1, 3), (2, 0))
+    blocks = []
+    for py in range(2):
+        for px in range(2):
+            taps = []
+            for ty in range(2):
+                for tx in range(2):
+                    taps.append(w5[:, :, 0, ksel[py][ty], ksel[px][tx]])      # (Ci, Co)
+            blocks.append(torch.stack(taps, 0).reshape(4 * Ci, Co))
+    return torch.stack(blocks, 0)                                             # (4, 4*Ci, Co)
+
+
+def rel_pos_bucket(rel: Tensor, num_buckets: int = 32, max_distance: int = 32) -> Tensor:
+    """RelativePositionBias._relative_position_bucket (MT:92-109), rel = k_pos - q_pos, fp32 log."""
+    n = -rel
+    half = num_buckets // 2
+    ret = (n < 0).long() * half
+    n = n.abs()
+    max_exact = half // 2
+    large = max_exact + (torch.log(n.float() / max_exact) / math.log(max_distance / max_exact)
+                         * (half - max_exact)).long()
+    large = torch.minimum(large, torch.full_like(large, half - 1))
+    return ret + torch.where(n < max_exact, n, large)
+
+
+@dataclass
+class PackedResBlock:
+    Cin: int
+    Co: int
+    w1: Tensor
+    b1: Tensor
+    g1: Tensor
+    be1: Tensor
+    w2: Tensor
+    b2: Tensor
+    g2: Tensor
+    be2: Tensor
+    wr: Optional[Tensor] = None
+    br: Optional[Tensor] = None
+    conditioned: bool = False
+    cond_index: int = -1
+    film_off: int = 0
+    wq: Optional[Tensor] = None            # (Cin -> 192), LayerNorm gains folded
+    q_scale: Optional[Tensor] = None       # (3, 8)
+    wo: Optional[List[Tensor]] = None      # 3 x (64 -> Co)
+    g3: Optional[Tensor] = None            # (3, Co)
+    # per-clip condition path (A6): kept in torch.nn.Linear layout for dawn_linear
+    mlp_w: Optional[List[Tensor]] = None
+    mlp_b: Optional[List[Tensor]] = None
+    kv_w: Optional[List[Tensor]] = None
+    k_scale: Optional[List[Tensor]] = None
+    null_kv: Optional[List[Tensor]] = None
+
+
+@dataclass
+class PackedAttn:
+    C: int
+    wqkv: Tensor
+    wout: Tensor
+    bout: Optional[Tensor] = None
+
+
+@dataclass
+class PackedUNet:
+    dim: int
+    dims: List[int]
+    n_levels: int
+    fea_ch: int
+    cond_dims: List[int]                   # [aud, pose, eye]
+    win: int
+    w3: Tensor = None
+    wfea: Tensor = None
+    b_init: Tensor = None
+    init_tattn: PackedAttn = None
+    t_w1: Tensor = None
+    t_b1: Tensor = None
+    t_w2: Tensor = None
+    t_b2: Tensor = None
+    film_w: Tensor = None
+    film_b: Tensor = None
+    downs: List[dict] = field(default_factory=list)
+    mid: dict = field(default_factory=dict)
+    ups: List[dict] = field(default_factory=list)
+    head_g: PackedResBlock = None
+    head_o: PackedResBlock = None
+    wg: Tensor = None
+    bg: Tensor = None
+    wo: Tensor = None
+    bo: Tensor = None
+    rel_emb: Tensor = None                 # (32, 8)
+    rot_freqs: Tensor = None               # (16,)
+    n_cond_blocks: int = 0
+
+    def band(self, win: int) -> Tensor:
+        """bias by offset d = j - i in [-win, win] -> (2*win+1, 8) (MT:111-119 inside the window)."""
+        d = torch.arange(-win, win + 1, device=self.rel_emb.device)
+        return self.rel_emb[rel_pos_bucket(d)].contiguous()
+
+    def rotary_tables(self, n: int):
+        """cos/sin (n,16) of rotary-embedding-torch 0.3.x: angle = pos * freqs (interleaved pairs)."""
+        pos = torch.arange(n, dtype=torch.float32)
+        ang = pos[:, None] * self.rot_freqs.detach().float().cpu()[None, :]
+        dev = self.rel_emb.device
+        return ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+
+
+def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn.") -> PackedUNet:
+    g = lambda k: sd[prefix + k].detach().float()
+    has = lambda k: (prefix + k) in sd
+    dev = lambda t: t.contiguous().to(device)
+
+    n_levels = 0
+    while has(f"downs.{n_levels}.0.block1.proj.weight"):
+        n_levels += 1
+    w_init = g("init_conv.weight")
+    dim = w_init.shape[0]
+    dims = [dim] + [g(f"downs.{l}.0.block1.proj.weight").shape[0] for l in range(n_levels)]
+    P = PackedUNet(dim=dim, dims=dims, n_levels=n_levels, fea_ch=w_init.shape[1] - 3,
+                   cond_dims=[g("downs.0.0.audio_mlp.1.weight").shape[1], g("downs.0.0.pose_mlp.1.weight").shape[1],
+                              g("downs.0.0.eye_mlp.1.weight").shape[1]], win=win)
+    assert w_init.shape[-1] == 7 and P.fea_ch % 16 == 0, "init conv: 7x7 kernel and fea channels % 16 == 0"
+    P.w3 = dev(conv_w_kn(w_init[:, :3]))                              # (147, dim)
+    P.wfea = dev(pack_kn(conv_w_kn(w_init[:, 3:])))
+    P.b_init = dev(g("init_conv.bias"))
+    P.rel_emb = dev(g("time_rel_pos_bias.relative_attention_bias.weight"))
+    P.rot_freqs = g("init_temporal_attn.fn.fn.fn.rotary_emb.freqs")
+    P.t_w1, P.t_b1 = dev(g("time_mlp.1.weight")), dev(g("time_mlp.1.bias"))
+    P.t_w2, P.t_b2 = dev(g("time_mlp.3.weight")), dev(g("time_mlp.3.bias"))
+
+    film_w, film_b = [], []
+    state = {"film_off": 0, "cond_idx": 0}
+
+    def attn(p: str, spatial_linear: bool = False) -> PackedAttn:
+        """p addresses the Residual module: p.fn.norm.gamma, p.fn.fn(.fn).to_qkv / to_out."""
+        gamma = g(p + "fn.norm.gamma").reshape(-1)
+        inner = "fn.fn." if spatial_linear else "fn.fn.fn."
+        wqkv = g(p + inner + "to_qkv.weight").reshape(768, -1)        # (768, C)
+        wout = g(p + inner + "to_out.weight").reshape(-1, 256)        # (C, 256)
+        a = PackedAttn(C=wqkv.shape[1], wqkv=dev(pack_kn(wqkv.t() * gamma[:, None])), wout=dev(pack_kn(wout.t())))
+        if spatial_linear:
+            a.bout = dev(g(p + inner + "to_out.bias"))
+        return a
+
+    def resblock(p: str) -> PackedResBlock:
+        w1 = g(p + "block1.proj.weight")
+        Co, Cin = w1.shape[0], w1.shape[1]
+        rb = PackedResBlock(
+            Cin=Cin, Co=Co,
+            w1=dev(pack_kn(conv_w_kn(w1))), b1=dev(g(p + "block1.proj.bias")),
+            g1=dev(g(p + "block1.norm.weight")), be1=dev(g(p + "block1.norm.bias")),
+            w2=dev(pack_kn(conv_w_kn(g(p + "block2.proj.weight")))), b2=dev(g(p + "block2.proj.bias")),
+            g2=dev(g(p + "block2.norm.weight")), be2=dev(g(p + "block2.norm.bias")))
+        if has(p + "res_conv.weight"):
+            rb.wr = dev(pack_kn(conv_w_kn(g(p + "res_conv.weight"))))
+            rb.br = dev(g(p + "res_conv.bias"))
+        if has(p + "time_mlp.1.weight"):
+            rb.conditioned = True
+            rb.cond_index = state["cond_idx"]
+            state["cond_idx"] += 1
+            rb.film_off = state["film_off"]
+            state["film_off"] += 2 * Co
+            film_w.append(g(p + "time_mlp.1.weight"))
+            film_b.append(g(p + "time_mlp.1.bias"))
+            wq, qs, wo, g3 = [], [], [], []
+            rb.mlp_w, rb.mlp_b, rb.kv_w, rb.k_scale, rb.null_kv = [], [], [], [], []
+            for br in BRANCHES:
+                q = p + f"cross_attn_{br}."
+                wq.append(g(q + "to_q.weight").t() * g(q + "norm.g")[:, None])           # (Cin, 64)
+                qs.append(g(q + "q_scale"))
+                wo.append(dev(pack_kn(g(q + "to_out.0.weight").t())))                     # (64, Co)
+                g3.append(g(q + "to_out.1.g"))
+                rb.mlp_w.append(dev(g(p + BRANCH_MLP[br] + ".1.weight")))
+                rb.mlp_b.append(dev(g(p + BRANCH_MLP[br] + ".1.bias")))
+                rb.kv_w.append(dev(g(q + "to_kv.weight")))
+                rb.k_scale.append(dev(g(q + "k_scale")))
+                rb.null_kv.append(dev(g(q + "null_kv")))
+            rb.wq = dev(pack_kn(torch.cat(wq, dim=1)))
+            rb.q_scale = dev(torch.stack(qs, 0))
+            rb.wo = wo
+            rb.g3 = dev(torch.stack(g3, 0))
+        return rb
+
+    P.init_tattn = attn("init_temporal_attn.")
+    for l in range(n_levels):
+        q = f"downs.{l}."
+        lvl = {"rb1": resblock(q + "0."), "rb2": resblock(q + "1."), "sla": attn(q + "2.", True),
+               "tattn": attn(q + "3."), "down": None}
+        if has(q + "4.weight"):
+            lvl["down"] = (dev(pack_kn(conv_w_kn(g(q + "4.weight")))), dev(g(q + "4.bias")))
+        P.downs.append(lvl)
+    P.mid = {"rb1": resblock("mid_block1."), "sattn": attn("mid_spatial_attn."),
+             "tattn": attn("mid_temporal_attn."), "rb2": resblock("mid_block2.")}
+    for l in range(n_levels):
+        q = f"ups.{l}."
+        lvl = {"rb1": resblock(q + "0."), "rb2": resblock(q + "1."), "sla": attn(q + "2.", True),
+               "tattn": attn(q + "3."), "up": None}
+        if has(q + "4.weight"):
+            ph = deconv_w_kn_phases(g(q + "4.weight"))
+            lvl["up"] = (dev(torch.stack([pack_kn(ph[i]) for i in range(4)], 0)), dev(g(q + "4.bias")))
+        P.ups.append(lvl)
+    P.head_g = resblock("final_conv.0.")
+    P.head_o = resblock("occlusion_map.0.")
+    P.wg, P.bg = dev(g("final_conv.1.weight").reshape(2, -1)), dev(g("final_conv.1.bias"))
+    P.wo, P.bo = dev(g("occlusion_map.1.weight").reshape(1, -1)), dev(g("occlusion_map.1.bias"))
+    P.film_w = dev(torch.cat(film_w, 0))
+    P.film_b = dev(torch.cat(film_b, 0))
+    P.n_cond_blocks = state["cond_idx"]
+    return P

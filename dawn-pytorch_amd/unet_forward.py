@@ -1,0 +1,176 @@
+"""Op-level orchestration of one denoiser evaluation (`Unet3D.forward`, MT:892-956) for ONE clip.
+
+Written against the op interface of :class:`ops.HipOps`; activations are `(rows, C)` channels-last
+buffers, rows = F*H*W.  What is hoisted out of the per-step path (all exact by linearity / independence
+of x):
+  * the 272 fea/bbox channels of `init_conv` -> once per clip (`ClipState.fea_pre`);
+  * the condition MLPs + `to_kv` of every cross-attention (A6, depend on `cond` only) -> once per clip;
+  * relative-position band and rotary tables -> once per clip.
+T-sharding: `ClipState.comm` (tshard.TShardComm) provides the temporal-attention halo exchange; GroupNorm
+statistics are all-reduced inside `ops.gn_coeffs`.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+import torch
+
+from .pack import PackedAttn, PackedResBlock, PackedUNet
+
+Tensor = torch.Tensor
+
+
+@dataclass
+class ClipState:
+    F: int                     # frames held by this rank
+    Ttotal: int                # frames of the whole clip (== F when not sharded)
+    f0: int                    # global index of this rank's first frame
+    h: int
+    w: int
+    fea_pre: Tensor            # (h*w, dim)
+    kvtab: List[Tensor]        # per conditioned block: (F, 3, 128)
+    nulltab: List[Tensor]      # per conditioned block: (3, 16)
+    rcos: Tensor
+    rsin: Tensor
+    band: Tensor
+    win: int
+    comm: object = None
+
+
+def build_clip_state(ops, P: PackedUNet, fea272: Tensor, cond: Tensor, win: Optional[int] = None, comm=None,
+                     Ttotal: Optional[int] = None, f0: int = 0) -> ClipState:
+    """fea272 (272, h, w) = cat[fea, bbox_mask] (MT:1151) in reference layout; cond (F, cond_dim)."""
+    win = P.win if win is None else win
+    Cf, h, w = fea272.shape
+    F = cond.shape[0]
+    fea_cl = fea272.permute(1, 2, 0).reshape(h * w, Cf).contiguous()          # layout change only
+    fea_pre = ops.conv_gemm(fea_cl, P.wfea, P.dim, F=1, Hi=h, Wi=w, KH=7, KW=7, pad=3, bias=P.b_init)
+    kvtabs, nulltabs = [None] * P.n_cond_blocks, [None] * P.n_cond_blocks
+    n_aud, n_pose, _ = P.cond_dims
+    cols = {"aud": (0, n_aud), "pose": (n_aud, n_aud + n_pose), "eye": (n_aud + n_pose, cond.shape[1])}
+    from .pack import BRANCHES
+    for rb in _conditioned_blocks(P):
+        kvtab = torch.empty(F, 3, 128, device=cond.device, dtype=torch.float32)
+        nulltab = torch.empty(3, 16, device=cond.device, dtype=torch.float32)
+        for b, br in enumerate(BRANCHES):
+            c0, c1 = cols[br]
+            ctx = ops.linear(cond[:, c0:c1], rb.mlp_w[b], rb.mlp_b[b], act_in=1)      # SiLU -> Linear
+            kv = ops.linear(ctx, rb.kv_w[b], None)
+            ops.xattn_prep(kv, rb.k_scale[b], rb.null_kv[b], kvtab, b, nulltab)
+        kvtabs[rb.cond_index], nulltabs[rb.cond_index] = kvtab, nulltab
+    rcos, rsin = P.rotary_tables(F + 2 * win)
+    return ClipState(F=F, Ttotal=F if Ttotal is None else Ttotal, f0=f0, h=h, w=w, fea_pre=fea_pre, kvtab=kvtabs,
+                     nulltab=nulltabs, rcos=rcos, rsin=rsin, band=P.band(win), win=win, comm=comm)
+
+
+def _conditioned_blocks(P: PackedUNet):
+    for lvl in P.downs:
+        yield lvl["rb1"]
+        yield lvl["rb2"]
+    yield P.mid["rb1"]
+    yield P.mid["rb2"]
+    for lvl in P.ups:
+        yield lvl["rb1"]
+        yield lvl["rb2"]
+
+
+def time_film(ops, P: PackedUNet, t: float, like: Tensor) -> Tensor:
+    """time_mlp (MT:789-794) then every block's SiLU->Linear(256, 2*Co) (MT:366-369) in one GEMV."""
+    e = ops.sinusoidal(float(t), P.t_w1.shape[1], like)
+    e = ops.linear(e, P.t_w1, P.t_b1)
+    e = ops.linear(e, P.t_w2, P.t_b2, act_in=2)            # exact GELU on the input of the 2nd Linear
+    return ops.linear(e, P.film_w, P.film_b, act_in=1).reshape(-1)
+
+
+def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, H: int, W: int, film_all: Tensor,
+              cs: ClipState) -> Tensor:
+    Co = rb.Co
+    total_rows = cs.Ttotal * H * W
+    g = dict(F=F, Hi=H, Wi=W)
+    hcond, film = None, None
+    if rb.conditioned:
+        stats = ops.ln_rowstats(x, x2)
+        q = ops.conv_gemm(x, rb.wq, 192, in1=x2, row_stats=stats, **g)
+        ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)
+        y3 = ops.empty(F * H * W, 3 * Co, like=x)
+        for b in range(3):
+            ops.conv_gemm(q[:, 64 * b:64 * b + 64], rb.wo[b], Co, out=y3[:, b * Co:(b + 1) * Co], **g)
+        hcond = ops.xattn_ln_sum(y3, rb.g3, Co)
+        film = (film_all[rb.film_off:rb.film_off + Co], film_all[rb.film_off + Co:rb.film_off + 2 * Co])
+    c1 = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, **g)
+    ab1 = ops.gn_coeffs(c1, rb.g1, rb.be1, film, total_rows)
+    c2 = ops.conv_gemm(c1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, ch_ab=ab1, pro_act=1, pro_add=hcond, **g)
+    a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows)
+    if rb.wr is not None:
+        return ops.conv_gemm(x, rb.wr, Co, in1=x2, bias=rb.br, tr=(c2, a2, b2), **g)
+    assert x2 is None
+    return ops.gn_apply_res(c2, a2, b2, x)
+
+
+def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState) -> Tensor:
+    HW = H * W
+    if cs.comm is not None:
+        xe, q0 = cs.comm.halo_exchange(x, HW, cs.win)      # (Fext*HW, C), first own frame index
+    else:
+        xe, q0 = x, 0
+    Fext = xe.shape[0] // HW
+    stats = ops.ln_rowstats(xe)
+    qkv = ops.conv_gemm(xe, a.wqkv, 768, row_stats=stats, F=Fext, Hi=H, Wi=W)
+    o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)
+    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W)
+
+
+def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
+    stats = ops.ln_rowstats(x)
+    qkv = ops.conv_gemm(x, a.wqkv, 768, row_stats=stats, F=F, Hi=H, Wi=W)
+    o = ops.sla(qkv, F, H * W)
+    return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W)
+
+
+def _mid_spatial(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
+    stats = ops.ln_rowstats(x)
+    qkv = ops.conv_gemm(x, a.wqkv, 768, row_stats=stats, F=F, Hi=H, Wi=W)
+    o = ops.frame_attn(qkv, F, H * W)
+    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W)
+
+
+def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float) -> Tensor:
+    """x3 (3, F, h, w) latent of one clip in reference layout, t the integer diffusion time ->
+    predicted noise (3, F, h, w).  Equivalent to Unet3D.forward(cat[x, fea], t, cond) with
+    null_cond_prob = 0 (MT:892-956)."""
+    F, H, W = cs.F, cs.h, cs.w
+    film_all = time_film(ops, P, t, cs.fea_pre)
+    r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
+    x = _temporal(ops, P.init_tattn, r, F, H, W, cs)
+    skips: List[Tuple[Tensor, int, int]] = []
+    for lvl in P.downs:
+        x = _resblock(ops, lvl["rb1"], x, None, F, H, W, film_all, cs)
+        x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)
+        x = _spatial_linear(ops, lvl["sla"], x, F, H, W)
+        x = _temporal(ops, lvl["tattn"], x, F, H, W, cs)
+        skips.append((x, H, W))
+        if lvl["down"] is not None:
+            wd, bd = lvl["down"]
+            x = ops.conv_gemm(x, wd, x.shape[1], F=F, Hi=H, Wi=W, Ho=H // 2, Wo=W // 2, KH=4, KW=4, stride=2, pad=1,
+                              bias=bd)
+            H, W = H // 2, W // 2
+    x = _resblock(ops, P.mid["rb1"], x, None, F, H, W, film_all, cs)
+    x = _mid_spatial(ops, P.mid["sattn"], x, F, H, W)
+    x = _temporal(ops, P.mid["tattn"], x, F, H, W, cs)
+    x = _resblock(ops, P.mid["rb2"], x, None, F, H, W, film_all, cs)
+    for lvl in P.ups:
+        skip, sh, sw = skips.pop()
+        assert (sh, sw) == (H, W)
+        x = _resblock(ops, lvl["rb1"], x, skip, F, H, W, film_all, cs)       # torch.cat((x, h.pop())) MT:948
+        x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)
+        x = _spatial_linear(ops, lvl["sla"], x, F, H, W)
+        x = _temporal(ops, lvl["tattn"], x, F, H, W, cs)
+        if lvl["up"] is not None:
+            wu, bu = lvl["up"]
+            x = ops.conv_gemm(x, wu, x.shape[1], F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=bu)
+            H, W = 2 * H, 2 * W
+    hg = _resblock(ops, P.head_g, x, r, F, H, W, film_all, cs)               # torch.cat((x, r)) MT:955
+    ho = _resblock(ops, P.head_o, x, r, F, H, W, film_all, cs)
+    eps = ops.head_out(hg, ho, P.wg, P.bg, P.wo, P.bo)                        # (3, rows)
+    return eps.reshape(3, F, H, W)

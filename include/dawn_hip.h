@@ -1,0 +1,132 @@
+/* dawn_hip.h -- C ABI of libdawn_hip.so: the MI355X (gfx950) kernels behind DAWN's
+ * video-flow-diffusion denoising path.
+ *
+ * The reference (Hanbo-Cheng/DAWN-pytorch) has no FFI layer on this path: every op is a stock
+ * PyTorch call inside Python modules.  Each entry point below therefore cites the reference
+ * Python symbol (file:line, abbreviations of SURVEY.md: MT = DM_3/modules/
+ * video_flow_diffusion_multiGPU_v0_crema_plus_faceemb_ca_multi_test.py, LA = DM_3/modules/
+ * local_attention.py) whose arithmetic it replaces.  The Python host side in
+ * dawn-pytorch_amd/ binds these with ctypes.
+ *
+ * Conventions
+ *  - plain pointers + sizes, no torch types; all pointers are DEVICE pointers unless noted;
+ *  - every launch goes to the caller's hipStream_t (`stream`, passed as void*); nothing allocates,
+ *    nothing synchronises; workspaces are caller-provided;
+ *  - return 0 on success, non-zero on error (dawn_last_error() gives the text); never throws;
+ *  - activations are fp32, channels-last per clip: (F frames, H, W, C) row-major, "row" = one
+ *    pixel of one frame; the API tensors x / eps keep the reference layout (3, F, h, w).
+ */
+#ifndef DAWN_HIP_H
+#define DAWN_HIP_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+const char* dawn_last_error(void);
+int dawn_abi_version(void);
+
+/* ---- A1/A2/A4/A12/A13 + every Linear: implicit-GEMM convolution on fp32 MFMA ---------------
+ * out[row][n] = bias[n] + sum_{tap,c} P(in[pixel(row)+tap][c]) * W[tap][c][n]  (+ epilogue terms)
+ * Replaces nn.Conv3d (1,k,k) per frame (MT:229 Block.proj, MT:417 res_conv, MT:176 Downsample,
+ * MT:776 init_conv fea part), nn.ConvTranspose3d (MT:167 Upsample; mode 1) and nn.Linear /
+ * 1x1 Conv2d projections (MT:505,512,608,609,662,663) with the PreNorm / GroupNorm-apply that
+ * precedes them fused as prologue P and the residual that follows fused as epilogue. */
+typedef struct dawn_conv_desc {
+    const float* in0; const float* in1; /* NHWC sources; in1 may be NULL; channels = [in0 | in1] */
+    int C0, C1, ld0, ld1;               /* channels per source, pixel stride (floats) per source */
+    int F, Hi, Wi, Ho, Wo;
+    int KH, KW, stride, pad;
+    int mode;                           /* 0 = conv, 1 = transposed 4x4/s2/p1 as 4 output phases of 2x2 taps */
+    const float* w;                     /* packed [K/4][N][4], k = tap*(C0+C1)+c; mode 1: 4 consecutive phase blocks */
+    const float* bias;                  /* N or NULL */
+    int N;
+    const float* row_mean; const float* row_rstd; /* per INPUT pixel: v=(v-mean)*rstd, or NULL */
+    const float* ch_a; const float* ch_b;         /* per input channel: v=v*a[c]+b[c], or NULL */
+    int pro_act;                                   /* 0 none, 1 SiLU (applied after the affine) */
+    const float* pro_add; int ld_add;              /* added after the activation, or NULL */
+    const float* res; int ld_res;                  /* epilogue: out += res[row][n], or NULL */
+    const float* tr; int ld_tr;                    /* epilogue: out += silu(tr[row][n]*tr_a[n]+tr_b[n]) */
+    const float* tr_a; const float* tr_b;
+    float* out; int ld_out;
+} dawn_conv_desc;
+int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
+
+/* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --
+ * partial: per-block fp64 (sum, sumsq) per group -> part[nblk][16]; reduce: fixed-order sum ->
+ * sums[16] (all-reduced across T-shards by the caller); finalize: per-channel fused coefficients
+ *   a[c] = rstd*gamma*(fs+1), b[c] = (beta-mean*rstd*gamma)*(fs+1)+fsh   (FiLM fs/fsh optional, MT:237-239) */
+int dawn_gn_partial(const float* x, long rows, int C, int ld, double* part, int nblk, void* stream);
+int dawn_gn_reduce(const double* part, int nblk, double* sums16, void* stream);
+int dawn_gn_finalize(const double* sums16, double count_per_group, const float* gamma, const float* beta,
+                     const float* film_scale, const float* film_shift, int C, float eps,
+                     float* a, float* b, void* stream);
+/* out = silu(x*a[c]+b[c]) + res   (Block.act MT:248 + residual add MT:479) */
+int dawn_gn_apply_res(const float* x, const float* a, const float* b, const float* res, float* out,
+                      long rows, int C, void* stream);
+
+/* ---- PreNorm LayerNorm / LayerNorm_img statistics per pixel over [in0|in1] channels (MT:179-203) */
+int dawn_ln_rowstats(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
+                     float eps, float* mean, float* rstd, void* stream);
+
+/* ---- A5 tri-modal CrossAttention (MT:516-559) ------------------------------------------------
+ * prep (once per clip): kv (F,128) from to_kv -> kvtab[f][branch] = [l2norm(k_h)*k_scale | v]  */
+int dawn_xattn_prep(const float* kv, int F, const float* k_scale, const float* null_kv,
+                    float* kvtab, int branch, float* nulltab, void* stream);
+/* core: q (rows,192)=[branch][head][8] -> o (rows,192): 2-key cosine-sim softmax == sigmoid lerp */
+int dawn_xattn_core(const float* q, float* o, long rows, int HW, const float* kvtab, const float* nulltab,
+                    const float* q_scale, void* stream);
+/* h_cond[row][c] = sum_b LayerNorm_img(y3[row][b][:])[c] * g[b][c]   (to_out.1, MT:513; sum MT:463) */
+int dawn_xattn_ln_sum(const float* y3, const float* g3, float* out, long rows, int Co, float eps, void* stream);
+
+/* ---- A9/A10 windowed temporal self-attention per pixel (MT:665-725 with the MT:117 window mask,
+ * == LA:71-99/300-342).  qkv (Fext*HW, 768) = [q|k|v][head 8][32]; queries are frames
+ * [q0, q0+Fq) of the buffer, keys every buffer frame within +-win; rotary (interleaved pairs)
+ * from cos/sin tables (Fext,16); band[(2*win+1)][8] = relative-position bias by offset j-i. */
+int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, int Fq, int win,
+                       const float* rot_cos, const float* rot_sin, const float* band,
+                       float* out, void* stream);
+
+/* ---- A8 SpatialLinearAttention core (MT:611-627) ---------------------------------------------- */
+int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);     /* ctx (F,8,32,32) */
+int dawn_sla_apply(const float* qkv, const float* ctx, int F, int HW, float* out, void* stream); /* out (F*HW,256) */
+
+/* ---- A11 mid spatial attention: full softmax attention over the HW tokens of a frame (MT:841-843) */
+int dawn_frame_attn(const float* qkv, int F, int N, float* out, void* stream);
+
+/* ---- A1 x-part of init_conv (3 of 275 channels) + hoisted fea part + bias (MT:776-777, 910) ------
+ * x (3,F,h,w) reference layout; w3 [7*7*3][Co] ; fea_pre (h,w,Co) = conv7x7(fea272)+bias; out (F,h,w,Co) */
+int dawn_init_conv_x(const float* x, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
+                     float* out, void* stream);
+/* ---- A13 heads: two 1x1 convs (Co->2, Co->1) + concat, written as (3,F,h,w) (MT:863,876,956) ------ */
+int dawn_head_out(const float* hg, const float* ho, const float* wg, const float* bg, const float* wo,
+                  const float* bo, long rows, int Co, float* eps_out, void* stream);
+
+/* ---- small dense ops: time / condition MLPs (MT:366-384, 789-794) ----------------------------- */
+/* out[m][n] = bias[n] + sum_k act(in[m][k]) * W[n][k];  act_in: 0 none, 1 SiLU, 2 exact GELU */
+int dawn_linear(const float* in, int M, int K, int ld_in, const float* W, const float* bias, int N,
+                int act_in, float* out, int ld_out, void* stream);
+int dawn_sinusoidal(float t, int dim, float* out, void* stream);                       /* MT:150-162 */
+
+/* ---- A0 DDIM sampler step pieces (MT:1169-1205) ------------------------------------------------ */
+/* x0 = recip*x - recipm1*eps ; also histogram of the top 11 bits of |x0| into hist[2048] */
+int dawn_ddim_x0(const float* x, const float* eps, float recip, float recipm1, long n, float* x0,
+                 unsigned* hist, void* stream);
+/* radix-select helpers for the exact 0.9-quantile of |x0| (torch.quantile, linear interpolation) */
+int dawn_select_scan(const unsigned* hist, int nbins, unsigned long long rank, unsigned* state, int pass,
+                     void* stream);
+int dawn_select_hist(const float* x0, long n, const unsigned* state, int pass, unsigned* hist, void* stream);
+int dawn_select_finalize(const unsigned* state, const unsigned* hist3, float weight, float* s_out, void* stream);
+/* x = clamp(x0,-s,s)/s*sqrt_alpha_next + c*eps + sigma*noise   (noise may be NULL) */
+int dawn_ddim_update(const float* x0, const float* eps, const float* s, const float* noise,
+                     float sqrt_alpha_next, float c, float sigma, long n, float* x, void* stream);
+/* classifier-free guidance (Unet3D.forward_with_cond_scale MT:889-890): out = null + (cond-null)*scale */
+int dawn_cfg_combine(const float* e_null, const float* e_cond, float scale, long n, float* out, void* stream);
+/* counter-based N(0,1): Philox4x32-10 keyed by seed, counter = (stream_id, global element index / 4) */
+int dawn_philox_normal(float* out, int C, int F, int f0, int Ftotal, int hw, uint64_t seed, uint32_t stream_id,
+                       void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

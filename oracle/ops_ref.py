@@ -1,0 +1,274 @@
+"""Op-level torch references with the SAME interface as dawn_pytorch_amd.ops.HipOps.
+
+TEST INFRASTRUCTURE ONLY (see oracle/dawn_oracle.py header).  Two uses:
+  * tests inject `RefOps` into the product's orchestration (unet_forward / sampler / tshard) to check the
+    host logic + weight packing on CPU against the end-to-end oracle and the reference goldens;
+  * `-m gpu` tests compare every HIP kernel against the method of the same name here.
+Each method states the op's contract in the internal channels-last `(rows, C)` layout; the arithmetic
+follows the reference lines cited in include/dawn_hip.h.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+import torch.nn.functional as F_
+
+Tensor = torch.Tensor
+
+
+def _unpack(wp: Tensor) -> Tensor:
+    K4, N, _ = wp.shape
+    return wp.permute(0, 2, 1).reshape(K4 * 4, N)
+
+
+class RefOps:
+    name = "ref"
+
+    def __init__(self, comm=None):
+        self.comm = comm
+
+    def empty(self, *shape, like: Tensor, dtype=torch.float32) -> Tensor:
+        return torch.zeros(*shape, device=like.device, dtype=dtype)
+
+    # ------------------------------------------------------------------ conv / linear
+    def conv_gemm(self, in0, w, N, *, F, Hi, Wi, Ho=None, Wo=None, KH=1, KW=1, stride=1, pad=0, mode=0, in1=None,
+                  bias=None, row_stats=None, ch_ab=None, pro_act=0, pro_add=None, res=None, tr=None, out=None):
+        Ho = Hi if Ho is None else Ho
+        Wo = Wi if Wo is None else Wo
+        x = in0 if in1 is None else torch.cat((in0, in1), dim=1)
+        Cin = x.shape[1]
+        if row_stats is not None:
+            x = (x - row_stats[0][:, None]) * row_stats[1][:, None]
+        if ch_ab is not None:
+            x = x * ch_ab[0][None, :] + ch_ab[1][None, :]
+        if pro_act:
+            x = F_.silu(x)
+        if pro_add is not None:
+            x = x + pro_add
+        img = x.reshape(F, Hi, Wi, Cin).permute(0, 3, 1, 2)
+        if mode == 0:
+            wk = _unpack(w).reshape(KH, KW, Cin, N).permute(3, 2, 0, 1)
+            y = F_.conv2d(img, wk, None, stride=stride, padding=pad)
+        else:
+            # 4 phase blocks (py,px) of 2x2 taps -> rebuild the ConvTranspose2d kernel (Cin, N, 4, 4)
+            ksel = ((1, 3), (2, 0))
+            wt = torch.zeros(Cin, N, 4, 4, device=x.device)
+            for ph in range(4):
+                py, px = ph >> 1, ph & 1
+                blk = _unpack(w[ph]).reshape(2, 2, Cin, N)
+                for ty in range(2):
+                    for tx in range(2):
+                        wt[:, :, ksel[py][ty], ksel[px][tx]] = blk[ty, tx]
+            y = F_.conv_transpose2d(img, wt, None, stride=2, padding=1)
+        assert y.shape[-2:] == (Ho, Wo), (y.shape, Ho, Wo)
+        y = y.permute(0, 2, 3, 1).reshape(F * Ho * Wo, N)
+        if bias is not None:
+            y = y + bias
+        if res is not None:
+            y = y + res
+        if tr is not None:
+            y = y + F_.silu(tr[0] * tr[1][None, :] + tr[2][None, :])
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y.contiguous()
+
+    # ------------------------------------------------------------------ norms
+    def gn_coeffs(self, x, gamma, beta, film, total_rows, eps=1e-5):
+        rows, C = x.shape
+        xg = x.double().reshape(rows, 8, C // 8)
+        sums = torch.stack((xg.sum(dim=(0, 2)), (xg * xg).sum(dim=(0, 2))), dim=1).reshape(16)
+        if self.comm is not None:
+            self.comm.all_reduce_sum(sums)
+        sums = sums.reshape(8, 2)
+        cnt = float(total_rows) * (C // 8)
+        mean = sums[:, 0] / cnt
+        var = (sums[:, 1] / cnt - mean * mean).clamp(min=0)
+        rstd = (1.0 / torch.sqrt(var + eps)).float().repeat_interleave(C // 8)
+        mu = mean.float().repeat_interleave(C // 8)
+        a = rstd * gamma
+        b = beta - mu * a
+        if film is not None:
+            sc = film[0] + 1.0
+            a = a * sc
+            b = b * sc + film[1]
+        return a, b
+
+    def gn_apply_res(self, x, a, b, res):
+        y = F_.silu(x * a[None, :] + b[None, :])
+        return y if res is None else y + res
+
+    def ln_rowstats(self, in0, in1=None, eps=1e-5):
+        x = in0 if in1 is None else torch.cat((in0, in1), dim=1)
+        mean = x.mean(dim=1)
+        var = x.var(dim=1, unbiased=False)
+        return mean, 1.0 / torch.sqrt(var + eps)
+
+    # ------------------------------------------------------------------ cross attention
+    def xattn_prep(self, kv, k_scale, null_kv, kvtab, branch, nulltab):
+        Fn = kv.shape[0]
+        k = kv[:, :64].reshape(Fn, 8, 8)
+        k = F_.normalize(k, dim=-1) * k_scale
+        kvtab[:, branch, :64] = k.reshape(Fn, 64)
+        kvtab[:, branch, 64:] = kv[:, 64:]
+        nulltab[branch, :8] = F_.normalize(null_kv[0], dim=-1) * k_scale
+        nulltab[branch, 8:] = null_kv[1]
+
+    def xattn_core(self, q, HW, kvtab, nulltab, q_scale):
+        rows = q.shape[0]
+        f = torch.arange(rows, device=q.device) // HW
+        qq = q.reshape(rows, 3, 8, 8)
+        qn = F_.normalize(qq, dim=-1) * q_scale[None, :, None, :]
+        kc = kvtab[f][:, :, :64].reshape(rows, 3, 8, 8)
+        vc = kvtab[f][:, :, 64:].reshape(rows, 3, 8, 8)
+        kn = nulltab[:, :8][None, :, None, :]
+        vn = nulltab[:, 8:][None, :, None, :]
+        sn = (qn * kn).sum(-1) * 8.0
+        sc = (qn * kc).sum(-1) * 8.0
+        att = torch.stack((sn, sc), dim=-1).softmax(dim=-1)
+        o = att[..., 0:1] * vn + att[..., 1:2] * vc
+        q.copy_(o.reshape(rows, 192))
+        return q
+
+    def xattn_ln_sum(self, y3, g3, Co, eps=1e-5):
+        rows = y3.shape[0]
+        y = y3.reshape(rows, 3, Co)
+        mean = y.mean(dim=-1, keepdim=True)
+        var = y.var(dim=-1, unbiased=False, keepdim=True)
+        return ((y - mean) * torch.rsqrt(var + eps) * g3[None]).sum(dim=1)
+
+    # ------------------------------------------------------------------ attention cores
+    def temporal_attn(self, qkv, Fext, HW, q0, Fq, win, rcos, rsin, band):
+        x = qkv.reshape(Fext, HW, 3, 8, 32)
+        q = x[:, :, 0].permute(1, 2, 0, 3) * 32 ** -0.5          # (HW, 8, Fext, 32)
+        k = x[:, :, 1].permute(1, 2, 0, 3)
+        v = x[:, :, 2].permute(1, 2, 0, 3)
+
+        def rot(t):
+            c, s = rcos[:Fext], rsin[:Fext]
+            t1, t2 = t[..., 0::2], t[..., 1::2]
+            return torch.stack((t1 * c - t2 * s, t2 * c + t1 * s), dim=-1).flatten(-2)
+
+        q, k = rot(q)[:, :, q0:q0 + Fq], rot(k)
+        i = torch.arange(q0, q0 + Fq, device=qkv.device)
+        j = torch.arange(Fext, device=qkv.device)
+        rel = j[None, :] - i[:, None]
+        inside = rel.abs() <= win
+        bias = band[(rel.clamp(-win, win) + win)].permute(2, 0, 1)           # (8, Fq, Fext)
+        sim = torch.einsum("nhid,nhjd->nhij", q, k) + bias[None]
+        sim = sim.masked_fill(~inside[None, None], float("-inf"))
+        att = sim.softmax(dim=-1)
+        o = torch.einsum("nhij,nhjd->nhid", att, v)                          # (HW, 8, Fq, 32)
+        return o.permute(2, 0, 1, 3).reshape(Fq * HW, 256).contiguous()
+
+    def sla(self, qkv, F, HW):
+        x = qkv.reshape(F, HW, 3, 8, 32)
+        q = x[:, :, 0].permute(0, 2, 3, 1)                                   # (F, 8, 32, HW)
+        k = x[:, :, 1].permute(0, 2, 3, 1)
+        v = x[:, :, 2].permute(0, 2, 3, 1)
+        q = q.softmax(dim=-2) * 32 ** -0.5
+        k = k.softmax(dim=-1)
+        ctx = torch.einsum("fhdn,fhen->fhde", k, v)
+        o = torch.einsum("fhde,fhdn->fhen", ctx, q)                          # (F, 8, 32, HW)
+        return o.permute(0, 3, 1, 2).reshape(F * HW, 256).contiguous()
+
+    def frame_attn(self, qkv, F, N):
+        x = qkv.reshape(F, N, 3, 8, 32)
+        q = x[:, :, 0].permute(0, 2, 1, 3) * 32 ** -0.5
+        k = x[:, :, 1].permute(0, 2, 1, 3)
+        v = x[:, :, 2].permute(0, 2, 1, 3)
+        att = torch.einsum("fhid,fhjd->fhij", q, k).softmax(dim=-1)
+        o = torch.einsum("fhij,fhjd->fhid", att, v)
+        return o.permute(0, 2, 1, 3).reshape(F * N, 256).contiguous()
+
+    # ------------------------------------------------------------------ boundary ops
+    def init_conv_x(self, x, w3, fea_pre, F, h, w, Co):
+        wk = w3.reshape(7, 7, 3, Co).permute(3, 2, 0, 1)
+        y = F_.conv2d(x.permute(1, 0, 2, 3), wk, None, padding=3)            # (F, Co, h, w)
+        y = y.permute(0, 2, 3, 1).reshape(F, h * w, Co) + fea_pre[None]
+        return y.reshape(F * h * w, Co).contiguous()
+
+    def head_out(self, hg, ho, wg, bg, wo, bo):
+        return torch.cat((hg @ wg.t() + bg, ho @ wo.t() + bo), dim=1).t().contiguous()
+
+    def linear(self, x, W, bias, act_in=0, out=None):
+        if act_in == 1:
+            x = F_.silu(x)
+        elif act_in == 2:
+            x = F_.gelu(x)
+        y = F_.linear(x, W, bias)
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def sinusoidal(self, t, dim, like):
+        half = dim // 2
+        f = torch.exp(torch.arange(half, dtype=torch.float32, device=like.device) * -(math.log(10000) / (half - 1)))
+        e = torch.tensor([float(t)], dtype=torch.float32, device=like.device)[:, None] * f[None, :]
+        return torch.cat((e.sin(), e.cos()), dim=-1)
+
+    # ------------------------------------------------------------------ sampler
+    def ddim_x0(self, x, eps, recip, recipm1):
+        x0 = recip * x - recipm1 * eps
+        bits = x0.abs().contiguous().view(torch.int32)
+        hist = torch.bincount((bits >> 20).flatten().long(), minlength=2048).to(torch.int32)
+        return x0, hist
+
+    def quantile_threshold(self, x0, hist1, n_total, q=0.9):
+        """Exact linear-interpolated order statistic (== torch.quantile for n <= 2^24), written via a
+        full sort; with a communicator the shards' |x0| are gathered first."""
+        v = x0.abs().flatten()
+        if self.comm is not None:
+            v = self.comm.all_gather_cat(v)
+        pos = np.float32(q) * np.float32(n_total - 1)
+        lo = int(np.floor(pos))
+        wgt = float(np.float32(pos) - np.float32(lo))
+        sv = torch.sort(v).values
+        a, b = sv[lo], sv[min(lo + 1, sv.numel() - 1)]
+        qv = torch.lerp(a, b, torch.tensor(wgt, dtype=torch.float32, device=v.device))
+        return torch.stack((qv.clamp(min=1.0), qv))
+
+    def ddim_update(self, x0, eps, s, noise, sqrt_alpha_next, c, sigma):
+        sv = s[0]
+        x = torch.minimum(torch.maximum(x0, -sv), sv) / sv * sqrt_alpha_next + c * eps
+        if noise is not None:
+            x = x + sigma * noise
+        return x
+
+    def cfg_combine(self, e_null, e_cond, scale):
+        return e_null + (e_cond - e_null) * scale
+
+    def philox_normal(self, Cc, F, f0, Ftotal, hw, seed, stream_id, device):
+        """Bit-level restatement of the kernel's Philox4x32-10 + Box-Muller (numpy uint64 arithmetic)."""
+        qpf = hw // 4
+        c = np.arange(Cc, dtype=np.uint64)[:, None, None]
+        f = (np.arange(F, dtype=np.uint64) + np.uint64(f0))[None, :, None]
+        qd = np.arange(qpf, dtype=np.uint64)[None, None, :]
+        gq = (c * np.uint64(Ftotal) + f) * np.uint64(qpf) + qd
+        M32 = np.uint64(0xFFFFFFFF)
+        c0, c1 = gq & M32, gq >> np.uint64(32)
+        c2 = np.full_like(gq, stream_id)
+        c3 = np.full_like(gq, 0x44415757)
+        k0, k1 = np.uint64(seed & 0xFFFFFFFF), np.uint64((seed >> 32) & 0xFFFFFFFF)
+        for _ in range(10):
+            p0 = np.uint64(0xD2511F53) * c0
+            p1 = np.uint64(0xCD9E8D57) * c2
+            n0 = (p1 >> np.uint64(32)) ^ c1 ^ k0
+            n1 = p1 & M32
+            n2 = (p0 >> np.uint64(32)) ^ c3 ^ k1
+            n3 = p0 & M32
+            c0, c1, c2, c3 = n0, n1, n2, n3
+            k0 = (k0 + np.uint64(0x9E3779B9)) & M32
+            k1 = (k1 + np.uint64(0xBB67AE85)) & M32
+        two32 = np.float32(2.3283064365386963e-10)
+        u = [((ci.astype(np.float32) + np.float32(0.5)) * two32) for ci in (c0, c1, c2, c3)]
+        r0 = np.sqrt(np.float32(-2.0) * np.log(np.clip(u[0], 1e-10, 1.0)))
+        r1 = np.sqrt(np.float32(-2.0) * np.log(np.clip(u[2], 1e-10, 1.0)))
+        a0 = np.float32(6.283185307179586) * u[1]
+        a1 = np.float32(6.283185307179586) * u[3]
+        out = np.stack((r0 * np.cos(a0), r0 * np.sin(a0), r1 * np.cos(a1), r1 * np.sin(a1)), axis=-1)
+        return torch.from_numpy(out.reshape(Cc, F, hw).astype(np.float32)).to(device)

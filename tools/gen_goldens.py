@@ -100,7 +100,9 @@ def gen_tiny_unet():
     unet_l.load_state_dict(unet.state_dict())
     g = torch.Generator().manual_seed(123)
     T, h = 12, 8
-    x = torch.randn(1, 19, T, h, h, generator=g)
+    # fea/bbox channels are frame-invariant by construction of ddim_sample (MT:1167, 1177)
+    x = torch.cat((torch.randn(1, 3, T, h, h, generator=g),
+                   torch.randn(1, 16, 1, h, h, generator=g).expand(-1, -1, T, -1, -1)), dim=1).contiguous()
     cond = torch.randn(1, T, 32, generator=g)
     time = torch.tensor([627])
 
@@ -141,7 +143,8 @@ def gen_tiny_unet():
     g = torch.Generator().manual_seed(7)
     T2 = 24
     unet.update_num_frames(T2)
-    x2 = torch.randn(1, 19, T2, 8, 8, generator=g)
+    x2 = torch.cat((torch.randn(1, 3, T2, 8, 8, generator=g),
+                    torch.randn(1, 16, 1, 8, 8, generator=g).expand(-1, -1, T2, -1, -1)), dim=1).contiguous()
     c2 = torch.randn(1, T2, 32, generator=g)
     y2 = unet.forward_with_cond_scale(x2, torch.tensor([39]), cond=c2, cond_scale=1.0)
     save("tiny_unet_T24.npz", x=x2.numpy(), cond=c2.numpy(), time=np.array([39]), y=y2.numpy())
