@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""Benchmark of the DAWN denoising path on MI355X: generated frames/sec at 256x256, 50 DDIM steps.
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input = ONE whole clip generation
+(`GaussianDiffusion.sample`: 50 DDIM steps x one UNet evaluation each + dynamic-threshold quantile + DDIM
+update) of a 200-frame 256x256 clip (BASELINE.json configs[2], 64x64 latent).  Inputs (random-init
+weights of the real DAWN_256 architecture, fea / bbox / cond / Philox noise) are resident in HBM before
+the timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU):
+  --mode tshard  (default): ONE clip of 200*N frames sharded along T, RCCL halo exchange + tiny
+                 GroupNorm / quantile all-reduces (BASELINE configs[3] shape per GPU) -- weak scaling;
+  --mode replica: N independent 200-frame clips, no collective (configs[4]) -- weak scaling.
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` (dominant kernel =
+fp32-MFMA implicit-GEMM conv, timed live with HIP events on the launch stream) and `cpu_baseline`
+(the CPU oracle on the host cores, bounded sample)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+UNET_KW = dict(dim=64, cond_dim=1032, cond_aud=1024, cond_pose=6, cond_eye=2, channels=275, out_grid_dim=2,
+               out_conf_dim=1, dim_mults=(1, 2, 4, 8), use_hubert_audio_cond=True, learn_null_cond=False,
+               use_final_activation=False, use_deconv=True, padding_mode="zeros", win_width=40)
+
+
+def algorithmic_flops_per_forward(T: int, h: int, w: int = 40) -> float:
+    """F(T,h) = a_h*T + b_h*(T*(2w+1) - w(w+1)) (T > 2w), reference-equivalent dense math."""
+    a = 6.25e9 * (h / 32) ** 2
+    b = 3.85e6 * (h / 32) ** 2
+    pairs = T * (2 * w + 1) - w * (w + 1) if T > 2 * w else T * T
+    return a * T + b * pairs
+
+
+def build_model(T, h, S, device, seed_weights=0):
+    import dawn_pytorch_amd as D
+    unet = D.DynamicNfUnet3D(default_num_frames=T, num_frames=T, init_seed=seed_weights, **UNET_KW)
+    diff = D.DynamicNfGaussianDiffusion(default_num_frames=T, denoise_fn=unet, num_frames=T, image_size=h,
+                                        sampling_timesteps=S, timesteps=1000, loss_type='l2', use_dynamic_thres=True,
+                                        null_cond_prob=0.1, ddim_sampling_eta=1.0)
+    return unet, diff.to(device)
+
+
+def synthetic_inputs(T, h, device, seed=123, f0=0, Ttotal=None):
+    """fea ~ N(0,1) (1,256,h,w), bbox_mask ~ N(0,1) (1,16,h,w), cond ~ N(0,1) (1,T,1032).
+    cond is generated for the whole clip and sliced so that T-shards see the same data."""
+    g = torch.Generator().manual_seed(seed)
+    fea = torch.randn(1, 256, h, h, generator=g)
+    bbox = torch.randn(1, 16, h, h, generator=g)
+    Ttotal = T if Ttotal is None else Ttotal
+    cond = torch.randn(1, Ttotal, 1032, generator=g)[:, f0:f0 + T]
+    return fea.to(device), bbox.to(device), cond.contiguous().to(device)
+
+
+def cpu_baseline(h, S, sample_frames, unet_cpu_sd):
+    """The CPU oracle (oracle/dawn_oracle.py, kind "port": the reference is Python and does not travel)
+    timed on this box's host cores on a bounded sample: ONE UNet evaluation + sampler epilogue on
+    `sample_frames` frames at the benchmark resolution; frames/s = frames / (S * t_step)."""
+    from oracle import dawn_oracle as O
+    g = torch.Generator().manual_seed(123)
+    Ts = sample_frames
+    fea = torch.randn(1, 272, h, h, generator=g)
+    cond = torch.randn(1, Ts, 1032, generator=g)
+    x = torch.randn(1, 3, Ts, h, h, generator=g)
+    xin = torch.cat((x, fea.unsqueeze(2).expand(-1, -1, Ts, -1, -1)), 1)
+    with torch.no_grad():
+        t0 = time.time()
+        eps = O.unet_forward(unet_cpu_sd, xin, torch.tensor([980]), cond, win=40)
+        x0 = 1.1 * x - 0.3 * eps
+        x0, s = O.dynamic_threshold(x0)
+        _ = x0 * 0.9 + 0.1 * eps
+        dt = time.time() - t0
+    return {"value": Ts / (S * dt), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"1 UNet evaluation + threshold/update on {Ts} frames @ {h * 4}x{h * 4} "
+                      f"({dt:.1f} s), extrapolated to {S} DDIM steps"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--frames", type=int, default=200, help="frames per GPU")
+    ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--ddim-steps", type=int, default=50)
+    ap.add_argument("--mode", choices=["tshard", "replica"], default="tshard")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-frames", type=int, default=8)
+    ap.add_argument("--no-kernel-events", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=device)
+
+    T, h, S = args.frames, args.res // 4, args.ddim_steps
+    comm, mode = None, "single"
+    Ttotal, f0 = T, 0
+    if world > 1:
+        mode = args.mode
+        if mode == "tshard":
+            from dawn_pytorch_amd.tshard import TShardComm
+            Ttotal, f0 = T * world, T * rank
+            comm = TShardComm(dist, rank, world, Ttotal, f0, T)
+    unet, diff = build_model(T, h, S, device)
+    diff.noise_seed = 1234 + (rank if mode == "replica" else 0)
+    fea, bbox, cond = synthetic_inputs(T, h, device, seed=123 + (rank if mode == "replica" else 0), f0=f0,
+                                       Ttotal=Ttotal)
+    ops = unet._ops()
+
+    def one_clip():
+        return diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_clip()
+    if not args.no_kernel_events:
+        ops.prof = []
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = one_clip()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof, ops.prof = getattr(ops, "prof", None), None
+    if dist is not None:
+        tt = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    assert torch.isfinite(out).all(), "non-finite output"
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    n_gpus = world
+    frames_total = T * n_gpus * args.steps
+    value = frames_total / dt
+    result = {
+        "metric": "generated frames/sec at 256x256, 50 DDIM steps" if (args.res, S) == (256, 50)
+        else f"generated frames/sec at {args.res}x{args.res}, {S} DDIM steps",
+        "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic (random-init DAWN weights, N(0,1) fea/bbox/cond, Philox noise)",
+        "config": {"workload": f"{args.res}x{args.res}, {T}-frame clip per GPU, {S} DDIM steps, window 40, eta 1.0, "
+                               f"cond_scale 1.0 (BASELINE configs[2])",
+                   "frames_per_gpu": T, "clip_frames": Ttotal, "latent": [h, h], "ddim_steps": S,
+                   "parallelism": {"single": "1 GPU", "tshard": f"T-shard x{n_gpus} (halo exchange over RCCL)",
+                                   "replica": f"{n_gpus} independent clips"}[mode]},
+    }
+    # ---- roofline of the dominant kernel (conv_gemm: every 3x3/1x1/4x4 conv and every projection)
+    if prof:
+        torch.cuda.synchronize()
+        t_ms = sum(a.elapsed_time(b) for _, a, b in prof)
+        flops = sum(f for f, _, _ in prof)
+        ach = flops / (t_ms * 1e-3) / 1e12
+        result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                              "kernel": "conv_gemm_kernel<64|128> (fp32 MFMA implicit GEMM)",
+                              "launches": len(prof), "avg_launch_us": t_ms * 1e3 / len(prof),
+                              "kernel_time_share": t_ms * 1e-3 / dt,
+                              "algorithmic_flops_per_launch_avg": flops / len(prof)}
+    alg = algorithmic_flops_per_forward(Ttotal if mode == "tshard" else T, h) * S * args.steps * \
+        (n_gpus if mode == "replica" else 1)
+    result["whole_path"] = {"algorithmic_tflop": alg / 1e12, "achieved_tflops": alg / dt / 1e12,
+                            "frac_of_fp32_mfma_peak": alg / dt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * n_gpus)}
+    if not args.no_cpu_baseline:
+        sd = {"denoise_fn." + k: v.detach().cpu() for k, v in unet.state_dict().items()}
+        result["cpu_baseline"] = cpu_baseline(h, S, args.cpu_sample_frames, sd)
+    print(json.dumps(result))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -67,7 +67,7 @@ class GaussianDiffusion(nn.Module):
         unet = self.denoise_fn
         ops = unet._ops()
         if comm is not None:
-            ops = type(ops)(comm=comm)
+            ops = ops.with_comm(comm)
         P = unet.packed()
         B, C, T, h, w = shape
         S, eta = self.sampling_timesteps, self.ddim_sampling_eta

@@ -37,6 +37,12 @@ class HipOps:
     def __init__(self, comm=None):
         self.L = _lib.lib()          # raises if the extension is missing: no fallback by design
         self.comm = comm             # T-shard communicator (see tshard.py) or None
+        self.prof = None             # list -> (algorithmic flops, start event, end event) per conv_gemm launch
+
+    def with_comm(self, comm):
+        o = HipOps(comm)
+        o.prof = self.prof
+        return o
 
     # ------------------------------------------------------------------ helpers
     @staticmethod
@@ -86,6 +92,14 @@ class HipOps:
         if tr is not None:
             d.tr, d.ld_tr, d.tr_a, d.tr_b = _p(tr[0]), _ld(tr[0]), _p(tr[1]), _p(tr[2])
         d.out, d.ld_out = _p(out), _ld(out)
+        if self.prof is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
+            e1.record()
+            rows_gemm = rows_out if mode == 0 else F * Hi * Wi * 4
+            self.prof.append((2.0 * rows_gemm * N * KH * KW * (d.C0 + d.C1), e0, e1))
+            return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
         return out
 

@@ -30,6 +30,9 @@ class RefOps:
     def __init__(self, comm=None):
         self.comm = comm
 
+    def with_comm(self, comm):
+        return RefOps(comm)
+
     def empty(self, *shape, like: Tensor, dtype=torch.float32) -> Tensor:
         return torch.zeros(*shape, device=like.device, dtype=dtype)
 

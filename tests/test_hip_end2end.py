@@ -1,0 +1,107 @@
+"""-m gpu: the product path (Unet3D / GaussianDiffusion on HipOps) against the reference goldens and the
+CPU oracle.  Tolerances (stated): predicted noise within 2e-4 abs of the reference golden on the tiny
+config (values O(1)); 1e-3 on the full DAWN_128 architecture (K up to 9216, ~300 chained ops, fp32)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT, load_golden, golden_sd
+from oracle import dawn_oracle as O
+import dawn_pytorch_amd as D
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+LOG = os.path.join(ROOT, "gpurun_out", "e2e_errors.jsonl")
+TINY_KW = dict(dim=16, cond_dim=32, cond_aud=24, cond_pose=6, cond_eye=2, num_frames=12, channels=19,
+               out_grid_dim=2, out_conf_dim=1, dim_mults=(1, 2), use_hubert_audio_cond=True, learn_null_cond=False,
+               use_final_activation=False, use_deconv=True, padding_mode="zeros", win_width=3)
+
+
+def log(name, got, want):
+    err = float((got.cpu() - want.cpu()).abs().max())
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write(json.dumps({"case": name, "max_abs_err": err, "max_abs_ref": float(want.abs().max())}) + "\n")
+    return err
+
+
+def tiny_unet(sd):
+    unet = D.DynamicNfUnet3D(default_num_frames=12, **TINY_KW)
+    unet.load_state_dict({k[len("denoise_fn."):]: v for k, v in sd.items()})
+    return unet.cuda()
+
+
+def test_loaded_native_library():
+    from dawn_pytorch_amd import _lib
+    assert _lib.lib().dawn_abi_version() == 1
+
+
+def test_tiny_unet_golden(tiny):
+    g, sd = tiny
+    unet = tiny_unet(sd)
+    y = unet.forward_with_cond_scale(T(g["x"]).cuda(), T(g["time"]).cuda(), cond=T(g["cond"]).cuda(), cond_scale=1.0)
+    assert log("tiny_unet", y, T(g["y"])) < 2e-4
+    y2 = unet.forward_with_cond_scale(T(g["x"]).cuda(), T(g["time"]).cuda(), cond=T(g["cond"]).cuda(), cond_scale=2.5)
+    assert log("tiny_unet_cfg2.5", y2, T(g["y_cond_scale_2p5"])) < 5e-4
+    h = load_golden("tiny_unet_T24.npz")
+    unet.update_num_frames(24)
+    y3 = unet.forward_with_cond_scale(T(h["x"]).cuda(), T(h["time"]).cuda(), cond=T(h["cond"]).cuda(), cond_scale=1.0)
+    assert log("tiny_unet_T24", y3, T(h["y"])) < 2e-4
+
+
+def test_tiny_ddim_golden(tiny):
+    g, sd = tiny
+    d = load_golden("ddim_tiny.npz")
+    unet = tiny_unet(sd)
+    diff = D.DynamicNfGaussianDiffusion(default_num_frames=12, denoise_fn=unet, num_frames=12, image_size=8,
+                                        sampling_timesteps=int(d["S"]), timesteps=1000, loss_type='l2',
+                                        use_dynamic_thres=True, null_cond_prob=0.1, ddim_sampling_eta=1.0).cuda()
+    diff.update_num_frames(12)
+    out = diff.sample(T(d["fea"]).cuda(), T(d["bbox"]).cuda(), cond=T(d["cond"]).cuda(), cond_scale=1.0,
+                      x_init=T(d["x_init"]).cuda(), noises=[n.cuda() for n in T(d["noises"])], trace=True)
+    qs = torch.stack([tr["s"][1] for tr in diff.last_trace[0]]).cpu()
+    assert float((qs - T(d["quantiles"]).float()).abs().max()) < 1e-3
+    assert log("tiny_ddim", out, T(d["out"])) < 5e-4
+
+
+def test_full_dawn128_forward_vs_oracle():
+    """Full DAWN_128 architecture (49.9 M params), T=8 frames, h=32: HIP vs the CPU oracle."""
+    Tn, h = 8, 32
+    unet = D.DynamicNfUnet3D(default_num_frames=Tn, dim=64, cond_dim=1032, cond_aud=1024, cond_pose=6, cond_eye=2,
+                             num_frames=Tn, channels=275, out_grid_dim=2, out_conf_dim=1, dim_mults=(1, 2, 4, 8),
+                             use_hubert_audio_cond=True, learn_null_cond=False, use_final_activation=False,
+                             use_deconv=True, padding_mode="zeros", win_width=40, init_seed=0)
+    assert sum(p.numel() for p in set(unet.parameters())) == 49857555
+    sd = {"denoise_fn." + k: v for k, v in unet.state_dict().items()}
+    g = torch.Generator().manual_seed(123)
+    fea = torch.randn(1, 272, h, h, generator=g)
+    cond = torch.randn(1, Tn, 1032, generator=g)
+    x3 = torch.randn(1, 3, Tn, h, h, generator=g)
+    xin = torch.cat((x3, fea.unsqueeze(2).expand(-1, -1, Tn, -1, -1)), 1)
+    want = O.unet_forward(sd, xin, torch.tensor([627]), cond, win=40)
+    unet = unet.cuda()
+    got = unet.forward_with_cond_scale(xin.cuda(), torch.tensor([627]).cuda(), cond=cond.cuda(), cond_scale=1.0)
+    assert log("dawn128_T8_forward", got, want) < 1e-3
+
+
+def test_sampler_properties_large():
+    """Size-independent properties at a larger size: determinism of the Philox path and |x| <= clamp bound
+    after the last step (alpha_next = 1 => x = clamp(x0)/s in [-1, 1])."""
+    Tn, h = 48, 16
+    unet = D.DynamicNfUnet3D(default_num_frames=Tn, dim=32, cond_dim=40, cond_aud=32, cond_pose=6, cond_eye=2,
+                             num_frames=Tn, channels=35, out_grid_dim=2, out_conf_dim=1, dim_mults=(1, 2, 4),
+                             use_hubert_audio_cond=True, win_width=10).cuda()
+    diff = D.DynamicNfGaussianDiffusion(default_num_frames=Tn, denoise_fn=unet, num_frames=Tn, image_size=h,
+                                        sampling_timesteps=4, timesteps=1000, loss_type='l2', use_dynamic_thres=True,
+                                        ddim_sampling_eta=1.0).cuda()
+    diff.noise_seed = 1234
+    g = torch.Generator().manual_seed(5)
+    fea, bbox = torch.randn(1, 28, h, h, generator=g).cuda(), torch.randn(1, 4, h, h, generator=g).cuda()
+    cond = torch.randn(1, Tn, 40, generator=g).cuda()
+    a = diff.sample(fea, bbox, cond=cond, cond_scale=1.0)
+    b = diff.sample(fea, bbox, cond=cond, cond_scale=1.0)
+    assert torch.equal(a, b), "sampler is not deterministic for a fixed Philox seed"
+    assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0 + 1e-6

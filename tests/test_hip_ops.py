@@ -1,0 +1,303 @@
+"""-m gpu: every HIP kernel (through the C ABI / HipOps) against the torch op reference of the same name
+(oracle/ops_ref.py, evaluated on CPU in fp32) on the same seeded inputs.
+
+Tolerance (stated): fp32 MFMA / VALU arithmetic vs CPU fp32 differ only in summation order, so
+|hip - ref| <= 1e-4 * max(1, max|ref|) for GEMM-like ops (K up to ~9k), 1e-5-class for elementwise ops;
+integer work (histograms, select state) is bit-exact."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import ROOT
+from oracle.ops_ref import RefOps
+
+pytestmark = pytest.mark.gpu
+
+LOG = os.path.join(ROOT, "gpurun_out", "op_errors.jsonl")
+
+
+@pytest.fixture(scope="module")
+def hip():
+    from dawn_pytorch_amd.ops import HipOps
+    assert torch.cuda.is_available(), "gpu tests need a GPU"
+    return HipOps()
+
+
+@pytest.fixture(scope="module")
+def ref():
+    return RefOps()
+
+
+def gpu(*ts):
+    return [None if t is None else (tuple(gpu(*t)) if isinstance(t, (tuple, list)) else t.cuda()) for t in ts]
+
+
+def check(name, got, want, tol=1e-4):
+    got = got.detach().float().cpu()
+    want = want.detach().float().cpu()
+    scale = max(1.0, float(want.abs().max()))
+    err = float((got - want).abs().max())
+    os.makedirs(os.path.dirname(LOG), exist_ok=True)
+    with open(LOG, "a") as f:
+        f.write(json.dumps({"op": name, "max_abs_err": err, "scale": scale, "tol": tol * scale,
+                            "nan": bool(torch.isnan(got).any())}) + "\n")
+    assert not torch.isnan(got).any(), f"{name}: NaN"
+    assert err <= tol * scale, f"{name}: max|diff| {err:.3e} > {tol * scale:.3e}"
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed + sum(shape))
+    return torch.randn(*shape, generator=g) * scale
+
+
+def packw(K, N, seed=0):
+    from dawn_pytorch_amd.pack import pack_kn
+    return pack_kn(rnd(K, N, seed=seed, scale=K ** -0.5))
+
+
+# ---------------------------------------------------------------------------------------------- conv_gemm
+CONV_CASES = [
+    # name, F, H, W, C0, C1, N, KH, stride, pad, extras
+    ("c3x3_64_64", 3, 16, 16, 64, 0, 64, 3, 1, 1, {}),
+    ("c3x3_cat_128p128_256_bias", 2, 8, 8, 128, 128, 256, 3, 1, 1, {"bias": True}),
+    ("c3x3_16_16_tinyN", 5, 8, 8, 16, 0, 16, 3, 1, 1, {"bias": True}),
+    ("c1x1_rowstats_768", 2, 8, 8, 64, 0, 768, 1, 1, 0, {"row_stats": True}),
+    ("c1x1_rowstats_cat_192", 3, 4, 4, 512, 512, 192, 1, 1, 0, {"row_stats": True}),
+    ("c3x3_gn_prologue_add", 3, 8, 8, 128, 0, 128, 3, 1, 1, {"ch_ab": True, "pro_act": 1, "pro_add": True, "bias": True}),
+    ("c1x1_tr_epilogue", 2, 8, 8, 256, 0, 128, 1, 1, 0, {"tr": True, "bias": True}),
+    ("c1x1_res_epilogue", 2, 8, 8, 256, 0, 64, 1, 1, 0, {"res": True}),
+    ("down4x4s2", 3, 16, 16, 64, 0, 64, 4, 2, 1, {"bias": True}),
+    ("c7x7_fea", 1, 16, 16, 272, 0, 64, 7, 1, 3, {"bias": True}),
+    ("c3x3_512_512_deepK", 7, 4, 4, 512, 0, 512, 3, 1, 1, {"bias": True}),
+    ("c3x3_ragged_M", 1, 5, 7, 32, 0, 48, 3, 1, 1, {}),
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_gemm(hip, ref, case):
+    name, F, H, W, C0, C1, N, k, stride, pad, ex = case
+    rows = F * H * W
+    Ho = (H + 2 * pad - k) // stride + 1
+    Wo = (W + 2 * pad - k) // stride + 1
+    in0 = rnd(rows, C0, seed=1)
+    in1 = rnd(rows, C1, seed=2) if C1 else None
+    w = packw(k * k * (C0 + C1), N, seed=3)
+    kw = dict(F=F, Hi=H, Wi=W, Ho=Ho, Wo=Wo, KH=k, KW=k, stride=stride, pad=pad)
+    if ex.get("bias"):
+        kw["bias"] = rnd(N, seed=4)
+    if ex.get("row_stats"):
+        x = in0 if in1 is None else torch.cat((in0, in1), 1)
+        kw["row_stats"] = (x.mean(1), 1.0 / torch.sqrt(x.var(1, unbiased=False) + 1e-5))
+    if ex.get("ch_ab"):
+        kw["ch_ab"] = (rnd(C0, seed=5) * 0.3 + 1.0, rnd(C0, seed=6) * 0.3)
+    if ex.get("pro_act"):
+        kw["pro_act"] = 1
+    if ex.get("pro_add"):
+        kw["pro_add"] = rnd(rows, C0, seed=7)
+    if ex.get("res"):
+        kw["res"] = rnd(F * Ho * Wo, N, seed=8)
+    if ex.get("tr"):
+        kw["tr"] = (rnd(F * Ho * Wo, N, seed=9), rnd(N, seed=10) * 0.3 + 1.0, rnd(N, seed=11) * 0.3)
+    want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
+    gkw = {k_: (tuple(t.cuda() for t in v) if isinstance(v, tuple) else (v.cuda() if torch.is_tensor(v) else v))
+           for k_, v in kw.items()}
+    got = hip.conv_gemm(in0.cuda(), w.cuda(), N, in1=None if in1 is None else in1.cuda(), **gkw)
+    torch.cuda.synchronize()
+    check("conv_gemm/" + name, got, want)
+
+
+def test_conv_gemm_transposed(hip, ref):
+    from dawn_pytorch_amd.pack import pack_kn, deconv_w_kn_phases
+    F, H, W, Cc = 3, 8, 8, 64
+    w5 = rnd(Cc, Cc, 1, 4, 4, seed=1, scale=(Cc * 4) ** -0.5)
+    ph = deconv_w_kn_phases(w5)
+    wp = torch.stack([pack_kn(ph[i]) for i in range(4)], 0)
+    x = rnd(F * H * W, Cc, seed=2)
+    b = rnd(Cc, seed=3)
+    want = torch.nn.functional.conv_transpose2d(x.reshape(F, H, W, Cc).permute(0, 3, 1, 2), w5[:, :, 0], b, stride=2,
+                                                padding=1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    r = ref.conv_gemm(x, wp, Cc, F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=b)
+    torch.testing.assert_close(r, want, atol=1e-5, rtol=1e-5)       # phase packing itself
+    got = hip.conv_gemm(x.cuda(), wp.cuda(), Cc, F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=b.cuda())
+    check("conv_gemm/transposed_up", got, want)
+
+
+def test_conv_gemm_strided_views(hip, ref):
+    """channel slices as input (xattn to_out reads q[:, 64b:64b+64]) and output (y3[:, b*Co:(b+1)*Co])."""
+    rows, Co = 200, 128
+    q = rnd(rows, 192, seed=1)
+    y3 = torch.zeros(rows, 3 * Co)
+    y3g = torch.zeros(rows, 3 * Co).cuda()
+    qg = q.cuda()
+    for b in range(3):
+        w = packw(64, Co, seed=10 + b)
+        ref.conv_gemm(q[:, 64 * b:64 * b + 64], w, Co, F=rows, Hi=1, Wi=1, out=y3[:, b * Co:(b + 1) * Co])
+        hip.conv_gemm(qg[:, 64 * b:64 * b + 64], w.cuda(), Co, F=rows, Hi=1, Wi=1, out=y3g[:, b * Co:(b + 1) * Co])
+    check("conv_gemm/strided_views", y3g, y3)
+
+
+# ---------------------------------------------------------------------------------------------- norms
+@pytest.mark.parametrize("C,rows,film", [(16, 12 * 64, True), (64, 3000, True), (128, 777, False), (512, 16 * 5, True)])
+def test_gn_coeffs_and_apply(hip, ref, C, rows, film):
+    x = rnd(rows, C, seed=1) * 2 + 0.5
+    gamma, beta = rnd(C, seed=2) * 0.2 + 1, rnd(C, seed=3) * 0.2
+    fl = (rnd(C, seed=4) * 0.3, rnd(C, seed=5) * 0.3) if film else None
+    wa, wb = ref.gn_coeffs(x, gamma, beta, fl, rows)
+    ga, gb = hip.gn_coeffs(x.cuda(), gamma.cuda(), beta.cuda(), None if fl is None else tuple(t.cuda() for t in fl), rows)
+    check(f"gn_coeffs/a_C{C}", ga, wa, 2e-5)
+    check(f"gn_coeffs/b_C{C}", gb, wb, 2e-5)
+    # against torch's own GroupNorm on the 5-D view
+    y = torch.nn.functional.group_norm(x.t().reshape(1, C, rows, 1, 1), 8, gamma, beta, eps=1e-5)[0, :, :, 0, 0].t()
+    if fl is not None:
+        y = y * (fl[0] + 1) + fl[1]
+    res = rnd(rows, C, seed=6)
+    want = torch.nn.functional.silu(y) + res
+    got = hip.gn_apply_res(x.cuda(), ga, gb, res.cuda())
+    check(f"gn_apply_res/C{C}", got, want, 2e-5)
+
+
+@pytest.mark.parametrize("C0,C1,rows", [(16, 0, 700), (64, 0, 4097), (64, 64, 300), (512, 512, 130), (256, 0, 64)])
+def test_ln_rowstats(hip, ref, C0, C1, rows):
+    a = rnd(rows, C0, seed=1) * 1.5 + 0.3
+    b = rnd(rows, C1, seed=2) if C1 else None
+    wm, wr = ref.ln_rowstats(a, b)
+    gm, gr = hip.ln_rowstats(a.cuda(), None if b is None else b.cuda())
+    check(f"ln_rowstats/mean_{C0}_{C1}", gm, wm, 1e-5)
+    check(f"ln_rowstats/rstd_{C0}_{C1}", gr, wr, 1e-5)
+
+
+# ---------------------------------------------------------------------------------------------- cross attention
+def test_xattn_pieces(hip, ref):
+    Fn, HW, Co = 7, 12, 96
+    rows = Fn * HW
+    kvtab_w, nulltab_w = torch.zeros(Fn, 3, 128), torch.zeros(3, 16)
+    kvtab_g, nulltab_g = torch.zeros(Fn, 3, 128).cuda(), torch.zeros(3, 16).cuda()
+    for b in range(3):
+        kv, ks, nk = rnd(Fn, 128, seed=b), rnd(8, seed=10 + b) * 0.2 + 1, rnd(2, 8, seed=20 + b)
+        ref.xattn_prep(kv, ks, nk, kvtab_w, b, nulltab_w)
+        hip.xattn_prep(kv.cuda(), ks.cuda(), nk.cuda(), kvtab_g, b, nulltab_g)
+    check("xattn_prep/kvtab", kvtab_g, kvtab_w, 1e-5)
+    check("xattn_prep/nulltab", nulltab_g, nulltab_w, 1e-5)
+    q = rnd(rows, 192, seed=3)
+    qs = rnd(3, 8, seed=4) * 0.2 + 1
+    want = ref.xattn_core(q.clone(), HW, kvtab_w, nulltab_w, qs)
+    got = hip.xattn_core(q.cuda(), HW, kvtab_g, nulltab_g, qs.cuda())
+    check("xattn_core", got, want, 1e-5)
+    for Co in (16, 96, 512):
+        y3, g3 = rnd(rows, 3 * Co, seed=5), rnd(3, Co, seed=6) * 0.2 + 1
+        check(f"xattn_ln_sum/Co{Co}", hip.xattn_ln_sum(y3.cuda(), g3.cuda(), Co), ref.xattn_ln_sum(y3, g3, Co), 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- attention cores
+@pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(12, 5, 0, 12, 3), (100, 3, 0, 100, 40), (70, 2, 20, 33, 40),
+                                                 (45, 4, 3, 40, 7), (33, 2, 0, 33, 40)])
+def test_temporal_attn(hip, ref, Fext, HW, q0, Fq, win):
+    qkv = rnd(Fext * HW, 768, seed=1)
+    ang = torch.arange(Fext).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
+    rc, rs = ang.cos().contiguous(), ang.sin().contiguous()
+    band = rnd(2 * win + 1, 8, seed=2)
+    want = ref.temporal_attn(qkv, Fext, HW, q0, Fq, win, rc, rs, band)
+    got = hip.temporal_attn(qkv.cuda(), Fext, HW, q0, Fq, win, rc.cuda(), rs.cuda(), band.cuda())
+    check(f"temporal_attn/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 2e-5)
+
+
+@pytest.mark.parametrize("F,HW", [(3, 64), (2, 256), (5, 16), (2, 100)])
+def test_sla(hip, ref, F, HW):
+    qkv = rnd(F * HW, 768, seed=1)
+    check(f"sla/F{F}_HW{HW}", hip.sla(qkv.cuda(), F, HW), ref.sla(qkv, F, HW), 2e-5)
+
+
+@pytest.mark.parametrize("F,N", [(4, 16), (3, 64), (2, 100)])
+def test_frame_attn(hip, ref, F, N):
+    qkv = rnd(F * N, 768, seed=1)
+    check(f"frame_attn/F{F}_N{N}", hip.frame_attn(qkv.cuda(), F, N), ref.frame_attn(qkv, F, N), 2e-5)
+
+
+# ---------------------------------------------------------------------------------------------- boundary / small
+def test_init_conv_x_and_head(hip, ref):
+    F, h, w, Co = 3, 8, 8, 64
+    x, w3, fp = rnd(3, F, h, w, seed=1), rnd(147, Co, seed=2) * 0.1, rnd(h * w, Co, seed=3)
+    check("init_conv_x", hip.init_conv_x(x.cuda(), w3.cuda(), fp.cuda(), F, h, w, Co), ref.init_conv_x(x, w3, fp, F, h, w, Co), 2e-5)
+    for Co in (16, 64):
+        hg, ho = rnd(500, Co, seed=4), rnd(500, Co, seed=5)
+        wg, bg, wo, bo = rnd(2, Co, seed=6), rnd(2, seed=7), rnd(1, Co, seed=8), rnd(1, seed=9)
+        check(f"head_out/Co{Co}", hip.head_out(*gpu(hg, ho, wg, bg, wo, bo)), ref.head_out(hg, ho, wg, bg, wo, bo), 2e-5)
+
+
+@pytest.mark.parametrize("M,K,N,act,bias", [(1, 64, 256, 0, True), (1, 256, 256, 2, True), (1, 256, 4352, 1, True),
+                                            (20, 1024, 128, 1, True), (20, 6, 128, 1, True), (20, 2, 32, 1, True),
+                                            (20, 128, 128, 0, False)])
+def test_linear(hip, ref, M, K, N, act, bias):
+    x, W = rnd(M, K, seed=1), rnd(N, K, seed=2) * K ** -0.5
+    b = rnd(N, seed=3) if bias else None
+    check(f"linear/{M}x{K}x{N}_a{act}", hip.linear(x.cuda(), W.cuda(), None if b is None else b.cuda(), act), ref.linear(x, W, b, act), 2e-5)
+
+
+def test_linear_strided_input(hip, ref):
+    cond = rnd(9, 1032, seed=1)
+    W, b = rnd(64, 6, seed=2), rnd(64, seed=3)
+    check("linear/strided", hip.linear(cond.cuda()[:, 1024:1030], W.cuda(), b.cuda(), 1), ref.linear(cond[:, 1024:1030], W, b, 1), 2e-5)
+
+
+def test_sinusoidal(hip, ref):
+    like = torch.zeros(1).cuda()
+    for t in (0, 19, 980):
+        check(f"sinusoidal/t{t}", hip.sinusoidal(t, 64, like), ref.sinusoidal(t, 64, torch.zeros(1)), 2e-6)
+
+
+# ---------------------------------------------------------------------------------------------- sampler
+def test_ddim_x0_and_histogram(hip, ref):
+    x, e = rnd(3, 5, 8, 8, seed=1), rnd(3, 5, 8, 8, seed=2)
+    wx0, wh = ref.ddim_x0(x, e, 1.25, 0.75)
+    gx0, gh = hip.ddim_x0(x.cuda(), e.cuda(), 1.25, 0.75)
+    check("ddim_x0", gx0, wx0, 1e-6)
+    gbits = (gx0.abs().cpu().contiguous().view(torch.int32) >> 20).flatten().long()
+    assert torch.equal(gh.cpu(), torch.bincount(gbits, minlength=2048).to(torch.int32)), "histogram not exact"
+
+
+@pytest.mark.parametrize("n,scale", [(7, 2.0), (10, 0.3), (11, 2.0), (1000, 1.0), (36864, 3.0), (100001, 0.5),
+                                     (2457600, 1.0)])
+def test_quantile_matches_torch(hip, n, scale):
+    v = rnd(n, seed=n % 97) * scale
+    if n == 1000:
+        v[::3] = 1.5                                   # heavy ties around the quantile
+    want = torch.quantile(v.abs(), 0.9)
+    x0 = v.cuda().contiguous()
+    _, hist = hip.ddim_x0(x0, torch.zeros_like(x0), 1.0, 0.0)
+    s = hip.quantile_threshold(x0, hist, n, 0.9).cpu()
+    assert float(s[1]) == pytest.approx(float(want), rel=0, abs=1e-6 * max(1, float(want))), (float(s[1]), float(want))
+    assert float(s[0]) == max(1.0, float(s[1]))
+
+
+def test_quantile_golden(hip):
+    from conftest import load_golden
+    d = load_golden("quantile.npz")
+    for k in d:
+        if k.startswith("v"):
+            for row, q in zip(torch.from_numpy(d[k]), d["q" + k[1:]]):
+                x0 = row.cuda().contiguous()
+                _, hist = hip.ddim_x0(x0, torch.zeros_like(x0), 1.0, 0.0)
+                s = hip.quantile_threshold(x0, hist, x0.numel(), 0.9).cpu()
+                assert abs(float(s[1]) - float(q)) <= 1e-6 * max(1.0, float(q)), (k, float(s[1]), float(q))
+
+
+def test_ddim_update_and_cfg(hip, ref):
+    x0, e, nz = rnd(3, 4, 8, 8, seed=1) * 2, rnd(3, 4, 8, 8, seed=2), rnd(3, 4, 8, 8, seed=3)
+    s = torch.tensor([1.7, 1.7])
+    check("ddim_update", hip.ddim_update(x0.cuda(), e.cuda(), s.cuda(), nz.cuda(), 0.9, 0.3, 0.2), ref.ddim_update(x0, e, s, nz, 0.9, 0.3, 0.2), 1e-6)
+    check("ddim_update/nonoise", hip.ddim_update(x0.cuda(), e.cuda(), s.cuda(), None, 1.0, 0.0, 0.0), ref.ddim_update(x0, e, s, None, 1.0, 0.0, 0.0), 1e-6)
+    check("cfg_combine", hip.cfg_combine(x0.cuda(), e.cuda(), 2.5), ref.cfg_combine(x0, e, 2.5), 1e-6)
+
+
+def test_philox_normal(hip, ref):
+    a = hip.philox_normal(3, 6, 0, 6, 64, 1234, 1, "cuda").cpu()
+    w = ref.philox_normal(3, 6, 0, 6, 64, 1234, 1, "cpu")
+    check("philox_normal", a, w, 2e-5)
+    # shard invariance: frames [2,5) of a 6-frame clip equal the slice of the unsharded draw
+    b = hip.philox_normal(3, 3, 2, 6, 64, 1234, 1, "cuda").cpu()
+    assert torch.equal(b, a[:, 2:5])
+    big = hip.philox_normal(3, 200, 0, 200, 4096, 7, 3, "cuda")
+    assert abs(float(big.mean())) < 3e-3 and abs(float(big.std()) - 1) < 3e-3
