@@ -55,7 +55,7 @@ SIGNATURES = {
     "dawn_init_conv_x": [c_f, c_f, c_f, _i, _i, _i, _i, c_f, c_f],
     "dawn_head_out": [c_f, c_f, c_f, c_f, c_f, c_f, _l, _i, c_f, c_f],
     "dawn_linear": [c_f, _i, _i, _i, c_f, c_f, _i, _i, c_f, _i, c_f],
-    "dawn_sinusoidal": [_f, _i, c_f, c_f],
+    "dawn_sinusoidal": [_f, _i, c_f, c_f, c_f],
     "dawn_ddim_x0": [c_f, c_f, _f, _f, _l, c_f, c_f, c_f],
     "dawn_select_scan": [c_f, _i, C.c_ulonglong, c_f, _i, c_f],
     "dawn_select_hist": [c_f, _l, c_f, _i, c_f, c_f],

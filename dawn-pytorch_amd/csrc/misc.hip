@@ -92,14 +92,12 @@ __global__ __launch_bounds__(256) void linear_kernel(const float* __restrict__ i
     if (lane == 0) out[(long)m * ld_out + n] = acc + (bias ? bias[n] : 0.f);
 }
 
-// SinusoidalPosEmb MT:150-162: out = [sin(t f_i) | cos(t f_i)], f_i = exp(-i ln(1e4)/(half-1))
-__global__ void sinusoidal_kernel(float t, int dim, float* __restrict__ out) {
+// SinusoidalPosEmb MT:150-162: out = [sin(t f_i) | cos(t f_i)], f_i = exp(-i ln(1e4)/(half-1)) (host table)
+__global__ void sinusoidal_kernel(float t, int dim, const float* __restrict__ freqs, float* __restrict__ out) {
     const int i = threadIdx.x;
     const int half = dim / 2;
     if (i < half) {
-        const float e = 9.210340371976184f / (float)(half - 1);
-        const float f = expf((float)i * -e);
-        const float a = t * f;
+        const float a = __fmul_rn(t, freqs[i]);
         out[i] = sinf(a);
         out[half + i] = cosf(a);
     }
@@ -132,9 +130,9 @@ extern "C" int dawn_linear(const float* in, int M, int K, int ld_in, const float
     DAWN_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int dawn_sinusoidal(float t, int dim, float* out, void* stream) {
+extern "C" int dawn_sinusoidal(float t, int dim, const float* freqs, float* out, void* stream) {
     if (dim > 256) return dawn_set_error_msg(-61, "dawn_sinusoidal: dim > 256");
-    hipLaunchKernelGGL(sinusoidal_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, t, dim, out);
+    hipLaunchKernelGGL(sinusoidal_kernel, dim3(1), dim3(128), 0, (hipStream_t)stream, t, dim, freqs, out);
     DAWN_LAUNCH_CHECK();
     return 0;
 }

@@ -218,9 +218,10 @@ class HipOps:
               "dawn_linear")
         return out
 
-    def sinusoidal(self, t: float, dim: int, like: Tensor) -> Tensor:
-        out = self.empty(1, dim, like=like)
-        check(self.L.dawn_sinusoidal(float(t), dim, _p(out), self._stream()), "dawn_sinusoidal")
+    def sinusoidal(self, t: float, freqs: Tensor) -> Tensor:
+        dim = 2 * freqs.numel()
+        out = self.empty(1, dim, like=freqs)
+        check(self.L.dawn_sinusoidal(float(t), dim, _p(freqs), _p(out), self._stream()), "dawn_sinusoidal")
         return out
 
     # ------------------------------------------------------------------ sampler

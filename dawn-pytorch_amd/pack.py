@@ -132,6 +132,7 @@ class PackedUNet:
     bo: Tensor = None
     rel_emb: Tensor = None                 # (32, 8)
     rot_freqs: Tensor = None               # (16,)
+    sin_freqs: Tensor = None               # (dim/2,) SinusoidalPosEmb table (MT:157-159)
     n_cond_blocks: int = 0
 
     def band(self, win: int) -> Tensor:
@@ -167,6 +168,8 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
     P.b_init = dev(g("init_conv.bias"))
     P.rel_emb = dev(g("time_rel_pos_bias.relative_attention_bias.weight"))
     P.rot_freqs = g("init_temporal_attn.fn.fn.fn.rotary_emb.freqs")
+    half = dim // 2
+    P.sin_freqs = dev(torch.exp(torch.arange(half, dtype=torch.float32) * -(math.log(10000) / (half - 1))))
     P.t_w1, P.t_b1 = dev(g("time_mlp.1.weight")), dev(g("time_mlp.1.bias"))
     P.t_w2, P.t_b2 = dev(g("time_mlp.3.weight")), dev(g("time_mlp.3.bias"))
 

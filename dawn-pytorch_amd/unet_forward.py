@@ -77,7 +77,7 @@ def _conditioned_blocks(P: PackedUNet):
 
 def time_film(ops, P: PackedUNet, t: float, like: Tensor) -> Tensor:
     """time_mlp (MT:789-794) then every block's SiLU->Linear(256, 2*Co) (MT:366-369) in one GEMV."""
-    e = ops.sinusoidal(float(t), P.t_w1.shape[1], like)
+    e = ops.sinusoidal(float(t), P.sin_freqs)
     e = ops.linear(e, P.t_w1, P.t_b1)
     e = ops.linear(e, P.t_w2, P.t_b2, act_in=2)            # exact GELU on the input of the 2nd Linear
     return ops.linear(e, P.film_w, P.film_b, act_in=1).reshape(-1)

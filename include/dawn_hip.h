@@ -106,7 +106,8 @@ int dawn_head_out(const float* hg, const float* ho, const float* wg, const float
 /* out[m][n] = bias[n] + sum_k act(in[m][k]) * W[n][k];  act_in: 0 none, 1 SiLU, 2 exact GELU */
 int dawn_linear(const float* in, int M, int K, int ld_in, const float* W, const float* bias, int N,
                 int act_in, float* out, int ld_out, void* stream);
-int dawn_sinusoidal(float t, int dim, float* out, void* stream);                       /* MT:150-162 */
+/* SinusoidalPosEmb MT:150-162; freqs (dim/2) = exp(-i*ln(1e4)/(dim/2-1)) table computed once on the host */
+int dawn_sinusoidal(float t, int dim, const float* freqs, float* out, void* stream);
 
 /* ---- A0 DDIM sampler step pieces (MT:1169-1205) ------------------------------------------------ */
 /* x0 = recip*x - recipm1*eps ; also histogram of the top 11 bits of |x0| into hist[2048] */

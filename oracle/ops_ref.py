@@ -208,10 +208,8 @@ class RefOps:
             return out
         return y
 
-    def sinusoidal(self, t, dim, like):
-        half = dim // 2
-        f = torch.exp(torch.arange(half, dtype=torch.float32, device=like.device) * -(math.log(10000) / (half - 1)))
-        e = torch.tensor([float(t)], dtype=torch.float32, device=like.device)[:, None] * f[None, :]
+    def sinusoidal(self, t, freqs):
+        e = torch.tensor([float(t)], dtype=torch.float32, device=freqs.device)[:, None] * freqs[None, :]
         return torch.cat((e.sin(), e.cos()), dim=-1)
 
     # ------------------------------------------------------------------ sampler

@@ -243,9 +243,10 @@ def test_linear_strided_input(hip, ref):
 
 
 def test_sinusoidal(hip, ref):
-    like = torch.zeros(1).cuda()
+    import math
+    fr = torch.exp(torch.arange(32, dtype=torch.float32) * -(math.log(10000) / 31))
     for t in (0, 19, 980):
-        check(f"sinusoidal/t{t}", hip.sinusoidal(t, 64, like), ref.sinusoidal(t, 64, torch.zeros(1)), 2e-6)
+        check(f"sinusoidal/t{t}", hip.sinusoidal(t, fr.cuda()), ref.sinusoidal(t, fr), 2e-6)
 
 
 # ---------------------------------------------------------------------------------------------- sampler
