@@ -169,8 +169,8 @@ def main():
     # ---- roofline of the dominant kernel (conv_gemm: every 3x3/1x1/4x4 conv and every projection)
     if prof:
         torch.cuda.synchronize()
-        t_ms = sum(a.elapsed_time(b) for _, a, b in prof)
-        flops = sum(f for f, _, _ in prof)
+        t_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
+        flops = sum(p[0] for p in prof)
         ach = flops / (t_ms * 1e-3) / 1e12
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,

@@ -50,21 +50,34 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
     if (tid < 16) part[(long)blockIdx.x * 16 + tid] = red[tid];
 }
 
-__global__ void gn_reduce_kernel(const double* __restrict__ part, int nblk, double* __restrict__ sums) {
-    const int t = threadIdx.x;
+// fixed-order (deterministic) column sums of part[nblk][16]
+__device__ __forceinline__ void gn_reduce_block(const double* __restrict__ part, int nblk, double* sh, double* out16) {
+    const int t = threadIdx.x;          // 256 threads: column t&15, row phase t>>4
+    const int c = t & 15, r = t >> 4;
+    double a = 0.0;
+    for (int b = r; b < nblk; b += 16) a += part[(long)b * 16 + c];
+    sh[t] = a;
+    __syncthreads();
     if (t < 16) {
-        double a = 0.0;
-        for (int b = 0; b < nblk; ++b) a += part[(long)b * 16 + t];
-        sums[t] = a;
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) s += sh[k * 16 + t];
+        out16[t] = s;
     }
+    __syncthreads();
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
-                                   const float* __restrict__ beta, const float* __restrict__ fs,
-                                   const float* __restrict__ fsh, int C, float eps, float* __restrict__ a,
-                                   float* __restrict__ b) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+__global__ __launch_bounds__(256) void gn_reduce_kernel(const double* __restrict__ part, int nblk,
+                                                        double* __restrict__ sums) {
+    __shared__ double sh[256];
+    __shared__ double res[16];
+    gn_reduce_block(part, nblk, sh, res);
+    if (threadIdx.x < 16) sums[threadIdx.x] = res[threadIdx.x];
+}
+
+__device__ __forceinline__ void gn_coeff(const double* sums, double count, const float* gamma, const float* beta,
+                                         const float* fs, const float* fsh, int C, float eps, float* a, float* b,
+                                         int c) {
     const int g = c / (C >> 3);
     const double mean = sums[g * 2] / count;
     double var = sums[g * 2 + 1] / count - mean * mean;
@@ -80,6 +93,27 @@ __global__ void gn_finalize_kernel(const double* __restrict__ sums, double count
     }
     a[c] = av;
     b[c] = bv;
+}
+
+// single-GPU fast path: reduce + finalize in one launch
+__global__ __launch_bounds__(256) void gn_reduce_finalize_kernel(const double* __restrict__ part, int nblk, double count,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta,
+                                                                 const float* __restrict__ fs,
+                                                                 const float* __restrict__ fsh, int C, float eps,
+                                                                 float* __restrict__ a, float* __restrict__ b) {
+    __shared__ double sh[256];
+    __shared__ double res[16];
+    gn_reduce_block(part, nblk, sh, res);
+    for (int c = threadIdx.x; c < C; c += 256) gn_coeff(res, count, gamma, beta, fs, fsh, C, eps, a, b, c);
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ beta, const float* __restrict__ fs,
+                                   const float* __restrict__ fsh, int C, float eps, float* __restrict__ a,
+                                   float* __restrict__ b) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < C) gn_coeff(sums, count, gamma, beta, fs, fsh, C, eps, a, b, c);
 }
 
 __global__ __launch_bounds__(256) void gn_apply_res_kernel(const float* __restrict__ x, const float* __restrict__ a,
@@ -151,7 +185,7 @@ extern "C" int dawn_gn_partial(const float* x, long rows, int C, int ld, double*
     return 0;
 }
 extern "C" int dawn_gn_reduce(const double* part, int nblk, double* sums16, void* stream) {
-    hipLaunchKernelGGL(gn_reduce_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, nblk, sums16);
+    hipLaunchKernelGGL(gn_reduce_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblk, sums16);
     DAWN_LAUNCH_CHECK();
     return 0;
 }
@@ -159,6 +193,14 @@ extern "C" int dawn_gn_finalize(const double* sums16, double count_per_group, co
                                 const float* film_scale, const float* film_shift, int C, float eps, float* a,
                                 float* b, void* stream) {
     hipLaunchKernelGGL(gn_finalize_kernel, dim3(dawn_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream, sums16,
+                       count_per_group, gamma, beta, film_scale, film_shift, C, eps, a, b);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dawn_gn_reduce_finalize(const double* part, int nblk, double count_per_group, const float* gamma,
+                                       const float* beta, const float* film_scale, const float* film_shift, int C,
+                                       float eps, float* a, float* b, void* stream) {
+    hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblk,
                        count_per_group, gamma, beta, film_scale, film_shift, C, eps, a, b);
     DAWN_LAUNCH_CHECK();
     return 0;

@@ -5,14 +5,15 @@
 // "local_opt" file's LocalSelfAttention_opt / window_attn (LA:71-99, 300-342): keys outside
 // [i-win, i+win] or outside the clip get weight exactly 0.
 //
-// One wave per (pixel, head, 32-query tile).  The wave computes S^T = K.Q^T with the MFMA
-// (A = K tile rows, B = Q rows), so that lane (l&31) owns ONE query column and its key scores sit in
-// that lane's accumulator registers: the softmax max/sum are in-register plus one xor-32 exchange.
-// The accumulator register r of key tile t holds key j = 32t + (r&3) + 8(r>>2) + 4(lane>>5), which is
-// exactly the k-index pattern an MFMA A operand wants (lanes 0-31 -> k_a, lanes 32-63 -> k_a+4), so P
-// feeds the P.V MFMAs straight from the accumulators with no LDS round trip; V rows are read as the B
-// operand (one coalesced 128-B row per half-wave).  Q/K/V come straight from L2/HBM: the only LDS use is
-// the (2*win+1) x 8 bias band.
+// One 4-wave block per (pixel, head, segment of 128 query frames).  The block stages the rotated K rows and
+// the V rows of its key range [i0-win, i0+128+win) once in LDS (K padded to 36 floats/row: conflict-free
+// ds_read_b128 A-fragments; V rows of 32 floats: conflict-free ds_read_b32 B-fragments); each wave owns
+// one 32-query tile.  The wave computes S^T = K.Q^T with the MFMA (A = K tile rows, B = Q rows), so that
+// lane (l&31) owns ONE query column and its key scores sit in that lane's accumulator registers: softmax
+// max/sum are in-register plus one xor-32 exchange.  Accumulator register r of key tile t holds key
+// j = 32t + (r&3) + 8(r>>2) + 4(lane>>5), which is exactly the k-index pattern an MFMA A operand wants
+// (lanes 0-31 -> k_a, lanes 32-63 -> k_a+4): P feeds the P.V MFMAs straight from the accumulators with no
+// LDS round trip and no shuffles.
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 
@@ -21,6 +22,8 @@ namespace {
 constexpr int HEADS = 8;
 constexpr int DH = 32;
 constexpr int QKV = 3 * HEADS * DH;  // 768
+constexpr int SEG = 128;             // query frames per block (4 waves x 32)
+constexpr int KLD = 36;              // floats per staged K row
 constexpr float NEG = -1.0e30f;
 
 __device__ __forceinline__ f32x4 rot4(f32x4 v, float c0, float s0, float c1, float s1) {
@@ -37,24 +40,50 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
                                                             int Fq, int win, const float* __restrict__ rcos,
                                                             const float* __restrict__ rsin,
                                                             const float* __restrict__ band, float* __restrict__ out,
-                                                            int nqt, long nwaves) {
-    extern __shared__ __attribute__((aligned(16))) float band_s[];  // [(2*win+1)][8]
-    const int nb = (2 * win + 1) * HEADS;
-    for (int i = threadIdx.x; i < nb; i += 256) band_s[i] = band[i];
-    __syncthreads();
+                                                            int nseg) {
+    constexpr int NKP = 32 * (3 + NKT);  // staged key rows (covers wave 3's last tile)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Ks = smem;                    // [NKP][KLD]
+    float* Vs = smem + NKP * KLD;        // [NKP][DH]
+    float* band_s = Vs + NKP * DH;       // [(2*win+1)][8]
 
-    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (w >= nwaves) return;
-    const int lane = threadIdx.x & 63;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int qt = (int)(w % nqt);
-    const long ph = w / nqt;
+    const int tid = threadIdx.x;
+    const int seg = blockIdx.x % nseg;
+    const long ph = blockIdx.x / nseg;
     const int h = (int)(ph % HEADS);
     const long p = ph / HEADS;
-
-    const int i0 = q0 + qt * 32;
+    const int ib0 = q0 + seg * SEG;      // first query frame of the block
+    const int jb0 = ib0 - win;           // first staged key frame
     const int qend = q0 + Fq;
-    const int j0 = i0 - win;
+
+    // ---- stage band, K (rotated), V
+    const int nb = (2 * win + 1) * HEADS;
+    for (int i = tid; i < nb; i += 256) band_s[i] = band[i];
+    const float* kg = qkv + p * QKV + HEADS * DH + h * DH;
+    const float* vg = qkv + p * QKV + 2 * HEADS * DH + h * DH;
+    for (int i = tid; i < NKP * 8; i += 256) {
+        const int row = i >> 3, qd = i & 7;
+        const int j = jb0 + row;
+        f32x4 kv = {0.f, 0.f, 0.f, 0.f}, vv = {0.f, 0.f, 0.f, 0.f};
+        if (j >= 0 && j < Fext) {
+            const long off = (long)j * HW * QKV + qd * 4;
+            kv = *reinterpret_cast<const f32x4*>(kg + off);
+            vv = *reinterpret_cast<const f32x4*>(vg + off);
+            const float2 c = *reinterpret_cast<const float2*>(rcos + j * 16 + qd * 2);
+            const float2 s = *reinterpret_cast<const float2*>(rsin + j * 16 + qd * 2);
+            kv = rot4(kv, c.x, s.x, c.y, s.y);
+        }
+        *reinterpret_cast<f32x4*>(Ks + row * KLD + qd * 4) = kv;
+        *reinterpret_cast<f32x4*>(Vs + row * DH + qd * 4) = vv;
+    }
+    __syncthreads();
+
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int i0 = ib0 + 32 * wave;      // this wave's first query
+    if (i0 >= qend) return;              // no barrier after this point
+    const int kl0 = 32 * wave;           // local index of key (i0 - win)
     const float scale = 0.17677669529663687f;  // 32^-0.5 (MT:657, 687)
 
     // ---- Q fragment (B operand): row i = i0 + l31, d chunks {8c + 4*half .. +3}
@@ -69,35 +98,30 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
         for (int c = 0; c < 4; ++c) {
             f32x4 v = *reinterpret_cast<const f32x4*>(qp + 8 * c);
             v = v * scale;
-            q4[c] = rot4(v, cp[4 * c], sp[4 * c], cp[4 * c + 1], sp[4 * c + 1]);
+            const float2 cc = *reinterpret_cast<const float2*>(cp + 4 * c);
+            const float2 ss = *reinterpret_cast<const float2*>(sp + 4 * c);
+            q4[c] = rot4(v, cc.x, ss.x, cc.y, ss.y);
         }
     }
 
-    // ---- S^T tiles
+    // ---- S^T tiles: A = K rows from LDS, B = Q
     f32x16 st[NKT];
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) st[t][r] = 0.f;
-        const int j = j0 + 32 * t + l31;
-        const int jc = j < 0 ? 0 : (j >= Fext ? Fext - 1 : j);
-        const float* kp = qkv + ((long)jc * HW + p) * QKV + HEADS * DH + h * DH + 4 * half;
-        const float* cp = rcos + jc * 16 + 2 * half;
-        const float* sp = rsin + jc * 16 + 2 * half;
-        f32x4 k4[4];
+        const float* kr = Ks + (kl0 + 32 * t + l31) * KLD + 4 * half;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(kp + 8 * c);
-            k4[c] = rot4(v, cp[4 * c], sp[4 * c], cp[4 * c + 1], sp[4 * c + 1]);
-        }
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
+            const f32x4 k4 = *reinterpret_cast<const f32x4*>(kr + 8 * c);
 #pragma unroll
             for (int s = 0; s < 4; ++s)
-                st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[c][s], q4[c][s], st[t], 0, 0, 0);
+                st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[s], q4[c][s], st[t], 0, 0, 0);
+        }
     }
 
     // ---- bias + mask + softmax over keys (this lane's query = iq)
+    const int j0 = i0 - win;
     float m = NEG;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
@@ -105,7 +129,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
         for (int r = 0; r < 16; ++r) {
             const int jj = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
             const int j = j0 + jj;
-            const int rel = j - iq;  // = jj - win - l31
+            const int rel = j - iq;
             const bool ok = (rel >= -win) && (rel <= win) && (j >= 0) && (j < Fext);
             const int bi = ok ? (rel + win) * HEADS + h : 0;
             const float sv = ok ? st[t][r] + band_s[bi] : NEG;
@@ -125,23 +149,18 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     l += __shfl_xor(l, 32, 64);
     const float inv = 1.0f / l;
 
-    // ---- O = P.V  (A = P from the accumulators, B = V rows)
+    // ---- O = P.V  (A = P from the accumulators, B = V rows from LDS)
     f32x16 o;
 #pragma unroll
     for (int r = 0; r < 16; ++r) o[r] = 0.f;
-    const float* vbase = qkv + p * QKV + 2 * HEADS * DH + h * DH + l31;
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
-        float vv[16];
+        const float* vr = Vs + (kl0 + 32 * t + 4 * half) * DH + l31;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int j = j0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int jc = j < 0 ? 0 : (j >= Fext ? Fext - 1 : j);
-            vv[r] = vbase[(long)jc * HW * QKV];
+            const float vv = vr[((r & 3) + 8 * (r >> 2)) * DH];
+            o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[t][r] * inv, vv, o, 0, 0, 0);
         }
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            o = __builtin_amdgcn_mfma_f32_32x32x2f32(st[t][r] * inv, vv[r], o, 0, 0, 0);
     }
 
     // ---- store: col d = l31, row = (r&3) + 8(r>>2) + 4*half
@@ -159,14 +178,17 @@ extern "C" int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, in
     if (Fq <= 0) return 0;
     if (q0 < 0 || q0 + Fq > Fext || win < 0) return dawn_set_error_msg(-30, "dawn_temporal_attn: bad frame range");
     const int nkt = (32 + 2 * win + 31) / 32;
-    const int nqt = (Fq + 31) / 32;
-    const long nwaves = (long)HW * HEADS * nqt;
-    const dim3 grid((unsigned)((nwaves + 3) / 4)), block(256);
-    const size_t lds = (size_t)(2 * win + 1) * HEADS * sizeof(float);
+    const int nseg = (Fq + SEG - 1) / SEG;
+    const long nblk = (long)HW * HEADS * nseg;
+    const dim3 grid((unsigned)nblk), block(256);
+    const int nkp = 32 * (3 + nkt);
+    const size_t lds = ((size_t)nkp * (KLD + DH) + (size_t)(2 * win + 1) * HEADS) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TA(N)                                                                                        \
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<N>,                        \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);       \
     hipLaunchKernelGGL(temporal_attn_kernel<N>, grid, block, lds, s, qkv, Fext, HW, q0, Fq, win, rot_cos, \
-                       rot_sin, band, out, nqt, nwaves)
+                       rot_sin, band, out, nseg)
     switch (nkt) {
         case 1: LAUNCH_TA(1); break;
         case 2: LAUNCH_TA(2); break;

@@ -98,7 +98,9 @@ class HipOps:
             check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
             e1.record()
             rows_gemm = rows_out if mode == 0 else F * Hi * Wi * 4
-            self.prof.append((2.0 * rows_gemm * N * KH * KW * (d.C0 + d.C1), e0, e1))
+            self.prof.append((2.0 * rows_gemm * N * KH * KW * (d.C0 + d.C1), e0, e1,
+                              f"M={rows_gemm} N={N} K={KH * KW * (d.C0 + d.C1)} k={KH}x{KW} s={stride} mode={mode} "
+                              f"pro={'r' if row_stats else ''}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}"))
             return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
         return out
@@ -112,15 +114,18 @@ class HipOps:
         self._require(x, gamma, beta)
         nblk = max(1, min(1024, (rows * (Cc // 4) + 255) // 256 // 8))
         part = self.empty(nblk, 16, like=x, dtype=torch.float64)
-        sums = self.empty(16, like=x, dtype=torch.float64)
+        sums = self.empty(16, like=x, dtype=torch.float64) if self.comm is not None else None
         s = self._stream()
         check(self.L.dawn_gn_partial(_p(x), rows, Cc, _ld(x), _p(part), nblk, s), "dawn_gn_partial")
-        check(self.L.dawn_gn_reduce(_p(part), nblk, _p(sums), s), "dawn_gn_reduce")
-        if self.comm is not None:
-            self.comm.all_reduce_sum(sums)
         a = self.empty(Cc, like=x)
         b = self.empty(Cc, like=x)
         fs, fsh = (film if film is not None else (None, None))
+        if self.comm is None:
+            check(self.L.dawn_gn_reduce_finalize(_p(part), nblk, float(total_rows) * (Cc // 8), _p(gamma), _p(beta),
+                                                 _p(fs), _p(fsh), Cc, eps, _p(a), _p(b), s), "dawn_gn_reduce_finalize")
+            return a, b
+        check(self.L.dawn_gn_reduce(_p(part), nblk, _p(sums), s), "dawn_gn_reduce")
+        self.comm.all_reduce_sum(sums)
         check(self.L.dawn_gn_finalize(_p(sums), float(total_rows) * (Cc // 8), _p(gamma), _p(beta), _p(fs), _p(fsh),
                                       Cc, eps, _p(a), _p(b), s), "dawn_gn_finalize")
         return a, b

@@ -100,7 +100,11 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
         film = (film_all[rb.film_off:rb.film_off + Co], film_all[rb.film_off + Co:rb.film_off + 2 * Co])
     c1 = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, **g)
     ab1 = ops.gn_coeffs(c1, rb.g1, rb.be1, film, total_rows)
-    c2 = ops.conv_gemm(c1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, ch_ab=ab1, pro_act=1, pro_add=hcond, **g)
+    # h1 = SiLU(FiLM(GN(c1))) + h_cond is materialised once (one streaming pass) instead of being fused into
+    # the 3x3 loader: an implicit GEMM reads every input element 9x, and 9x exp/div per element cost the conv
+    # ~35 % of its MFMA rate (profiles/r1_b_conv_shapes.txt) -- far more than the extra 3 x C x 4 B per pixel.
+    h1 = ops.gn_apply_res(c1, ab1[0], ab1[1], hcond)
+    c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, **g)
     a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows)
     if rb.wr is not None:
         return ops.conv_gemm(x, rb.wr, Co, in1=x2, bias=rb.br, tr=(c2, a2, b2), **g)
