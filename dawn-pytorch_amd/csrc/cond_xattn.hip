@@ -89,47 +89,58 @@ __global__ __launch_bounds__(256) void xattn_core_kernel(const float* __restrict
     }
 }
 
-// one wave per row: out[row][c] = sum_b LN(y3[row][b][:])[c] * g3[b][c]      (Co <= 512)
+// L lanes per row (float4 each): out[row][c] = sum_b LN(y3[row][b][:])[c] * g3[b][c]      (Co <= 512)
+template <int L>
 __global__ __launch_bounds__(256) void xattn_ln_sum_kernel(const float* __restrict__ y3, const float* __restrict__ g3,
                                                            float* __restrict__ out, long rows, int Co, float eps) {
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const int lane = threadIdx.x & 63;
-    constexpr int MAXE = 8;
-    float acc[MAXE];
+    constexpr int RPB = 256 / L;
+    constexpr int MAXQ = 2;
+    const int sub = threadIdx.x % L;
+    const long row = (long)blockIdx.x * RPB + threadIdx.x / L;
+    const bool ok = row < rows;
+    const int nq = Co >> 2;
+    f32x4 acc[MAXQ];
 #pragma unroll
-    for (int i = 0; i < MAXE; ++i) acc[i] = 0.f;
+    for (int i = 0; i < MAXQ; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int b = 0; b < 3; ++b) {
         const float* y = y3 + (row * 3 + b) * Co;
-        float v[MAXE];
+        f32x4 v[MAXQ];
         float s = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXE; ++i) {
-            const int c = lane + 64 * i;
-            v[i] = c < Co ? y[c] : 0.f;
-            s += v[i];
+        for (int i = 0; i < MAXQ; ++i) {
+            const int qd = sub + i * L;
+            v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (ok && qd < nq) {
+                v[i] = *reinterpret_cast<const f32x4*>(y + qd * 4);
+                s += v[i].x + v[i].y + v[i].z + v[i].w;
+            }
         }
-        s = wave_sum(s);
+        s = wave_sum(s, L);
         const float mu = s / (float)Co;
         float ss = 0.f;
 #pragma unroll
-        for (int i = 0; i < MAXE; ++i) {
-            const int c = lane + 64 * i;
-            const float dl = c < Co ? v[i] - mu : 0.f;
-            ss += dl * dl;
+        for (int i = 0; i < MAXQ; ++i) {
+            const int qd = sub + i * L;
+            if (ok && qd < nq) {
+                const f32x4 dl = v[i] - mu;
+                ss += dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w;
+            }
         }
-        ss = wave_sum(ss);
+        ss = wave_sum(ss, L);
         const float rs = rsqrtf(ss / (float)Co + eps);
 #pragma unroll
-        for (int i = 0; i < MAXE; ++i) {
-            const int c = lane + 64 * i;
-            if (c < Co) acc[i] += (v[i] - mu) * rs * g3[b * Co + c];
+        for (int i = 0; i < MAXQ; ++i) {
+            const int qd = sub + i * L;
+            if (ok && qd < nq) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(g3 + b * Co + qd * 4);
+                acc[i] += (v[i] - mu) * rs * g;
+            }
         }
     }
 #pragma unroll
-    for (int i = 0; i < MAXE; ++i) {
-        const int c = lane + 64 * i;
-        if (c < Co) out[row * Co + c] = acc[i];
+    for (int i = 0; i < MAXQ; ++i) {
+        const int qd = sub + i * L;
+        if (ok && qd < nq) *reinterpret_cast<f32x4*>(out + row * Co + qd * 4) = acc[i];
     }
 }
 
@@ -154,9 +165,18 @@ extern "C" int dawn_xattn_core(const float* q, float* o, long rows, int HW, cons
 }
 extern "C" int dawn_xattn_ln_sum(const float* y3, const float* g3, float* out, long rows, int Co, float eps,
                                  void* stream) {
-    if (Co > 512) return dawn_set_error_msg(-50, "dawn_xattn_ln_sum: Co > 512 not supported");
-    hipLaunchKernelGGL(xattn_ln_sum_kernel, dim3(dawn_cdiv(rows, 4)), dim3(256), 0, (hipStream_t)stream, y3, g3, out,
-                       rows, Co, eps);
+    if (Co > 512 || Co % 4 != 0 || Co < 16) return dawn_set_error_msg(-50, "dawn_xattn_ln_sum: need 16 <= Co <= 512");
+    hipStream_t s = (hipStream_t)stream;
+    const int nq = Co / 4;
+#define LAUNCH_XL(L)                                                                                            \
+    hipLaunchKernelGGL(xattn_ln_sum_kernel<L>, dim3(dawn_cdiv(rows, 256 / L)), dim3(256), 0, s, y3, g3, out, rows, \
+                       Co, eps)
+    if (nq >= 64) LAUNCH_XL(64);
+    else if (nq >= 32) LAUNCH_XL(32);
+    else if (nq >= 16) LAUNCH_XL(16);
+    else if (nq >= 8) LAUNCH_XL(8);
+    else LAUNCH_XL(4);
+#undef LAUNCH_XL
     DAWN_LAUNCH_CHECK();
     return 0;
 }

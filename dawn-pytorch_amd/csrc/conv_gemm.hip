@@ -4,110 +4,125 @@
 //
 // Replaces (reference file:line, MT = ...ca_multi_test.py): Block.proj Conv3d(1,3,3) MT:229, res_conv
 // MT:417, Downsample MT:176, Upsample ConvTranspose3d MT:167, init_conv (fea part) MT:776, and all
-// Linear / 1x1 projections MT:505,512,608,609,662,663 -- with the LayerNorm (row statistics) or
-// GroupNorm-apply+FiLM+SiLU (per-channel affine) that precedes them fused into the A-operand loader
-// and bias / residual / "silu(gn(.))" terms fused into the epilogue.
+// Linear / 1x1 projections MT:505,512,608,609,662,663 -- with the LayerNorm (row statistics) that precedes
+// them fused into the A-operand loader and bias / residual / "silu(gn(.))" terms fused into the epilogue.
 //
-// Tiling: 128 x BN block tile, 4 waves (2x2), each wave (64 x BN/2) = TM x TN tiles of 32x32, BK = 16.
-// Activations are channels-last so a K-chunk (one tap, 16 channels) of one pixel is 64 contiguous bytes.
-// LDS A image [row][20] (pad 4 -> conflict-free ds_read_b128), B image [k/4][n][4] (weights are
-// pre-packed in exactly that order, so the B stage is a linear copy).  The MFMA k index is a free
-// permutation: lanes 0-31 feed k = {0..3} (+8), lanes 32-63 feed k = {4..7} (+8) of each chunk, so every
-// lane reads ONE float4 per operand tile for four MFMAs.
+// Tiling: BM x BN block tile, 4 waves (WM x WN), each wave TM x TN tiles of 32x32, K-chunks of BK.
+// Activations are channels-last so a K-chunk (one tap, BK channels of one pixel) is BK*4 contiguous bytes.
+// LDS A image [row][BK+4] (pad -> conflict-free ds_read_b128), B image [k/4][n][4] (weights are pre-packed
+// in exactly that order, so the B stage is a linear copy).  The MFMA k index is a free permutation:
+// lanes 0-31 feed k = {0..3}, lanes 32-63 feed k = {4..7} of each 8-wide k group, so every lane reads ONE
+// float4 per operand tile for four MFMAs.  Workgroups are remapped so that each XCD (private L2) walks a
+// contiguous range of M tiles: the +-1 row halos of a 3x3 conv then hit in that XCD's L2.
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 
 namespace {
 
-constexpr int BM = 128;
-constexpr int BK = 16;
-constexpr int LDA = 20;  // floats per A row in LDS (16 + 4 pad), 80 B: 16-B aligned, conflict-free b128 reads
+// Tuning policy (measured on MI355X, profiles/r1_d_conv_variants.txt): bit0 BK=32 tiles for deep-K GEMMs
+// (K >= 4096, N > 64: +6 %), bit1 256x64 tile for N <= 64 (no gain: off), bit2 XCD-contiguous tile order for
+// multi-tap convs on >= 32x32 frames (+7..17 %; hurts pure streaming 1x1 GEMMs, so not used there).
+static int g_variant = 0x5;
 
 struct RowInfo {
-    int pixbase;  // f * Hi * Wi
-    int yb, xb;   // mode 0: yo*stride - pad ; mode 1: a, b
+    long rowoff;  // (f*Hi + yb)*Wi + xb : input pixel index of tap (0,0) (may point outside; bounds via yb/xb)
+    int yb, xb;
     bool valid;
 };
 
-template <int BN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d) {
-    constexpr int WTN = BN / 2;       // wave tile cols
-    constexpr int TM = 2;             // 64 rows per wave
-    constexpr int TN = WTN / 32;      // 1 (BN=64) or 2 (BN=128)
-    constexpr int NB4 = BN * 4 / 256; // float4 B loads per thread per chunk (1 or 2)
+template <int BM, int BN, int BK, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, const int xcd_remap) {
+    constexpr int LDA = BK + 4;
+    constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
+    constexpr int TM = WTM / 32, TN = WTN / 32;
+    constexpr int TPR = BK / 4;                   // threads (float4) per A row
+    constexpr int RPT = BM * TPR / 256;           // A rows per thread
+    constexpr int RSTEP = 256 / TPR;
+    constexpr int NB4 = BN * (BK / 4) / 256;      // B float4 per thread per chunk
+    constexpr int KQ = BK / 4;
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && RPT >= 1 && NB4 >= 1, "bad tile config");
 
-    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDA + 2 * 4 * BN * 4];
+    __shared__ __attribute__((aligned(16))) float smem[2 * BM * LDA + 2 * KQ * BN * 4];
     float* As = smem;
     float* Bs = smem + 2 * BM * LDA;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
 
     const int Cin = d.C0 + d.C1;
     const int nC = Cin / BK;
-    const int taps = d.KH * d.KW;
-    const int nChunks = taps * nC;
+    const int nChunks = d.KH * d.KW * nC;
     const int phase = blockIdx.z;  // mode 1 only
     const int py = phase >> 1, px = phase & 1;
     const long M = (d.mode == 0) ? (long)d.F * d.Ho * d.Wo : (long)d.F * d.Hi * d.Wi;
     const int nNt = (d.N + BN - 1) / BN;
-    const int mt = blockIdx.x / nNt, nt = blockIdx.x % nNt;
+    const int nMt = (int)((M + BM - 1) / BM);
+    // ---- tile assignment: n fastest; optionally give each XCD a contiguous range of M tiles
+    int bid = blockIdx.x;
+    if (xcd_remap) {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;   // bijective for any nwg
+    }
+    const int mt = bid / nNt, nt = bid - mt * nNt;
+    if (mt >= nMt) return;
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
     const float* wbase = d.w + (d.mode == 1 ? (size_t)phase * (size_t)nChunks * BK * d.N : 0);
 
     // ---- per-thread A rows
-    const int kqA = tid & 3;
-    RowInfo ri[2];
+    const int kqA = tid % TPR;
+    const int r0 = tid / TPR;
+    RowInfo ri[RPT];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        long m = m0 + (tid >> 2) + 64 * i;
+    for (int i = 0; i < RPT; ++i) {
+        const long m = m0 + r0 + RSTEP * i;
         ri[i].valid = m < M;
-        long mm = ri[i].valid ? m : 0;
+        const long mm = ri[i].valid ? m : 0;
         if (d.mode == 0) {
-            int hw = d.Ho * d.Wo;
-            int f = (int)(mm / hw);
-            int rem = (int)(mm - (long)f * hw);
-            int yo = rem / d.Wo, xo = rem - yo * d.Wo;
-            ri[i].pixbase = f * d.Hi * d.Wi;
+            const int hw = d.Ho * d.Wo;
+            const int f = (int)(mm / hw);
+            const int rem = (int)(mm - (long)f * hw);
+            const int yo = rem / d.Wo, xo = rem - yo * d.Wo;
             ri[i].yb = yo * d.stride - d.pad;
             ri[i].xb = xo * d.stride - d.pad;
+            ri[i].rowoff = ((long)f * d.Hi + ri[i].yb) * d.Wi + ri[i].xb;
         } else {
-            int hw = d.Hi * d.Wi;
-            int f = (int)(mm / hw);
-            int rem = (int)(mm - (long)f * hw);
-            int a = rem / d.Wi, b = rem - a * d.Wi;
-            ri[i].pixbase = f * hw;
-            ri[i].yb = a;
-            ri[i].xb = b;
+            const int hw = d.Hi * d.Wi;
+            const int f = (int)(mm / hw);
+            const int rem = (int)(mm - (long)f * hw);
+            ri[i].yb = rem / d.Wi;
+            ri[i].xb = rem - ri[i].yb * d.Wi;
+            ri[i].rowoff = (long)f * hw + rem;
         }
     }
 
-    f32x4 ga[2];
+    f32x4 ga[RPT];
     f32x4 gb[NB4];
+    // incremental chunk state (uniform): channel chunk, tap coordinates
+    int cc = 0, ky = 0, kx = 0;
 
     auto load_chunk = [&](int chunk) {
-        const int tap = chunk / nC;
-        const int cc = chunk - tap * nC;
-        const int ky = tap / d.KW, kx = tap - ky * d.KW;
         int dy, dx;
         if (d.mode == 0) { dy = ky; dx = kx; }
         else { dy = ky ? (py ? 1 : -1) : 0; dx = kx ? (px ? 1 : -1) : 0; }
+        const int tapoff = dy * d.Wi + dx;
         const int c = cc * BK + kqA * 4;
         const bool src1 = c >= d.C0;
         const float* src = src1 ? d.in1 : d.in0;
         const int ld = src1 ? d.ld1 : d.ld0;
         const int cs = src1 ? c - d.C0 : c;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < RPT; ++i) {
             const int yi = ri[i].yb + dy, xi = ri[i].xb + dx;
             const bool inb = ri[i].valid && yi >= 0 && yi < d.Hi && xi >= 0 && xi < d.Wi;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
             if (inb) {
-                const long pix = (long)ri[i].pixbase + (long)yi * d.Wi + xi;
+                const long pix = ri[i].rowoff + tapoff;
                 v = *reinterpret_cast<const f32x4*>(src + pix * ld + cs);
                 if (d.row_mean) {
                     const float mu = d.row_mean[pix], rs = d.row_rstd[pix];
@@ -128,20 +143,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d) 
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
             const int idx = tid + 256 * i;
-            const int kq = idx / BN, n = idx - kq * BN;
+            const int kq = idx / BN, n = idx % BN;   // BN is a power of two
             const int gn = n0 + n;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (gn < d.N) v = *reinterpret_cast<const f32x4*>(wbase + ((size_t)(chunk * 4 + kq) * d.N + gn) * 4);
+            if (gn < d.N) v = *reinterpret_cast<const f32x4*>(wbase + ((size_t)(chunk * KQ + kq) * d.N + gn) * 4);
             gb[i] = v;
+        }
+        // advance the uniform chunk state
+        if (++cc == nC) {
+            cc = 0;
+            if (++kx == d.KW) { kx = 0; ++ky; }
         }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
-            *reinterpret_cast<f32x4*>(As + buf * BM * LDA + ((tid >> 2) + 64 * i) * LDA + kqA * 4) = ga[i];
+        for (int i = 0; i < RPT; ++i)
+            *reinterpret_cast<f32x4*>(As + buf * BM * LDA + (r0 + RSTEP * i) * LDA + kqA * 4) = ga[i];
 #pragma unroll
         for (int i = 0; i < NB4; ++i)
-            *reinterpret_cast<f32x4*>(Bs + buf * 4 * BN * 4 + (tid + 256 * i) * 4) = gb[i];
+            *reinterpret_cast<f32x4*>(Bs + buf * KQ * BN * 4 + (tid + 256 * i) * 4) = gb[i];
     };
 
     f32x16 acc[TM][TN];
@@ -160,14 +180,14 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d) 
         const int buf = chunk & 1;
         if (chunk + 1 < nChunks) load_chunk(chunk + 1);
         const float* Ab = As + buf * BM * LDA;
-        const float* Bb = Bs + buf * 4 * BN * 4;
+        const float* Bb = Bs + buf * KQ * BN * 4;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 8; ++kk) {
             const int kq = kk * 2 + half;
             f32x4 a[TM], b[TN];
 #pragma unroll
             for (int i = 0; i < TM; ++i)
-                a[i] = *reinterpret_cast<const f32x4*>(Ab + (wm * 64 + i * 32 + l31) * LDA + kq * 4);
+                a[i] = *reinterpret_cast<const f32x4*>(Ab + (wm * WTM + i * 32 + l31) * LDA + kq * 4);
 #pragma unroll
             for (int j = 0; j < TN; ++j)
                 b[j] = *reinterpret_cast<const f32x4*>(Bb + (kq * BN + wn * WTN + j * 32 + l31) * 4);
@@ -188,7 +208,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d) 
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const long m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m >= M) continue;
             long orow = m;
             if (d.mode == 1) {
@@ -212,12 +232,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d) 
     }
 }
 
+template <int BM, int BN, int BK, int WM, int WN>
+void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
+    const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
+    const int z = d.mode == 1 ? 4 : 1;
+    const int nwg = nMt * nNt;
+    const int remap = ((g_variant & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN>), dim3(nwg, 1, z), dim3(256), 0, s, d, remap);
+}
+
 }  // namespace
+
+extern "C" void dawn_conv_set_variant(int v) { g_variant = v; }
 
 extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     const dawn_conv_desc d = *dp;
     const int Cin = d.C0 + d.C1;
-    if (d.C0 % BK != 0 || d.C1 % BK != 0 || Cin == 0)
+    if (d.C0 % 16 != 0 || d.C1 % 16 != 0 || Cin == 0)
         return dawn_set_error_msg(-10, "dawn_conv_gemm: channel counts must be multiples of 16");
     if ((d.ld0 % 4) || (d.in1 && (d.ld1 % 4)) || (d.pro_add && (d.ld_add % 4)))
         return dawn_set_error_msg(-11, "dawn_conv_gemm: pixel strides must be multiples of 4 floats");
@@ -227,15 +258,14 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         return dawn_set_error_msg(-13, "dawn_conv_gemm: channel-affine / add prologue needs a single source");
     const long M = (d.mode == 0) ? (long)d.F * d.Ho * d.Wo : (long)d.F * d.Hi * d.Wi;
     if (M <= 0 || d.N <= 0) return 0;
-    const int nMt = dawn_cdiv(M, BM);
     hipStream_t s = (hipStream_t)stream;
-    const int z = d.mode == 1 ? 4 : 1;
+    const bool k32 = (g_variant & 1) && (d.C0 % 32 == 0) && (d.C1 % 32 == 0) && (d.KH * d.KW * Cin >= 4096);
     if (d.N <= 64) {
-        dim3 grid(nMt * dawn_cdiv(d.N, 64), 1, z);
-        hipLaunchKernelGGL(conv_gemm_kernel<64>, grid, dim3(256), 0, s, d);
+        if ((g_variant & 2) && M >= 256 * 256) launch<256, 64, 16, 4, 1>(d, M, s);
+        else launch<128, 64, 16, 2, 2>(d, M, s);
     } else {
-        dim3 grid(nMt * dawn_cdiv(d.N, 128), 1, z);
-        hipLaunchKernelGGL(conv_gemm_kernel<128>, grid, dim3(256), 0, s, d);
+        if (k32) launch<128, 128, 32, 2, 2>(d, M, s);
+        else launch<128, 128, 16, 2, 2>(d, M, s);
     }
     DAWN_LAUNCH_CHECK();
     return 0;

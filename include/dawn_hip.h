@@ -51,6 +51,8 @@ typedef struct dawn_conv_desc {
     float* out; int ld_out;
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
+/* tuning knob for A/B measurements: bit0 BK=32 tiles, bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order */
+void dawn_conv_set_variant(int v);
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --
  * partial: per-block fp64 (sum, sumsq) per group -> part[nblk][16]; reduce: fixed-order sum ->

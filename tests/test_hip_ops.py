@@ -73,6 +73,10 @@ CONV_CASES = [
     ("c7x7_fea", 1, 16, 16, 272, 0, 64, 7, 1, 3, {"bias": True}),
     ("c3x3_512_512_deepK", 7, 4, 4, 512, 0, 512, 3, 1, 1, {"bias": True}),
     ("c3x3_ragged_M", 1, 5, 7, 32, 0, 48, 3, 1, 1, {}),
+    ("c3x3_bigM_N64_tile256", 2, 192, 190, 16, 0, 64, 3, 1, 1, {"bias": True}),
+    ("c1x1_bigM_N64_rowstats_res", 3, 160, 150, 32, 32, 64, 1, 1, 0, {"row_stats": True, "res": True}),
+    ("c3x3_k32_cat_N128", 2, 24, 24, 64, 32, 128, 3, 1, 1, {"bias": True}),
+    ("c3x3_k32_cat_256p256_N128_deepK", 3, 8, 8, 256, 256, 128, 3, 1, 1, {"bias": True}),
 ]
 
 
@@ -102,6 +106,12 @@ def test_conv_gemm(hip, ref, case):
     if ex.get("tr"):
         kw["tr"] = (rnd(F * Ho * Wo, N, seed=9), rnd(N, seed=10) * 0.3 + 1.0, rnd(N, seed=11) * 0.3)
     want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
+    for variant in (0, 7, 5):                      # every tile configuration; 5 = shipped policy (left active)
+        hip.L.dawn_conv_set_variant(variant)
+        _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
+
+
+def _conv_case(hip, name, in0, in1, w, N, kw, want):
     gkw = {k_: (tuple(t.cuda() for t in v) if isinstance(v, tuple) else (v.cuda() if torch.is_tensor(v) else v))
            for k_, v in kw.items()}
     got = hip.conv_gemm(in0.cuda(), w.cuda(), N, in1=None if in1 is None else in1.cuda(), **gkw)
@@ -186,7 +196,7 @@ def test_xattn_pieces(hip, ref):
     want = ref.xattn_core(q.clone(), HW, kvtab_w, nulltab_w, qs)
     got = hip.xattn_core(q.cuda(), HW, kvtab_g, nulltab_g, qs.cuda())
     check("xattn_core", got, want, 1e-5)
-    for Co in (16, 96, 512):
+    for Co in (16, 64, 96, 128, 512):
         y3, g3 = rnd(rows, 3 * Co, seed=5), rnd(3, Co, seed=6) * 0.2 + 1
         check(f"xattn_ln_sum/Co{Co}", hip.xattn_ln_sum(y3.cuda(), g3.cuda(), Co), ref.xattn_ln_sum(y3, g3, Co), 2e-5)
 
