@@ -1,0 +1,306 @@
+// Fused temporal-attention LAYER for 64-channel levels: out = x + to_out(attn(LN(x))) in ONE kernel.
+//
+// Reference: Residual(PreNorm(EinopsToAndFrom('b c f h w','b (h w) f c', Attention))) -- LayerNorm MT:179-188,
+// Attention.forward MT:665-725 (to_qkv, q*scale, rotary, sim + rel-pos bias with the MT:117 window mask,
+// softmax, PV, to_out), Residual MT:141-147.  Used for the four C=64 instances (init, downs.0, ups.2, ups.3),
+// which carry ~85 % of the temporal-attention cost: the unfused path writes and re-reads a (F,HW,768) fp32
+// qkv tensor (2.5 GB at 256x256 / 200 frames) per instance, this kernel reads x once and writes out once.
+//
+// One 8-wave block per pixel column (all frames, all heads).  LDS: LayerNorm'ed rows Xs[F][68], and per head
+// the rotated K rows Ks[F][36] and V rows Vs[F][32].  Every GEMM is issued in "transposed" form
+// (D^T = B^T . A^T) so that results land with lane = frame and registers = feature subset
+// {8c + 4*(lane>>5) + s}: exactly the k-index pattern the NEXT MFMA wants for its B operand.  Hence
+//   Q^T = Wq^T . Xs^T       -> registers ARE the B fragments of S^T = K . Q^T       (rotary is lane-local)
+//   K^T, V^T = W^T . Xs^T   -> one float4 per lane per 4 features, written row-major to LDS
+//   S^T = K . Q^T           -> lane owns one query column: softmax in registers + one xor-32 exchange
+//   O^T = V^T . P^T         -> P fed straight from the S^T accumulators
+//   out^T += Wout_h^T . O^T -> O^T registers are again B fragments; accumulated over the 8 heads
+// No shuffles, no LDS round trips for Q, P or O.
+#include "dawn_common.h"
+#include "../../include/dawn_hip.h"
+
+namespace {
+
+constexpr int C = 64;
+constexpr int HEADS = 8;
+constexpr int DH = 32;
+constexpr int XLD = 68;   // Xs row stride (floats): conflict-free ds_read_b128
+constexpr int KLD = 36;   // Ks row stride
+constexpr float NEG = -1.0e30f;
+
+__device__ __forceinline__ f32x16 zero16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// D^T(32 feat x 32 rows) = W^T . X^T : A = weight fragments (global, packed [K/4][N][4], column n0 + l31),
+// B = row fragments from LDS.  xr points at Xs[row][4*half].
+__device__ __forceinline__ f32x16 proj_T(const float* wp, int Nw, int n, int half, const float* xr) {
+    f32x16 acc = zero16();
+#pragma unroll
+    for (int c = 0; c < C / 8; ++c) {
+        const f32x4 w4 = *reinterpret_cast<const f32x4*>(wp + ((2 * c + half) * Nw + n) * 4);
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xr + 8 * c);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], x4[s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+// WLDS: stage the head's weight slices (Wq|Wk|Wv 64x96 + Wout 32x64 = 32 KB) in LDS, prefetched one head
+// ahead through registers, so no MFMA waits on an L2 round trip (used when the LDS budget allows: F <= 224).
+template <int NKT, bool WLDS>
+__global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
+    const float* __restrict__ x, int Fext, int HW, int q0, int Fq, int win, const float* __restrict__ wqkv,
+    const float* __restrict__ wout, const float* __restrict__ rcos, const float* __restrict__ rsin,
+    const float* __restrict__ band, float eps, float* __restrict__ out, int nrt) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int FP = 32 * nrt;                // padded frame rows
+    float* Xs = smem;                       // [FP][XLD]
+    float* Ks = Xs + FP * XLD;              // [FP][KLD]
+    float* Vs = Ks + FP * KLD;              // [FP][DH]
+    float* band_s = Vs + FP * DH;           // [(2*win+1)][8]
+    float* Wl = band_s + (((2 * win + 1) * HEADS + 3) & ~3);   // WLDS: [16][96][4] qkv slices, then [8][64][4] out
+    float* Wo = Wl + 16 * 96 * 4;
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const long p = blockIdx.x;
+
+    // ---- phase 0: LayerNorm rows into LDS (16 lanes per row, float4 each)
+    for (int i = tid; i < (2 * win + 1) * HEADS; i += 512) band_s[i] = band[i];
+    {
+        const int sub = tid & 15;
+        for (int j = tid >> 4; j < FP; j += 32) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
+            if (j < Fext) v = *reinterpret_cast<const f32x4*>(x + ((long)j * HW + p) * C + sub * 4);
+            float s = v.x + v.y + v.z + v.w;
+            s = wave_sum(s, 16);
+            const float mu = s * (1.0f / C);
+            const f32x4 dl = v - mu;
+            float ss = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w;
+            ss = wave_sum(ss, 16);
+            const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
+            f32x4 o = dl * rs;
+            if (j >= Fext) o = f32x4{0.f, 0.f, 0.f, 0.f};
+            *reinterpret_cast<f32x4*>(Xs + j * XLD + sub * 4) = o;
+        }
+    }
+    __syncthreads();
+
+    const int nqt = (Fq + 31) >> 5;
+    const bool has_q = wave < nqt;           // this wave's query tile (8 waves => Fq <= 256)
+    const int i0 = q0 + 32 * wave;
+    const int iq = i0 + l31;
+    const int iqc = iq < Fext ? iq : Fext - 1;
+    const int qend = q0 + Fq;
+    const float scale = 0.17677669529663687f;
+    f32x16 outT[2];
+    outT[0] = zero16();
+    outT[1] = zero16();
+
+    // weight prefetch (WLDS): thread t carries float4 #(t + 512 i), i < 4, of the head's 2048-float4 weight image
+    f32x4 wpre[4];
+    auto wfetch = [&](int h) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 512 * i;
+            const float* src;
+            if (idx < 1536) {
+                const int kq = idx / 96, nn = idx - kq * 96;
+                src = wqkv + ((size_t)kq * (3 * HEADS * DH) + (nn >> 5) * (HEADS * DH) + h * DH + (nn & 31)) * 4;
+            } else {
+                const int jx = idx - 1536;
+                src = wout + ((size_t)(h * (DH / 4) + (jx >> 6)) * C + (jx & 63)) * 4;
+            }
+            wpre[i] = *reinterpret_cast<const f32x4*>(src);
+        }
+    };
+    if (WLDS) wfetch(0);
+
+    for (int h = 0; h < HEADS; ++h) {
+        if (WLDS) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) *reinterpret_cast<f32x4*>(Wl + (tid + 512 * i) * 4) = wpre[i];
+            __syncthreads();
+            if (h + 1 < HEADS) wfetch(h + 1);
+        }
+        const float* wq_p = WLDS ? Wl : wqkv + (size_t)(h * DH) * 4;
+        const float* wk_p = WLDS ? Wl + 32 * 4 : wqkv + (size_t)(HEADS * DH + h * DH) * 4;
+        const float* wv_p = WLDS ? Wl + 64 * 4 : wqkv + (size_t)(2 * HEADS * DH + h * DH) * 4;
+        const int wN = WLDS ? 96 : 3 * HEADS * DH;
+        // ---- K^T / V^T projection of every frame row, rotary on K, row-major into LDS
+        for (int rt = wave; rt < nrt; rt += 8) {
+            const int j = 32 * rt + l31;
+            const float* xr = Xs + j * XLD + 4 * half;
+            f32x16 kT = proj_T(wk_p, wN, l31, half, xr);
+            f32x16 vT = proj_T(wv_p, wN, l31, half, xr);
+            const int jc = j < Fext ? j : Fext - 1;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float2 cc = *reinterpret_cast<const float2*>(rcos + jc * 16 + 4 * c + 2 * half);
+                const float2 sn = *reinterpret_cast<const float2*>(rsin + jc * 16 + 4 * c + 2 * half);
+                f32x4 k4;
+                k4.x = kT[4 * c] * cc.x - kT[4 * c + 1] * sn.x;
+                k4.y = kT[4 * c + 1] * cc.x + kT[4 * c] * sn.x;
+                k4.z = kT[4 * c + 2] * cc.y - kT[4 * c + 3] * sn.y;
+                k4.w = kT[4 * c + 3] * cc.y + kT[4 * c + 2] * sn.y;
+                *reinterpret_cast<f32x4*>(Ks + j * KLD + 8 * c + 4 * half) = k4;
+                *reinterpret_cast<f32x4*>(Vs + j * DH + 8 * c + 4 * half) =
+                    f32x4{vT[4 * c], vT[4 * c + 1], vT[4 * c + 2], vT[4 * c + 3]};
+            }
+        }
+        __syncthreads();
+
+        if (has_q) {
+            // ---- Q^T for this wave's 32 queries (registers = B fragments), scale + rotary (lane-local)
+            f32x16 qT = proj_T(wq_p, wN, l31, half, Xs + iqc * XLD + 4 * half);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const float2 cc = *reinterpret_cast<const float2*>(rcos + iqc * 16 + 4 * c + 2 * half);
+                const float2 sn = *reinterpret_cast<const float2*>(rsin + iqc * 16 + 4 * c + 2 * half);
+                const float a0 = qT[4 * c] * scale, a1 = qT[4 * c + 1] * scale;
+                const float a2 = qT[4 * c + 2] * scale, a3 = qT[4 * c + 3] * scale;
+                qT[4 * c] = a0 * cc.x - a1 * sn.x;
+                qT[4 * c + 1] = a1 * cc.x + a0 * sn.x;
+                qT[4 * c + 2] = a2 * cc.y - a3 * sn.y;
+                qT[4 * c + 3] = a3 * cc.y + a2 * sn.y;
+            }
+            // ---- S^T tiles: keys j0 + 32t + row
+            const int j0 = i0 - win;
+            f32x16 st[NKT];
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+                st[t] = zero16();
+                int j = j0 + 32 * t + l31;
+                j = j < 0 ? 0 : (j >= FP ? FP - 1 : j);
+                const float* kr = Ks + j * KLD + 4 * half;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 k4 = *reinterpret_cast<const f32x4*>(kr + 8 * c);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[s], qT[4 * c + s], st[t], 0, 0, 0);
+                }
+            }
+            // ---- bias + mask + softmax (lane's query = iq)
+            // (opaque copy: keeps the compiler from hoisting the 64 head-invariant mask/index values out of the
+            //  head loop, which costs 64+ live VGPRs and spills)
+            int j0m = j0;
+            asm volatile("" : "+v"(j0m));
+            float m = NEG;
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int j = j0m + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    const int rel = j - iq;
+                    const bool ok = (rel >= -win) && (rel <= win) && (j >= 0) && (j < Fext);
+                    const int bi = ok ? (rel + win) * HEADS + h : 0;
+                    const float sv = ok ? st[t][r] + band_s[bi] : NEG;
+                    st[t][r] = sv;
+                    m = fmaxf(m, sv);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int t = 0; t < NKT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = expf(st[t][r] - m);
+                    st[t][r] = pv;
+                    l += pv;
+                }
+            l += __shfl_xor(l, 32, 64);
+            const float inv = 1.0f / l;
+            // ---- O^T = V^T . P^T  (A = V column fragments from LDS, B = P from the accumulators)
+            f32x16 oT = zero16();
+#pragma unroll
+            for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int j = j0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    j = j < 0 ? 0 : (j >= FP ? FP - 1 : j);
+                    oT = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[j * DH + l31], st[t][r] * inv, oT, 0, 0, 0);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep at most one key tile of V fragments in flight
+            }
+            // ---- out^T += Wout_h^T . O^T   (A = to_out rows h*32 + d, columns n)
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 w4 = WLDS
+                        ? *reinterpret_cast<const f32x4*>(Wo + ((2 * c + half) * C + 32 * nt + l31) * 4)
+                        : *reinterpret_cast<const f32x4*>(
+                              wout + ((size_t)(h * (DH / 4) + 2 * c + half) * C + 32 * nt + l31) * 4);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s)
+                        outT[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], oT[4 * c + s], outT[nt], 0, 0, 0);
+                    if (c == 1) __builtin_amdgcn_sched_barrier(0);
+                }
+        }
+        __syncthreads();   // Ks / Vs are rewritten by the next head
+    }
+
+    // ---- residual + store: lane = query iq, registers 4g..4g+3 = channels 32nt + 8g + 4half + {0..3}
+    if (has_q && iq < qend) {
+        const float* xr = x + ((long)iq * HW + p) * C;
+        float* orow = out + ((long)(iq - q0) * HW + p) * C;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * nt + 8 * g + 4 * half;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + n);
+                f32x4 o = {outT[nt][4 * g], outT[nt][4 * g + 1], outT[nt][4 * g + 2], outT[nt][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(orow + n) = o + xv;
+            }
+    }
+}
+
+}  // namespace
+
+extern "C" int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
+                                       const float* wout, const float* rot_cos, const float* rot_sin,
+                                       const float* band, float eps, float* out, void* stream) {
+    if (Fq <= 0) return 0;
+    if (q0 < 0 || q0 + Fq > Fext || win < 0) return dawn_set_error_msg(-32, "dawn_temporal_layer_c64: bad frame range");
+    if (Fq > 256 || Fext > 288) return dawn_set_error_msg(-33, "dawn_temporal_layer_c64: Fq <= 256 and Fext <= 288 only");
+    const int nkt = (32 + 2 * win + 31) / 32;
+    const int nrt = (Fext + 31) / 32;
+    const size_t base = ((size_t)32 * nrt * (XLD + KLD + DH) + (size_t)(((2 * win + 1) * HEADS + 3) & ~3)) * sizeof(float);
+    const bool wlds = base + 32768 <= 163840;
+    const size_t lds = base + (wlds ? 32768 : 0);
+    if (lds > 163840) return dawn_set_error_msg(-34, "dawn_temporal_layer_c64: LDS budget exceeded");
+    hipStream_t s = (hipStream_t)stream;
+#define LAUNCH_TL(N)                                                                                           \
+    do {                                                                                                       \
+        if (wlds) {                                                                                            \
+            (void)hipFuncSetAttribute((const void*)temporal_layer_c64_kernel<N, true>,                         \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+            hipLaunchKernelGGL((temporal_layer_c64_kernel<N, true>), dim3(HW), dim3(512), lds, s, x, Fext, HW, \
+                               q0, Fq, win, wqkv, wout, rot_cos, rot_sin, band, eps, out, nrt);                \
+        } else {                                                                                               \
+            (void)hipFuncSetAttribute((const void*)temporal_layer_c64_kernel<N, false>,                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+            hipLaunchKernelGGL((temporal_layer_c64_kernel<N, false>), dim3(HW), dim3(512), lds, s, x, Fext,    \
+                               HW, q0, Fq, win, wqkv, wout, rot_cos, rot_sin, band, eps, out, nrt);            \
+        }                                                                                                      \
+    } while (0)
+    switch (nkt) {
+        case 1: LAUNCH_TL(1); break;
+        case 2: LAUNCH_TL(2); break;
+        case 3: LAUNCH_TL(3); break;
+        case 4: LAUNCH_TL(4); break;
+        default: return dawn_set_error_msg(-35, "dawn_temporal_layer_c64: win > 48 not supported (use the unfused path)");
+    }
+#undef LAUNCH_TL
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}

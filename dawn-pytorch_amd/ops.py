@@ -179,6 +179,20 @@ class HipOps:
                                         self._stream()), "dawn_temporal_attn")
         return out
 
+    @staticmethod
+    def can_fuse_temporal(C: int, Fext: int, Fq: int, win: int) -> bool:
+        return C == 64 and Fext <= 288 and Fq <= 256 and win <= 48
+
+    def temporal_layer_c64(self, x: Tensor, Fext: int, HW: int, q0: int, Fq: int, win: int, wqkv: Tensor,
+                           wout: Tensor, rcos: Tensor, rsin: Tensor, band: Tensor, eps: float = 1e-5) -> Tensor:
+        """out = x[q0:q0+Fq] + to_out(attn(LayerNorm(x))) for 64-channel levels, one kernel."""
+        assert x.is_contiguous() and x.shape == (Fext * HW, 64)
+        self._require(x, wqkv, wout, rcos, rsin, band)
+        out = self.empty(Fq * HW, 64, like=x)
+        check(self.L.dawn_temporal_layer_c64(_p(x), Fext, HW, q0, Fq, win, _p(wqkv), _p(wout), _p(rcos), _p(rsin),
+                                             _p(band), eps, _p(out), self._stream()), "dawn_temporal_layer_c64")
+        return out
+
     def sla(self, qkv: Tensor, F: int, HW: int) -> Tensor:
         assert qkv.is_contiguous() and qkv.shape == (F * HW, 768)
         ctx = self.empty(F, 8, 32, 32, like=qkv)

@@ -119,6 +119,8 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
     else:
         xe, q0 = x, 0
     Fext = xe.shape[0] // HW
+    if ops.can_fuse_temporal(a.C, Fext, F, cs.win):
+        return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band)
     stats = ops.ln_rowstats(xe)
     qkv = ops.conv_gemm(xe, a.wqkv, 768, row_stats=stats, F=Fext, Hi=H, Wi=W)
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)

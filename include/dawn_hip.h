@@ -93,6 +93,13 @@ int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, int Fq, int w
                        const float* rot_cos, const float* rot_sin, const float* band,
                        float* out, void* stream);
 
+/* Fused LAYER for 64-channel levels: out[(i-q0)] = x[i] + to_out(attn(LayerNorm(x)))  (MT:179-188, 665-725,
+ * 141-147) -- x (Fext*HW, 64) rows, packed wqkv [(64/4)][768][4] (LayerNorm gain folded), wout [(256/4)][64][4].
+ * Limits: Fext <= 288, Fq <= 256, win <= 48; the caller falls back to the unfused ops otherwise. */
+int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
+                            const float* wout, const float* rot_cos, const float* rot_sin, const float* band,
+                            float eps, float* out, void* stream);
+
 /* ---- A8 SpatialLinearAttention core (MT:611-627) ---------------------------------------------- */
 int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);     /* ctx (F,8,32,32) */
 int dawn_sla_apply(const float* qkv, const float* ctx, int F, int HW, float* out, void* stream); /* out (F*HW,256) */

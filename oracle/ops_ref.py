@@ -167,6 +167,17 @@ class RefOps:
         o = torch.einsum("nhij,nhjd->nhid", att, v)                          # (HW, 8, Fq, 32)
         return o.permute(2, 0, 1, 3).reshape(Fq * HW, 256).contiguous()
 
+    @staticmethod
+    def can_fuse_temporal(C, Fext, Fq, win):
+        return C == 64 and Fext <= 288 and Fq <= 256 and win <= 48
+
+    def temporal_layer_c64(self, x, Fext, HW, q0, Fq, win, wqkv, wout, rcos, rsin, band, eps=1e-5):
+        """Composition of the unfused reference ops (what the fused kernel must equal)."""
+        stats = self.ln_rowstats(x, None, eps)
+        qkv = self.conv_gemm(x, wqkv, 768, row_stats=stats, F=Fext, Hi=1, Wi=HW)
+        o = self.temporal_attn(qkv, Fext, HW, q0, Fq, win, rcos, rsin, band)
+        return self.conv_gemm(o, wout, 64, res=x[q0 * HW:(q0 + Fq) * HW], F=Fq, Hi=1, Wi=HW)
+
     def sla(self, qkv, F, HW):
         x = qkv.reshape(F, HW, 3, 8, 32)
         q = x[:, :, 0].permute(0, 2, 3, 1)                                   # (F, 8, 32, HW)

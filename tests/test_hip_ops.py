@@ -214,6 +214,20 @@ def test_temporal_attn(hip, ref, Fext, HW, q0, Fq, win):
     check(f"temporal_attn/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 2e-5)
 
 
+@pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(12, 5, 0, 12, 3), (200, 3, 0, 200, 40), (280, 2, 40, 200, 40),
+                                                 (45, 4, 3, 40, 7), (33, 2, 0, 33, 40), (240, 2, 40, 200, 40)])
+def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
+    """Fused layer kernel == composition of LN stats + qkv GEMM + windowed attention + out GEMM + residual."""
+    x = rnd(Fext * HW, 64, seed=1) * 1.3 + 0.2
+    wqkv, wout = packw(64, 768, seed=2), packw(256, 64, seed=3)
+    ang = torch.arange(Fext).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
+    rc, rs = ang.cos().contiguous(), ang.sin().contiguous()
+    band = rnd(2 * win + 1, 8, seed=4)
+    want = ref.temporal_layer_c64(x, Fext, HW, q0, Fq, win, wqkv, wout, rc, rs, band)
+    got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band))
+    check(f"temporal_layer_c64/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 3e-5)
+
+
 @pytest.mark.parametrize("F,HW", [(3, 64), (2, 256), (5, 16), (2, 100)])
 def test_sla(hip, ref, F, HW):
     qkv = rnd(F * HW, 768, seed=1)
