@@ -1,0 +1,275 @@
+// Fused SpatialLinearAttention LAYER for 64-channel levels: out = x + to_out(linattn(LN(x))) in two kernels,
+// without ever materialising q/k/v.
+//
+// Reference: Residual(PreNorm(SpatialLinearAttention)) -- LayerNorm MT:179-188, SpatialLinearAttention.forward
+// MT:611-627 (to_qkv 1x1 conv, q.softmax(d), k.softmax(pixels), q*scale, context = k v^T, out = context^T q,
+// to_out 1x1 conv + bias), Residual MT:141-147.
+//
+//  kernel 1 (sla_c64_context): one 8-wave block per frame, wave = head.  Two sweeps over the frame's pixels
+//    (32-pixel tiles, LayerNorm'ed rows staged in LDS): sweep 1 = exact column max of K (softmax over pixels),
+//    sweep 2 = ctx[d][e] += exp(K - max)^T . V with K, V computed on the fly (Wk_h / Wv_h live in registers).
+//    The per-head 32x32 context is normalised and folded with the head's to_out rows:
+//    M_h = (ctx_h / den) . Wout_h  (32 x 64), stored in the packed [k/4][n][4] order of an MFMA A operand.
+//  kernel 2 (sla_c64_apply): per 32-pixel tile: Q^T = Wq_h^T . x^T (registers), softmax over d in registers,
+//    out^T += M_h^T . q^T over the 8 heads, + bias + residual.
+// Both use the transposed-GEMM chaining of temporal_layer.hip: results land as B fragments of the next MFMA.
+#include "dawn_common.h"
+#include "../../include/dawn_hip.h"
+
+namespace {
+
+constexpr int C = 64;
+constexpr int HEADS = 8;
+constexpr int DH = 32;
+constexpr int XLD = 68;
+constexpr int QKVN = 3 * HEADS * DH;
+
+__device__ __forceinline__ f32x16 z16() {
+    f32x16 z;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) z[r] = 0.f;
+    return z;
+}
+
+// stage one 32-pixel tile of LayerNorm'ed rows into LDS: thread t -> pixel t>>4, float4 t&15 (512 threads)
+__device__ __forceinline__ void stage_tile(const float* __restrict__ xf, int n0, int HW, float eps, float* Xt, int tid) {
+    const int px = tid >> 4, sub = tid & 15;
+    const int n = n0 + px;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < HW) v = *reinterpret_cast<const f32x4*>(xf + (long)n * C + sub * 4);
+    float s = v.x + v.y + v.z + v.w;
+    s = wave_sum(s, 16);
+    const float mu = s * (1.0f / C);
+    const f32x4 dl = v - mu;
+    float ss = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w;
+    ss = wave_sum(ss, 16);
+    const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
+    f32x4 o = dl * rs;
+    if (n >= HW) o = f32x4{0.f, 0.f, 0.f, 0.f};
+    *reinterpret_cast<f32x4*>(Xt + px * XLD + sub * 4) = o;
+}
+
+// normal-form projection tile: D[px][feat] = sum_c X[px][c] W[c][feat]; A = X rows (LDS), B = weight frags (regs)
+__device__ __forceinline__ f32x16 proj_N(const float* Xt, int l31, int half, const f32x4* w) {
+    f32x16 acc = z16();
+    const float* xr = Xt + l31 * XLD + 4 * half;
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(xr + 8 * c);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(x4[s], w[c][s], acc, 0, 0, 0);
+    }
+    return acc;
+}
+
+__global__ __launch_bounds__(512) void sla_c64_context_kernel(const float* __restrict__ x, int HW,
+                                                              const float* __restrict__ wqkv,
+                                                              const float* __restrict__ wout, float eps,
+                                                              float* __restrict__ Mout) {
+    __shared__ __attribute__((aligned(16))) float Xs[2][32 * XLD];
+    __shared__ __attribute__((aligned(16))) float cT[HEADS][32 * 36];
+    const int tid = threadIdx.x;
+    const int h = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int f = blockIdx.x;
+    const float* xf = x + (long)f * HW * C;
+    const int ntiles = (HW + 31) >> 5;
+
+    // weight fragments of this wave's head: B[k=c][j=feat] -> packed float4 at ((2c'+half)*768 + col)*4
+    f32x4 wk[8], wv[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        wk[c] = *reinterpret_cast<const f32x4*>(wqkv + ((size_t)(2 * c + half) * QKVN + HEADS * DH + h * DH + l31) * 4);
+        wv[c] = *reinterpret_cast<const f32x4*>(wqkv + ((size_t)(2 * c + half) * QKVN + 2 * HEADS * DH + h * DH + l31) * 4);
+    }
+
+    // ---- sweep 1: column max of K over all pixels of the frame (lane column = feature d)
+    float mx = -3.0e38f;
+    stage_tile(xf, 0, HW, eps, Xs[0], tid);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage_tile(xf, 32 * (t + 1), HW, eps, Xs[(t + 1) & 1], tid);
+        const f32x16 kt = proj_N(Xs[t & 1], l31, half, wk);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (n < HW) mx = fmaxf(mx, kt[r]);
+        }
+        __syncthreads();
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+
+    // ---- sweep 2: ctx[d][e] += exp(K - max)[n][d] * V[n][e], den[d] += exp(K - max)[n][d]
+    f32x16 ctx = z16();
+    float den = 0.f;
+    stage_tile(xf, 0, HW, eps, Xs[0], tid);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage_tile(xf, 32 * (t + 1), HW, eps, Xs[(t + 1) & 1], tid);
+        f32x16 kt = proj_N(Xs[t & 1], l31, half, wk);
+        const f32x16 vt = proj_N(Xs[t & 1], l31, half, wv);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float e = n < HW ? expf(kt[r] - mx) : 0.f;
+            kt[r] = e;
+            den += e;
+        }
+        // ctx^T? : D[i=d][j=e] = sum_n ek[n][d] v[n][e]; A = ek (lane col d, k = row n), B = v (lane col e)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[r], vt[r], ctx, 0, 0, 0);
+        __syncthreads();
+    }
+    den += __shfl_xor(den, 32, 64);                 // lane l31 = d: softmax denominator of column d
+    // normalise rows d of ctx (lane col e, rows d by register): 1/den[d] via LDS
+    float* dens = Xs[0];                            // reuse (all waves are past the last tile barrier)
+    if (half == 0) dens[h * 32 + l31] = 1.0f / den;
+    __syncthreads();
+    float* ct = cT[h];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+        ct[d * 36 + l31] = ctx[r] * dens[h * 32 + d];
+    }
+    __syncthreads();
+    // ---- M_h[d][n] = sum_e ctxn[d][e] Wout[h*32+e][n] : A = ctxn rows d (LDS float4 over e), B = Wout frags
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        f32x16 m = z16();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ct + l31 * 36 + 8 * c + 4 * half);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(wout + ((size_t)(h * 8 + 2 * c + half) * C + 32 * nt + l31) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) m = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], m, 0, 0, 0);
+        }
+        // m: lane col n = 32nt + l31, rows d = 8g + 4half + {0..3} for regs 4g..4g+3 -> packed [h][d/4][n][4]
+        float* mo = Mout + (long)f * (HEADS * 8 * C * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(mo + ((size_t)(h * 8 + 2 * g + half) * C + 32 * nt + l31) * 4) =
+                f32x4{m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]};
+    }
+}
+
+// one block per (frame, split): LDS = Wq for all heads [16][256][4] (64 KB) + the frame's M [8][8][64][4] (64 KB)
+__global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* __restrict__ x, int HW,
+                                                            const float* __restrict__ wqkv,
+                                                            const float* __restrict__ Mg, const float* __restrict__ bias,
+                                                            float eps, float* __restrict__ out, int nsplit) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* Wq = smem;                   // [16][256][4]
+    float* Ms = smem + 16 * 256 * 4;    // [64][64][4]  (h*8 + d/4, n)
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int f = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+    for (int i = tid; i < 16 * 256; i += 512) {
+        const int kq = i >> 8, n = i & 255;
+        *reinterpret_cast<f32x4*>(Wq + i * 4) = *reinterpret_cast<const f32x4*>(wqkv + ((size_t)kq * QKVN + n) * 4);
+    }
+    const float* mf = Mg + (long)f * (HEADS * 8 * C * 4);
+    for (int i = tid; i < 64 * 64; i += 512)
+        *reinterpret_cast<f32x4*>(Ms + i * 4) = *reinterpret_cast<const f32x4*>(mf + (size_t)i * 4);
+    __syncthreads();
+
+    const int ntiles = (HW + 31) >> 5;
+    const int per = (ntiles + nsplit - 1) / nsplit;
+    const int t0 = sp * per, t1 = min(ntiles, t0 + per);
+    const float scale = 0.17677669529663687f;
+    for (int t = t0 + wave; t < t1; t += 8) {
+        const int n = 32 * t + l31;
+        const int nc = n < HW ? n : HW - 1;
+        const float* xr = x + ((long)f * HW + nc) * C + 4 * half;
+        // x fragments (B operand of the transposed projection): x[n][8c + 4half + s]; LayerNorm in registers
+        f32x4 xb[8];
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            xb[c] = *reinterpret_cast<const f32x4*>(xr + 8 * c);
+            s += xb[c].x + xb[c].y + xb[c].z + xb[c].w;
+        }
+        s += __shfl_xor(s, 32, 64);
+        const float mu = s * (1.0f / C);
+        float ss = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const f32x4 dl = xb[c] - mu;
+            ss += dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w;
+        }
+        ss += __shfl_xor(ss, 32, 64);
+        const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
+        f32x4 xn[8];
+#pragma unroll
+        for (int c = 0; c < 8; ++c) xn[c] = (xb[c] - mu) * rs;
+
+        f32x16 oT[2];
+        oT[0] = z16();
+        oT[1] = z16();
+        for (int h = 0; h < HEADS; ++h) {
+            // Q^T (32 d x 32 px): A = Wq_h frags (LDS), B = xn
+            f32x16 qT = z16();
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wq + ((2 * c + half) * 256 + h * DH + l31) * 4);
+#pragma unroll
+                for (int s2 = 0; s2 < 4; ++s2)
+                    qT = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s2], xn[c][s2], qT, 0, 0, 0);
+            }
+            // softmax over d (16 in-lane values + the other half-wave), then * 32^-0.5
+            float m = qT[0];
+#pragma unroll
+            for (int r = 1; r < 16; ++r) m = fmaxf(m, qT[r]);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            float l = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                qT[r] = expf(qT[r] - m);
+                l += qT[r];
+            }
+            l += __shfl_xor(l, 32, 64);
+            const float inv = scale / l;
+            // out^T (64 n x 32 px) += M_h^T (n x d) . q^T (d x px): A = M frags (LDS), B = q^T registers
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ms + ((h * 8 + 2 * c + half) * C + 32 * nt + l31) * 4);
+#pragma unroll
+                    for (int s2 = 0; s2 < 4; ++s2)
+                        oT[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s2], qT[4 * c + s2] * inv, oT[nt], 0, 0, 0);
+                }
+        }
+        // epilogue: lane = pixel n, registers 4g..4g+3 = channels 32nt + 8g + 4half + {0..3}
+        if (n < HW) {
+            float* orow = out + ((long)f * HW + n) * C;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int ch = 32 * nt + 8 * g + 4 * half;
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + ch);
+                    const f32x4 xv = xb[(32 * nt + 8 * g) / 8];      // x[n][ch..ch+3] is fragment c = ch/8 of this half
+                    f32x4 o = {oT[nt][4 * g], oT[nt][4 * g + 1], oT[nt][4 * g + 2], oT[nt][4 * g + 3]};
+                    *reinterpret_cast<f32x4*>(orow + ch) = o + b4 + xv;
+                }
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const float* wout,
+                                  const float* bias, float eps, float* M_ws, float* out, void* stream) {
+    if (F <= 0 || HW <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(sla_c64_context_kernel, dim3(F), dim3(512), 0, s, x, HW, wqkv, wout, eps, M_ws);
+    const int ntiles = (HW + 31) / 32;
+    const int nsplit = (ntiles >= 64) ? 2 : 1;
+    const int lds = (16 * 256 * 4 + 64 * 64 * 4) * 4;   // 128 KB
+    (void)hipFuncSetAttribute((const void*)sla_c64_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    hipLaunchKernelGGL(sla_c64_apply_kernel, dim3(F * nsplit), dim3(512), lds, s, x, HW, wqkv, M_ws, bias, eps, out,
+                       nsplit);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}

@@ -202,6 +202,17 @@ class HipOps:
         check(self.L.dawn_sla_apply(_p(qkv), _p(ctx), F, HW, _p(out), s), "dawn_sla_apply")
         return out
 
+    def sla_layer_c64(self, x: Tensor, F: int, HW: int, wqkv: Tensor, wout: Tensor, bias: Tensor,
+                      eps: float = 1e-5) -> Tensor:
+        """out = x + to_out(linear_attention(LayerNorm(x))) for 64-channel levels (two kernels, no qkv tensor)."""
+        assert x.is_contiguous() and x.shape == (F * HW, 64)
+        self._require(x, wqkv, wout, bias)
+        ws = self.empty(F, 8 * 8 * 64 * 4, like=x)
+        out = self.empty(F * HW, 64, like=x)
+        check(self.L.dawn_sla_layer_c64(_p(x), F, HW, _p(wqkv), _p(wout), _p(bias), eps, _p(ws), _p(out),
+                                        self._stream()), "dawn_sla_layer_c64")
+        return out
+
     def frame_attn(self, qkv: Tensor, F: int, N: int) -> Tensor:
         assert qkv.is_contiguous() and qkv.shape == (F * N, 768)
         out = self.empty(F * N, 256, like=qkv)

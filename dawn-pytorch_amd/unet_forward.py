@@ -128,6 +128,8 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
 
 
 def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
+    if a.C == 64:
+        return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout)
     stats = ops.ln_rowstats(x)
     qkv = ops.conv_gemm(x, a.wqkv, 768, row_stats=stats, F=F, Hi=H, Wi=W)
     o = ops.sla(qkv, F, H * W)

@@ -104,6 +104,11 @@ int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, in
 int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);     /* ctx (F,8,32,32) */
 int dawn_sla_apply(const float* qkv, const float* ctx, int F, int HW, float* out, void* stream); /* out (F*HW,256) */
 
+/* Fused LAYER for 64-channel levels: out = x + to_out(linattn(LayerNorm(x))) + bias, q/k/v never materialised.
+ * M_ws: caller workspace of F*8*8*64*4 floats (per-frame folded context . to_out matrices). */
+int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const float* wout, const float* bias,
+                       float eps, float* M_ws, float* out, void* stream);
+
 /* ---- A11 mid spatial attention: full softmax attention over the HW tokens of a frame (MT:841-843) */
 int dawn_frame_attn(const float* qkv, int F, int N, float* out, void* stream);
 

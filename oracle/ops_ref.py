@@ -189,6 +189,12 @@ class RefOps:
         o = torch.einsum("fhde,fhdn->fhen", ctx, q)                          # (F, 8, 32, HW)
         return o.permute(0, 3, 1, 2).reshape(F * HW, 256).contiguous()
 
+    def sla_layer_c64(self, x, F, HW, wqkv, wout, bias, eps=1e-5):
+        stats = self.ln_rowstats(x, None, eps)
+        qkv = self.conv_gemm(x, wqkv, 768, row_stats=stats, F=F, Hi=1, Wi=HW)
+        o = self.sla(qkv, F, HW)
+        return self.conv_gemm(o, wout, 64, bias=bias, res=x, F=F, Hi=1, Wi=HW)
+
     def frame_attn(self, qkv, F, N):
         x = qkv.reshape(F, N, 3, 8, 32)
         q = x[:, :, 0].permute(0, 2, 1, 3) * 32 ** -0.5

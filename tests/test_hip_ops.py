@@ -234,6 +234,16 @@ def test_sla(hip, ref, F, HW):
     check(f"sla/F{F}_HW{HW}", hip.sla(qkv.cuda(), F, HW), ref.sla(qkv, F, HW), 2e-5)
 
 
+@pytest.mark.parametrize("F,HW", [(3, 64), (2, 1024), (5, 256), (1, 4096), (2, 100)])
+def test_sla_layer_c64(hip, ref, F, HW):
+    """Fused layer == LN stats + qkv GEMM + linear attention + out GEMM (+bias) + residual."""
+    x = rnd(F * HW, 64, seed=1) * 1.3 + 0.2
+    wqkv, wout, bias = packw(64, 768, seed=2) * 2.0, packw(256, 64, seed=3), rnd(64, seed=4)
+    want = ref.sla_layer_c64(x, F, HW, wqkv, wout, bias)
+    got = hip.sla_layer_c64(*gpu(x), F, HW, *gpu(wqkv, wout, bias))
+    check(f"sla_layer_c64/F{F}_HW{HW}", got, want, 3e-5)
+
+
 @pytest.mark.parametrize("F,N", [(4, 16), (3, 64), (2, 100)])
 def test_frame_attn(hip, ref, F, N):
     qkv = rnd(F * N, 768, seed=1)
