@@ -82,6 +82,36 @@ def cpu_baseline(h, S, sample_frames, unet_cpu_sd):
                       f"({dt:.1f} s), extrapolated to {S} DDIM steps"}
 
 
+def tshard_preflight(dist, rank, world, device) -> bool:
+    """Tiny T-sharded sample over RCCL (halo send/recv + fp64 / int32 all-reduces).  Any failure on any rank
+    makes every rank fall back to replica mode instead of losing the whole scaling run."""
+    ok = 1
+    try:
+        import dawn_pytorch_amd as D
+        from dawn_pytorch_amd.tshard import TShardComm
+        F, h = 16, 8
+        unet = D.DynamicNfUnet3D(default_num_frames=F, num_frames=F, dim=64, cond_dim=40, cond_aud=32, cond_pose=6,
+                                 cond_eye=2, channels=35, dim_mults=(1, 2), use_hubert_audio_cond=True, win_width=8)
+        diff = D.DynamicNfGaussianDiffusion(default_num_frames=F, denoise_fn=unet, num_frames=F, image_size=h,
+                                            sampling_timesteps=2, use_dynamic_thres=True).to(device)
+        diff.noise_seed = 1
+        g = torch.Generator().manual_seed(1)
+        fea, bbox = torch.randn(1, 28, h, h, generator=g).to(device), torch.randn(1, 4, h, h, generator=g).to(device)
+        cond = torch.randn(1, F * world, 40, generator=g)[:, rank * F:(rank + 1) * F].contiguous().to(device)
+        out = diff.sample(fea, bbox, cond=cond, comm=TShardComm(dist, rank, world, F * world, rank * F, F))
+        torch.cuda.synchronize()
+        ok = int(bool(torch.isfinite(out).all()))
+    except Exception as e:                                    # noqa: BLE001
+        print(f"[rank {rank}] T-shard preflight failed: {type(e).__name__}: {str(e)[:300]}", file=sys.stderr)
+        ok = 0
+    try:
+        flag = torch.tensor([ok], device=device, dtype=torch.int32)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+    except Exception:                                         # noqa: BLE001
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -94,6 +124,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="disable the two-stream overlap inside ResBlocks")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -103,15 +134,18 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    if world > 1 or os.environ.get("DAWN_FORCE_DIST") == "1":
+        import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
 
     T, h, S = args.frames, args.res // 4, args.ddim_steps
     comm, mode = None, "single"
     Ttotal, f0 = T, 0
-    if world > 1:
+    if dist is not None:
         mode = args.mode
+        if mode == "tshard" and not tshard_preflight(dist, rank, world, device):
+            mode = "replica"            # reported honestly in config.parallelism
         if mode == "tshard":
             from dawn_pytorch_amd.tshard import TShardComm
             Ttotal, f0 = T * world, T * rank
@@ -121,6 +155,7 @@ def main():
     fea, bbox, cond = synthetic_inputs(T, h, device, seed=123 + (rank if mode == "replica" else 0), f0=f0,
                                        Ttotal=Ttotal)
     ops = unet._ops()
+    ops.overlap = not args.no_overlap
 
     def one_clip():
         return diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)
@@ -152,6 +187,8 @@ def main():
             dist.destroy_process_group()
         return
     n_gpus = world
+    if dist is not None and world == 1:
+        mode = {"tshard": "tshard", "replica": "replica"}[mode]
     frames_total = T * n_gpus * args.steps
     value = frames_total / dt
     result = {
@@ -163,7 +200,7 @@ def main():
         "config": {"workload": f"{args.res}x{args.res}, {T}-frame clip per GPU, {S} DDIM steps, window 40, eta 1.0, "
                                f"cond_scale 1.0 (BASELINE configs[2])",
                    "frames_per_gpu": T, "clip_frames": Ttotal, "latent": [h, h], "ddim_steps": S,
-                   "parallelism": {"single": "1 GPU", "tshard": f"T-shard x{n_gpus} (halo exchange over RCCL)",
+                   "parallelism": {"single": "1 GPU", "tshard": f"T-shard x{n_gpus}: one {Ttotal}-frame clip, RCCL neighbour halo exchange + GroupNorm/quantile all-reduces",
                                    "replica": f"{n_gpus} independent clips"}[mode]},
     }
     # ---- roofline of the dominant kernel (conv_gemm: every 3x3/1x1/4x4 conv and every projection)
@@ -182,7 +219,7 @@ def main():
         (n_gpus if mode == "replica" else 1)
     result["whole_path"] = {"algorithmic_tflop": alg / 1e12, "achieved_tflops": alg / dt / 1e12,
                             "frac_of_fp32_mfma_peak": alg / dt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * n_gpus)}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and n_gpus == 1:
         sd = {"denoise_fn." + k: v.detach().cpu() for k, v in unet.state_dict().items()}
         result["cpu_baseline"] = cpu_baseline(h, S, args.cpu_sample_frames, sd)
     print(json.dumps(result))

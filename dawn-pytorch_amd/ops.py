@@ -38,10 +38,13 @@ class HipOps:
         self.L = _lib.lib()          # raises if the extension is missing: no fallback by design
         self.comm = comm             # T-shard communicator (see tshard.py) or None
         self.prof = None             # list -> (algorithmic flops, start event, end event) per conv_gemm launch
+        self.overlap = True          # two-stream overlap of independent branches (fork_join)
+        self._side_stream = None
 
     def with_comm(self, comm):
         o = HipOps(comm)
         o.prof = self.prof
+        o.overlap = self.overlap
         return o
 
     # ------------------------------------------------------------------ helpers
@@ -61,6 +64,26 @@ class HipOps:
 
     def empty(self, *shape, like: Tensor, dtype=torch.float32) -> Tensor:
         return torch.empty(*shape, device=like.device, dtype=dtype)
+
+    def fork_join(self, side, main):
+        """Run `side()` on a second HIP stream concurrently with `main()` on the current stream; both see all
+        work enqueued so far, and everything enqueued afterwards sees both (stream/event plumbing only)."""
+        if not self.overlap:
+            a = side()
+            return a, main()
+        cur = torch.cuda.current_stream()
+        if self._side_stream is None or self._side_stream.device != cur.device:
+            self._side_stream = torch.cuda.Stream(device=cur.device)
+        s2 = self._side_stream
+        s2.wait_stream(cur)
+        with torch.cuda.stream(s2):
+            a = side()
+        b = main()
+        cur.wait_stream(s2)
+        for t in (a if isinstance(a, (tuple, list)) else (a,)):
+            if torch.is_tensor(t):
+                t.record_stream(cur)       # allocated on the side stream, consumed on the main one
+        return a, b
 
     # ------------------------------------------------------------------ conv / linear on MFMA
     def conv_gemm(self, in0: Tensor, w: Tensor, N: int, *, F: int, Hi: int, Wi: int, Ho: Optional[int] = None,

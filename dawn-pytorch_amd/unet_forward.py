@@ -89,17 +89,27 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     total_rows = cs.Ttotal * H * W
     g = dict(F=F, Hi=H, Wi=W)
     hcond, film = None, None
-    if rb.conditioned:
+
+    def cross_attention():
         stats = ops.ln_rowstats(x, x2)
         q = ops.conv_gemm(x, rb.wq, 192, in1=x2, row_stats=stats, **g)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)
         y3 = ops.empty(F * H * W, 3 * Co, like=x)
         for b in range(3):
             ops.conv_gemm(q[:, 64 * b:64 * b + 64], rb.wo[b], Co, out=y3[:, b * Co:(b + 1) * Co], **g)
-        hcond = ops.xattn_ln_sum(y3, rb.g3, Co)
+        return ops.xattn_ln_sum(y3, rb.g3, Co)
+
+    def conv1_and_stats():
+        c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, **g)
+        return c, ops.gn_coeffs(c, rb.g1, rb.be1, film, total_rows)
+
+    if rb.conditioned:
         film = (film_all[rb.film_off:rb.film_off + Co], film_all[rb.film_off + Co:rb.film_off + 2 * Co])
-    c1 = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, **g)
-    ab1 = ops.gn_coeffs(c1, rb.g1, rb.be1, film, total_rows)
+        # the HBM-bound cross-attention chain and the MFMA-bound conv1 + GroupNorm statistics only meet at
+        # h1 = SiLU(GN(c1)) + h_cond: run them on two HIP streams so that they overlap on the GPU
+        hcond, (c1, ab1) = ops.fork_join(cross_attention, conv1_and_stats)
+    else:
+        c1, ab1 = conv1_and_stats()
     # h1 = SiLU(FiLM(GN(c1))) + h_cond is materialised once (one streaming pass) instead of being fused into
     # the 3x3 loader: an implicit GEMM reads every input element 9x, and 9x exp/div per element cost the conv
     # ~35 % of its MFMA rate (profiles/r1_b_conv_shapes.txt) -- far more than the extra 3 x C x 4 B per pixel.

@@ -33,6 +33,10 @@ class RefOps:
     def with_comm(self, comm):
         return RefOps(comm)
 
+    def fork_join(self, side, main):
+        a = side()
+        return a, main()
+
     def empty(self, *shape, like: Tensor, dtype=torch.float32) -> Tensor:
         return torch.zeros(*shape, device=like.device, dtype=dtype)
 

@@ -105,3 +105,30 @@ def test_sampler_properties_large():
     b = diff.sample(fea, bbox, cond=cond, cond_scale=1.0)
     assert torch.equal(a, b), "sampler is not deterministic for a fixed Philox seed"
     assert torch.isfinite(a).all() and float(a.abs().max()) <= 1.0 + 1e-6
+
+
+class _LoopbackComm:
+    """World-size-1 stand-in for tshard.TShardComm: exercises the sharded code paths of HipOps (separate GroupNorm
+    reduce / finalize kernels, histogram + min 'all-reduces', halo plumbing) without a second GPU."""
+    Ttotal, f0 = 12, 0
+
+    def all_reduce_sum(self, t):
+        pass
+
+    def all_reduce_min(self, t):
+        pass
+
+    def halo_exchange(self, x, HW, win):
+        return x, 0
+
+
+def test_sharded_code_paths_world1(tiny):
+    g, sd = tiny
+    d = load_golden("ddim_tiny.npz")
+    unet = tiny_unet(sd)
+    diff = D.DynamicNfGaussianDiffusion(default_num_frames=12, denoise_fn=unet, num_frames=12, image_size=8,
+                                        sampling_timesteps=int(d["S"]), timesteps=1000, loss_type='l2',
+                                        use_dynamic_thres=True, null_cond_prob=0.1, ddim_sampling_eta=1.0).cuda()
+    out = diff.sample(T(d["fea"]).cuda(), T(d["bbox"]).cuda(), cond=T(d["cond"]).cuda(), cond_scale=1.0,
+                      x_init=T(d["x_init"]).cuda(), noises=[n.cuda() for n in T(d["noises"])], comm=_LoopbackComm())
+    assert log("tiny_ddim_sharded_paths", out, T(d["out"])) < 5e-4
