@@ -30,7 +30,10 @@ struct RowInfo {
     bool valid;
 };
 
-template <int BM, int BN, int BK, int WM, int WN>
+// PRO: 0 = no prologue, 1 = per-pixel (mean, rstd) only, 2 = generic (row stats / channel affine / SiLU / add).
+// The prologue is applied when the chunk is written to LDS (after the MFMA burst), never right after the
+// global load: the loads of chunk c+1 stay in flight behind the MFMAs of chunk c.
+template <int BM, int BN, int BK, int WM, int WN, int PRO>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, const int xcd_remap) {
     constexpr int LDA = BK + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
@@ -102,6 +105,10 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
     }
 
     f32x4 ga[RPT];
+    f32x4 gadd[PRO == 2 ? RPT : 1];
+    float gmu[PRO >= 1 ? RPT : 1], grs[PRO >= 1 ? RPT : 1];
+    bool ginb[RPT];
+    int gc = 0;                       // channel offset of the chunk held in ga (for the channel-affine prologue)
     f32x4 gb[NB4];
     // incremental chunk state (uniform): channel chunk, tap coordinates
     int cc = 0, ky = 0, kx = 0;
@@ -116,29 +123,25 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
         const float* src = src1 ? d.in1 : d.in0;
         const int ld = src1 ? d.ld1 : d.ld0;
         const int cs = src1 ? c - d.C0 : c;
+        gc = c;
 #pragma unroll
         for (int i = 0; i < RPT; ++i) {
             const int yi = ri[i].yb + dy, xi = ri[i].xb + dx;
             const bool inb = ri[i].valid && yi >= 0 && yi < d.Hi && xi >= 0 && xi < d.Wi;
+            const long pix = inb ? ri[i].rowoff + tapoff : 0;
+            ginb[i] = inb;
             f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (inb) {
-                const long pix = ri[i].rowoff + tapoff;
-                v = *reinterpret_cast<const f32x4*>(src + pix * ld + cs);
-                if (d.row_mean) {
-                    const float mu = d.row_mean[pix], rs = d.row_rstd[pix];
-                    v = (v - mu) * rs;
-                }
-                if (d.ch_a) {
-                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(d.ch_a + c);
-                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(d.ch_b + c);
-                    v = v * a4 + b4;
-                }
-                if (d.pro_act) {
-                    v.x = dawn_silu(v.x); v.y = dawn_silu(v.y); v.z = dawn_silu(v.z); v.w = dawn_silu(v.w);
-                }
-                if (d.pro_add) v += *reinterpret_cast<const f32x4*>(d.pro_add + pix * d.ld_add + c);
-            }
+            if (inb) v = *reinterpret_cast<const f32x4*>(src + pix * ld + cs);
             ga[i] = v;
+            if (PRO >= 1 && d.row_mean) {
+                gmu[i] = d.row_mean[pix];
+                grs[i] = d.row_rstd[pix];
+            }
+            if (PRO == 2 && d.pro_add) {
+                f32x4 av = {0.f, 0.f, 0.f, 0.f};
+                if (inb) av = *reinterpret_cast<const f32x4*>(d.pro_add + pix * d.ld_add + c);
+                gadd[i] = av;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB4; ++i) {
@@ -157,8 +160,23 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < RPT; ++i)
-            *reinterpret_cast<f32x4*>(As + buf * BM * LDA + (r0 + RSTEP * i) * LDA + kqA * 4) = ga[i];
+        for (int i = 0; i < RPT; ++i) {
+            f32x4 v = ga[i];
+            if (PRO >= 1 && d.row_mean) v = (v - gmu[i]) * grs[i];
+            if (PRO == 2) {
+                if (d.ch_a) {
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(d.ch_a + gc);
+                    const f32x4 b4 = *reinterpret_cast<const f32x4*>(d.ch_b + gc);
+                    v = v * a4 + b4;
+                }
+                if (d.pro_act) {
+                    v.x = dawn_silu(v.x); v.y = dawn_silu(v.y); v.z = dawn_silu(v.z); v.w = dawn_silu(v.w);
+                }
+                if (d.pro_add) v += gadd[i];
+            }
+            if (PRO >= 1 && !ginb[i]) v = f32x4{0.f, 0.f, 0.f, 0.f};     // zero padding applies AFTER the prologue
+            *reinterpret_cast<f32x4*>(As + buf * BM * LDA + (r0 + RSTEP * i) * LDA + kqA * 4) = v;
+        }
 #pragma unroll
         for (int i = 0; i < NB4; ++i)
             *reinterpret_cast<f32x4*>(Bs + buf * KQ * BN * 4 + (tid + 256 * i) * 4) = gb[i];
@@ -232,13 +250,20 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
     }
 }
 
-template <int BM, int BN, int BK, int WM, int WN>
-void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
+template <int BM, int BN, int BK, int WM, int WN, int PRO>
+void launch_pro(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
     const int z = d.mode == 1 ? 4 : 1;
     const int nwg = nMt * nNt;
     const int remap = ((g_variant & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
-    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN>), dim3(nwg, 1, z), dim3(256), 0, s, d, remap);
+    hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, PRO>), dim3(nwg, 1, z), dim3(256), 0, s, d, remap);
+}
+
+template <int BM, int BN, int BK, int WM, int WN>
+void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
+    if (d.ch_a || d.pro_act || d.pro_add) launch_pro<BM, BN, BK, WM, WN, 2>(d, M, s);
+    else if (d.row_mean) launch_pro<BM, BN, BK, WM, WN, 1>(d, M, s);
+    else launch_pro<BM, BN, BK, WM, WN, 0>(d, M, s);
 }
 
 }  // namespace

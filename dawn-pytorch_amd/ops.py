@@ -192,6 +192,22 @@ class HipOps:
         check(self.L.dawn_xattn_ln_sum(_p(y3), _p(g3), _p(out), rows, Co, eps, self._stream()), "dawn_xattn_ln_sum")
         return out
 
+    @staticmethod
+    def can_fuse_xattn(Cin: int, Co: int, C0: int) -> bool:
+        return Co == 64 and Cin in (64, 128) and C0 % 8 == 0
+
+    def xattn_layer_c64(self, x: Tensor, x2: Optional[Tensor], HW: int, wq: Tensor, wo, g3: Tensor, q_scale: Tensor,
+                        kvtab: Tensor, nulltab: Tensor, eps: float = 1e-5) -> Tensor:
+        """h_cond (rows,64) = sum over the three branches of LN(to_out(attn(LN(x)))) in one launch."""
+        rows = x.shape[0]
+        self._require(x, x2, wq, g3, q_scale, kvtab, nulltab, *wo)
+        out = self.empty(rows, 64, like=x)
+        check(self.L.dawn_xattn_layer_c64(_p(x), x.shape[1], _ld(x), _p(x2), 0 if x2 is None else x2.shape[1], _ld(x2),
+                                          rows, HW, _p(wq), _p(wo[0]), _p(wo[1]), _p(wo[2]), _p(g3), _p(q_scale),
+                                          _p(kvtab), _p(nulltab), eps, _p(out), self._stream()),
+              "dawn_xattn_layer_c64")
+        return out
+
     # ------------------------------------------------------------------ attention cores
     def temporal_attn(self, qkv: Tensor, Fext: int, HW: int, q0: int, Fq: int, win: int, rcos: Tensor, rsin: Tensor,
                       band: Tensor) -> Tensor:

@@ -91,6 +91,9 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     hcond, film = None, None
 
     def cross_attention():
+        if ops.can_fuse_xattn(rb.Cin, Co, x.shape[1]):
+            return ops.xattn_layer_c64(x, x2, H * W, rb.wq, rb.wo, rb.g3, rb.q_scale, cs.kvtab[rb.cond_index],
+                                       cs.nulltab[rb.cond_index])
         stats = ops.ln_rowstats(x, x2)
         q = ops.conv_gemm(x, rb.wq, 192, in1=x2, row_stats=stats, **g)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)

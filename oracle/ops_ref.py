@@ -147,6 +147,20 @@ class RefOps:
         var = y.var(dim=-1, unbiased=False, keepdim=True)
         return ((y - mean) * torch.rsqrt(var + eps) * g3[None]).sum(dim=1)
 
+    @staticmethod
+    def can_fuse_xattn(Cin, Co, C0):
+        return Co == 64 and Cin in (64, 128) and C0 % 8 == 0
+
+    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5):
+        rows = x.shape[0]
+        stats = self.ln_rowstats(x, x2, eps)
+        q = self.conv_gemm(x, wq, 192, in1=x2, row_stats=stats, F=rows, Hi=1, Wi=1)
+        self.xattn_core(q, HW, kvtab, nulltab, q_scale)
+        y3 = torch.zeros(rows, 192, device=x.device)
+        for b in range(3):
+            self.conv_gemm(q[:, 64 * b:64 * b + 64], wo[b], 64, F=rows, Hi=1, Wi=1, out=y3[:, 64 * b:64 * b + 64])
+        return self.xattn_ln_sum(y3, g3, 64, eps)
+
     # ------------------------------------------------------------------ attention cores
     def temporal_attn(self, qkv, Fext, HW, q0, Fq, win, rcos, rsin, band):
         x = qkv.reshape(Fext, HW, 3, 8, 32)

@@ -201,6 +201,24 @@ def test_xattn_pieces(hip, ref):
         check(f"xattn_ln_sum/Co{Co}", hip.xattn_ln_sum(y3.cuda(), g3.cuda(), Co), ref.xattn_ln_sum(y3, g3, Co), 2e-5)
 
 
+@pytest.mark.parametrize("C0,C1,Fn,HW", [(64, 0, 5, 64), (64, 64, 3, 100), (128, 0, 2, 33), (64, 0, 2, 4096)])
+def test_xattn_layer_c64(hip, ref, C0, C1, Fn, HW):
+    """Fused branch kernel == LN stats + q GEMM + 2-key attention + 3 out GEMMs + LN-sum."""
+    rows = Fn * HW
+    x = rnd(rows, C0, seed=1) * 1.5 + 0.3
+    x2 = rnd(rows, C1, seed=2) if C1 else None
+    wq = packw(C0 + C1, 192, seed=3)
+    wo = [packw(64, 64, seed=10 + b) for b in range(3)]
+    g3, qs = rnd(3, 64, seed=4) * 0.2 + 1, rnd(3, 8, seed=5) * 0.2 + 1
+    kvtab, nulltab = torch.zeros(Fn, 3, 128), torch.zeros(3, 16)
+    for b in range(3):
+        ref.xattn_prep(rnd(Fn, 128, seed=20 + b), rnd(8, seed=30 + b) * 0.2 + 1, rnd(2, 8, seed=40 + b), kvtab, b, nulltab)
+    want = ref.xattn_layer_c64(x, x2, HW, wq, wo, g3, qs, kvtab, nulltab)
+    got = hip.xattn_layer_c64(x.cuda(), None if x2 is None else x2.cuda(), HW, wq.cuda(), [w.cuda() for w in wo],
+                              g3.cuda(), qs.cuda(), kvtab.cuda(), nulltab.cuda())
+    check(f"xattn_layer_c64/{C0}+{C1}_F{Fn}_HW{HW}", got, want, 3e-5)
+
+
 # ---------------------------------------------------------------------------------------------- attention cores
 @pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(12, 5, 0, 12, 3), (100, 3, 0, 100, 40), (70, 2, 20, 33, 40),
                                                  (45, 4, 3, 40, 7), (33, 2, 0, 33, 40)])
