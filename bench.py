@@ -209,8 +209,13 @@ def main():
         t_ms = sum(p[1].elapsed_time(p[2]) for p in prof)
         flops = sum(p[0] for p in prof)
         ach = flops / (t_ms * 1e-3) / 1e12
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
+        if (T, args.res) == (200, 256) and os.path.exists(tp):     # PMC counters cannot be read live: measured
+            traffic = json.load(open(tp))["hbm_bytes_per_launch"]  # on this exact workload by tools/pmc_bench.sh
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": None,
+                              "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
+                              "algorithmic_bytes_per_launch_avg": sum(p[4] for p in prof) / len(prof),
                               "kernel": "conv_gemm_kernel<64|128> (fp32 MFMA implicit GEMM)",
                               "launches": len(prof), "avg_launch_us": t_ms * 1e3 / len(prof),
                               "kernel_time_share": t_ms * 1e-3 / dt,

@@ -32,7 +32,7 @@ for _ in range(a.iters):
 t1.record()
 torch.cuda.synchronize()
 agg = collections.OrderedDict()
-for fl, e0, e1, key in ops.prof:
+for fl, e0, e1, key, _ in ops.prof:
     d = agg.setdefault(key, [0, 0.0, 0.0])
     d[0] += 1; d[1] += e0.elapsed_time(e1); d[2] += fl
 tot_ms = sum(d[1] for d in agg.values()); tot_fl = sum(d[2] for d in agg.values())
