@@ -19,10 +19,13 @@
 
 namespace {
 
-// Tuning policy (measured on MI355X, profiles/r1_d_conv_variants.txt): bit0 BK=32 tiles for deep-K GEMMs
-// (K >= 4096, N > 64: +6 %), bit1 256x64 tile for N <= 64 (no gain: off), bit2 XCD-contiguous tile order for
-// multi-tap convs on >= 32x32 frames (+7..17 %; hurts pure streaming 1x1 GEMMs, so not used there).
-static int g_variant = 0x5;
+// Tuning policy (measured on MI355X, profiles/r1_d_conv_variants.txt, r1_j_conv_glds.txt): bit0 BK=32 tiles for
+// deep-K GEMMs on the register-staged path (K >= 4096, N > 64: +6 %), bit1 256x64 tile for N <= 64 (no gain:
+// off), bit2 XCD-contiguous tile order for multi-tap convs on >= 32x32 frames (+7..17 %; hurts pure streaming
+// 1x1 GEMMs, so not used there), bit3 direct-to-LDS staging for prologue-free GEMMs (+5..15 %; BK=32 there when
+// K >= 2304 and N >= 256), 0x80 force BK=32 on that path, 0x100 its 3-stage counted-vmcnt pipeline (no gain:
+// the loop is bound by the per-CU fetch rate, not by load latency), 0x10/0x20 perf ablations.
+static int g_variant = 0xD;
 
 struct RowInfo {
     long rowoff;  // (f*Hi + yb)*Wi + xb : input pixel index of tap (0,0) (may point outside; bounds via yb/xb)
@@ -33,7 +36,7 @@ struct RowInfo {
 // PRO: 0 = no prologue, 1 = per-pixel (mean, rstd) only, 2 = generic (row stats / channel affine / SiLU / add).
 // The prologue is applied when the chunk is written to LDS (after the MFMA burst), never right after the
 // global load: the loads of chunk c+1 stay in flight behind the MFMAs of chunk c.
-template <int BM, int BN, int BK, int WM, int WN, int PRO>
+template <int BM, int BN, int BK, int WM, int WN, int PRO, int ABL = 0>
 __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, const int xcd_remap) {
     constexpr int LDA = BK + 4;
     constexpr int WTM = BM / WM, WTN = BN / WN;   // wave tile
@@ -195,8 +198,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
     __syncthreads();
 
     for (int chunk = 0; chunk < nChunks; ++chunk) {
-        const int buf = chunk & 1;
-        if (chunk + 1 < nChunks) load_chunk(chunk + 1);
+        const int buf = ABL ? 0 : (chunk & 1);
+        if (ABL == 0 && chunk + 1 < nChunks) load_chunk(chunk + 1);
         const float* Ab = As + buf * BM * LDA;
         const float* Bb = Bs + buf * KQ * BN * 4;
 #pragma unroll
@@ -217,8 +220,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
         }
-        if (chunk + 1 < nChunks) store_chunk(buf ^ 1);
-        __syncthreads();
+        if (ABL == 0 && chunk + 1 < nChunks) store_chunk(buf ^ 1);
+        if (ABL < 2) __syncthreads();
     }
 
     // ---- epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -227,6 +230,211 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const long m = m0 + wm * WTM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= M) continue;
+            long orow = m;
+            if (d.mode == 1) {
+                const int hw = d.Hi * d.Wi;
+                const int f = (int)(m / hw);
+                const int rem = (int)(m - (long)f * hw);
+                const int a = rem / d.Wi, b = rem - a * d.Wi;
+                orow = ((long)f * d.Ho + 2 * a + py) * d.Wo + 2 * b + px;
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                if (n >= d.N) continue;
+                float v = acc[i][j][r];
+                if (d.bias) v += d.bias[n];
+                if (d.res) v += d.res[orow * d.ld_res + n];
+                if (d.tr) v += dawn_silu(d.tr[orow * d.ld_tr + n] * d.tr_a[n] + d.tr_b[n]);
+                d.out[orow * d.ld_out + n] = v;
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Direct-to-LDS variant for prologue-free convs / GEMMs (the bulk of the FLOPs): both operand tiles are
+// staged with global_load_lds_dwordx4 (no VGPR round trip, no ds_write, almost no address VALU).  An LDS-DMA
+// write is lane-linear (wave-uniform base + lane*16 B), so the A image is unpadded [row][16 floats] and the
+// bank-conflict fix is an XOR swizzle of the 16-B slot, applied on the SOURCE address (lane L loads the
+// global bytes that belong at physical slot L&3 of row L>>2) and again on the ds_read_b128 address.
+// Out-of-frame taps / tail rows / tail columns read from a zero block instead of being predicated.
+// Measured ablation (profiles/r1_j_conv_ablation.txt): the register-staged kernel loses ~20 % to staging.
+__device__ __attribute__((aligned(64))) float dawn_zero_block[16];
+
+// NST = 3: three LDS stages, loads issued TWO chunks ahead and retired with a COUNTED s_waitcnt vmcnt(IPC) + raw
+// s_barrier (a __syncthreads() would drain the whole DMA queue), so one chunk of loads is always in flight
+// across the barrier (cdna_hip_programming.md "Pipelining across barriers").
+template <int BN, int NST, int BK>
+__global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const dawn_conv_desc d, const int xcd_remap) {
+    constexpr int BM = 128, KQ = BK / 4;           // KQ 16-B slots per A row (4 or 8)
+    constexpr int WTN = BN / 2;
+    constexpr int TM = 2, TN = WTN / 32;
+    constexpr int NAI = BM * KQ / 64 / 4;          // A wave-instructions per wave per chunk (2 or 4)
+    constexpr int RPI = 64 / KQ;                   // A rows per wave-instruction (16 or 8)
+    constexpr int NBI = BN * KQ / 64 / 4;          // B wave-instructions per wave per chunk
+    constexpr int IPC = NAI + NBI;                 // LDS-DMA instructions per wave per chunk
+    constexpr int SW = (BK == 16) ? 2 : 1;         // swizzle: slot ^= (row >> SW) & (KQ-1)
+    __shared__ __attribute__((aligned(16))) float smem[NST * BM * BK + NST * KQ * BN * 4];
+    float* As = smem;
+    float* Bs = smem + NST * BM * BK;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int Cin = d.C0 + d.C1;
+    const int nC = Cin / BK;
+    const int nChunks = d.KH * d.KW * nC;
+    const int phase = blockIdx.z;
+    const int py = phase >> 1, px = phase & 1;
+    const long M = (d.mode == 0) ? (long)d.F * d.Ho * d.Wo : (long)d.F * d.Hi * d.Wi;
+    const int nNt = (d.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    if (xcd_remap) {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / nNt, nt = bid - mt * nNt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+    const float* wbase = d.w + (d.mode == 1 ? (size_t)phase * (size_t)nChunks * BK * d.N : 0);
+
+    // ---- this lane's A rows (one per wave-instruction) and its logical k-slot
+    RowInfo ri[NAI];
+    int kql[NAI];
+#pragma unroll
+    for (int j = 0; j < NAI; ++j) {
+        const int row = (wave * NAI + j) * RPI + lane / KQ;
+        kql[j] = (lane % KQ) ^ ((row >> SW) & (KQ - 1));
+        const long m = m0 + row;
+        ri[j].valid = m < M;
+        const long mm = ri[j].valid ? m : 0;
+        if (d.mode == 0) {
+            const int hw = d.Ho * d.Wo;
+            const int f = (int)(mm / hw);
+            const int rem = (int)(mm - (long)f * hw);
+            const int yo = rem / d.Wo, xo = rem - yo * d.Wo;
+            ri[j].yb = yo * d.stride - d.pad;
+            ri[j].xb = xo * d.stride - d.pad;
+            ri[j].rowoff = ((long)f * d.Hi + ri[j].yb) * d.Wi + ri[j].xb;
+        } else {
+            const int hw = d.Hi * d.Wi;
+            const int f = (int)(mm / hw);
+            const int rem = (int)(mm - (long)f * hw);
+            ri[j].yb = rem / d.Wi;
+            ri[j].xb = rem - ri[j].yb * d.Wi;
+            ri[j].rowoff = (long)f * hw + rem;
+        }
+    }
+    int cc = 0, ky = 0, kx = 0;
+    auto issue = [&](int chunk, int buf) {
+        int dy, dx;
+        if (d.mode == 0) { dy = ky; dx = kx; }
+        else { dy = ky ? (py ? 1 : -1) : 0; dx = kx ? (px ? 1 : -1) : 0; }
+        const int tapoff = dy * d.Wi + dx;
+        const int cbase = cc * BK;
+        const bool src1 = cbase >= d.C0;
+        const float* src = src1 ? d.in1 : d.in0;
+        const int ld = src1 ? d.ld1 : d.ld0;
+        const int cs0 = src1 ? cbase - d.C0 : cbase;
+#pragma unroll
+        for (int j = 0; j < NAI; ++j) {
+            const int yi = ri[j].yb + dy, xi = ri[j].xb + dx;
+            const bool inb = ri[j].valid && yi >= 0 && yi < d.Hi && xi >= 0 && xi < d.Wi;
+            const float* g = inb ? src + (ri[j].rowoff + tapoff) * ld + cs0 + kql[j] * 4 : dawn_zero_block;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(As + buf * BM * BK + (wave * NAI + j) * 256),
+                                             16, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < NBI; ++j) {
+            const int q = wave * NBI + j;
+            const int idx = q * 64 + lane;
+            const int kq = idx / BN, n = idx % BN;
+            const int gn = n0 + n;
+            const float* g = gn < d.N ? wbase + ((size_t)(chunk * KQ + kq) * d.N + gn) * 4 : dawn_zero_block;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * KQ * BN * 4 + q * 256),
+                                             16, 0, 0);
+        }
+        if (++cc == nC) {
+            cc = 0;
+            if (++kx == d.KW) { kx = 0; ++ky; }
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issue(0, 0);
+    if (NST == 3) {
+        if (nChunks > 1) {
+            issue(1, 1);
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(IPC) : "memory");
+        } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+    } else {
+        __syncthreads();
+    }
+    int buf = 0;
+    for (int chunk = 0; chunk < nChunks; ++chunk) {
+        if (NST == 3) {
+            if (chunk + 2 < nChunks) issue(chunk + 2, buf >= 1 ? buf - 1 : 2);     // (buf + 2) % 3
+        } else {
+            if (chunk + 1 < nChunks) issue(chunk + 1, buf ^ 1);
+        }
+        const float* Ab = As + buf * BM * BK;
+        const float* Bb = Bs + buf * KQ * BN * 4;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            const int kq = kk * 2 + half;
+            f32x4 a[TM], b[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int row = wm * 64 + i * 32 + l31;
+                a[i] = *reinterpret_cast<const f32x4*>(Ab + row * BK + ((kq ^ ((row >> SW) & (KQ - 1))) << 2));
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                b[j] = *reinterpret_cast<const f32x4*>(Bb + (kq * BN + wn * WTN + j * 32 + l31) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+        }
+        if (NST == 3) {
+            // chunk+1 must have landed, chunk+2 (just issued) may stay in flight; all reads of `buf` retired
+            if (chunk + 2 < nChunks) asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(IPC) : "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            buf = buf == 2 ? 0 : buf + 1;
+        } else {
+            __syncthreads();   // drains the LDS-DMA of chunk+1 (vmcnt) and retires every read of `buf`
+            buf ^= 1;
+        }
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             if (m >= M) continue;
             long orow = m;
             if (d.mode == 1) {
@@ -261,6 +469,29 @@ void launch_pro(const dawn_conv_desc& d, long M, hipStream_t s) {
 
 template <int BM, int BN, int BK, int WM, int WN>
 void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
+    if (g_variant & 0x30) {   // perf ablations only (wrong results): 0x10 no re-staging, 0x20 also no barrier
+        const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
+        const int nwg = nMt * nNt;
+        if (g_variant & 0x20)
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, 0, 2>), dim3(nwg, 1, 1), dim3(256), 0, s, d, 0);
+        else
+            hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, 0, 1>), dim3(nwg, 1, 1), dim3(256), 0, s, d, 0);
+        return;
+    }
+    if ((g_variant & 8) && BM == 128 && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
+        const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
+        const int nwg = nMt * nNt;
+        const int remap = ((g_variant & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
+        const dim3 grid(nwg, 1, d.mode == 1 ? 4 : 1);
+        const bool deep = d.KH * d.KW * (d.C0 + d.C1) >= 2304 && d.N >= 256;
+        if (((g_variant & 0x80) || deep) && d.C0 % 32 == 0 && d.C1 % 32 == 0)
+            hipLaunchKernelGGL((conv_gemm_glds_kernel<BN, 2, 32>), grid, dim3(256), 0, s, d, remap);
+        else if (g_variant & 0x100)
+            hipLaunchKernelGGL((conv_gemm_glds_kernel<BN, 3, 16>), grid, dim3(256), 0, s, d, remap);
+        else
+            hipLaunchKernelGGL((conv_gemm_glds_kernel<BN, 2, 16>), grid, dim3(256), 0, s, d, remap);
+        return;
+    }
     if (d.ch_a || d.pro_act || d.pro_add) launch_pro<BM, BN, BK, WM, WN, 2>(d, M, s);
     else if (d.row_mean) launch_pro<BM, BN, BK, WM, WN, 1>(d, M, s);
     else launch_pro<BM, BN, BK, WM, WN, 0>(d, M, s);

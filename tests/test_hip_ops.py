@@ -106,7 +106,7 @@ def test_conv_gemm(hip, ref, case):
     if ex.get("tr"):
         kw["tr"] = (rnd(F * Ho * Wo, N, seed=9), rnd(N, seed=10) * 0.3 + 1.0, rnd(N, seed=11) * 0.3)
     want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
-    for variant in (0, 7, 5):                      # every tile configuration; 5 = shipped policy (left active)
+    for variant in (0, 7, 141, 269, 13):               # every tile configuration; 13 = shipped policy (left active)
         hip.L.dawn_conv_set_variant(variant)
         _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
 
