@@ -125,6 +125,11 @@ def main():
     ap.add_argument("--cpu-sample-frames", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="disable the two-stream overlap inside ResBlocks")
+    ap.add_argument("--graph", action="store_true",
+                    help="replay one captured HIP graph per DDIM step (measured: no gain, 70.4 vs 72.0 frames/s -- the "
+                         "path is not launch-bound; kept as an option)")
+    ap.add_argument("--eager-every", type=int, default=10,
+                    help="with graphs: every n-th DDIM step runs eagerly so HIP events sample the conv kernel live")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -156,6 +161,8 @@ def main():
                                        Ttotal=Ttotal)
     ops = unet._ops()
     ops.overlap = not args.no_overlap
+    diff.use_graph = args.graph and mode != "tshard"
+    diff.eager_every = args.eager_every
 
     def one_clip():
         return diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)
@@ -213,17 +220,22 @@ def main():
         tp = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
         if (T, args.res) == (200, 256) and os.path.exists(tp):     # PMC counters cannot be read live: measured
             traffic = json.load(open(tp))["hbm_bytes_per_launch"]  # on this exact workload by tools/pmc_bench.sh
+        sampled = diff.use_graph and getattr(ops, "graph_error", None) is None
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                               "algorithmic_bytes_per_launch_avg": sum(p[4] for p in prof) / len(prof),
                               "kernel": "conv_gemm_kernel<64|128> (fp32 MFMA implicit GEMM)",
                               "launches": len(prof), "avg_launch_us": t_ms * 1e3 / len(prof),
-                              "kernel_time_share": t_ms * 1e-3 / dt,
+                              "timing": (f"HIP events around every conv_gemm launch of every {args.eager_every}th DDIM step "
+                                         "(those steps run eagerly inside the timed region; the others replay a HIP graph)"
+                                         if sampled else "HIP events around every conv_gemm launch of the timed region"),
                               "algorithmic_flops_per_launch_avg": flops / len(prof)}
     alg = algorithmic_flops_per_forward(Ttotal if mode == "tshard" else T, h) * S * args.steps * \
         (n_gpus if mode == "replica" else 1)
     result["whole_path"] = {"algorithmic_tflop": alg / 1e12, "achieved_tflops": alg / dt / 1e12,
                             "frac_of_fp32_mfma_peak": alg / dt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * n_gpus)}
+    result["config"]["launch"] = ("HIP graph replay per DDIM step" if diff.use_graph and getattr(ops, "graph_error", None) is None
+                                  else "eager" + (f" (graph capture failed: {ops.graph_error})" if getattr(ops, "graph_error", None) else ""))
     if not args.no_cpu_baseline and n_gpus == 1:
         sd = {"denoise_fn." + k: v.detach().cpu() for k, v in unet.state_dict().items()}
         result["cpu_baseline"] = cpu_baseline(h, S, args.cpu_sample_frames, sd)

@@ -40,6 +40,8 @@ class GaussianDiffusion(nn.Module):
             raise NotImplementedError("HIP sampler implements the shipped setting: dynamic thresholding at 0.9 (FD:164)")
         # reproducibility knobs (the reference draws from the global torch generator)
         self.noise_seed: Optional[int] = None     # int -> shard-invariant Philox stream on device
+        self.use_graph = False                    # capture one UNet evaluation per clip as a HIP graph
+        self.eager_every = 0                      # with use_graph: run every n-th step eagerly (profiling hooks)
         self.last_trace: Optional[list] = None
 
     # ------------------------------------------------------------------ reference call surface
@@ -102,7 +104,8 @@ class GaussianDiffusion(nn.Module):
             else:
                 x0 = torch.randn(3, T, h, w, device=device)                           # MT:1166
             tr = [] if trace else None
-            outs.append(ddim_sample_clip(ops, P, cs, x0, steps, noise_fn, cond_scale, cs_null, tr))
+            outs.append(ddim_sample_clip(ops, P, cs, x0, steps, noise_fn, cond_scale, cs_null, tr,
+                                         use_graph=self.use_graph, eager_every=self.eager_every))
             traces.append(tr)
         self.last_trace = traces if trace else None
         return torch.stack(outs, 0)

@@ -40,6 +40,7 @@ class HipOps:
         self.prof = None             # list -> (algorithmic flops, start event, end event) per conv_gemm launch
         self.overlap = True          # two-stream overlap of independent branches (fork_join)
         self._side_stream = None
+        self.graph_error = None      # set when a HIP-graph capture failed and the sampler fell back to eager
 
     def with_comm(self, comm):
         o = HipOps(comm)

@@ -69,14 +69,28 @@ def ddim_step_scalars(bufs: Dict[str, Tensor], S: int, eta: float, total: int = 
 
 def ddim_sample_clip(ops, P: PackedUNet, cs: ClipState, x_init: Tensor, steps: Sequence[dict],
                      noise_fn: Callable[[int], Optional[Tensor]], cond_scale: float = 1.0,
-                     cs_null: Optional[ClipState] = None, trace: Optional[list] = None) -> Tensor:
+                     cs_null: Optional[ClipState] = None, trace: Optional[list] = None, use_graph: bool = False,
+                     eager_every: int = 0) -> Tensor:
     """x_init (3, F, h, w) on the ops' device -> final latent (3, F, h, w).
 
     noise_fn(i) returns the N(0,1) tensor of step i (only called when t_next > 0, MT:1201)."""
     x = x_init.contiguous()
     n_total = 3 * cs.Ttotal * cs.h * cs.w
+    graphed = None
+    if use_graph and cond_scale == 1.0 and cs.comm is None and x.is_cuda:
+        from .unet_forward import GraphedForward
+        try:
+            graphed = GraphedForward(ops, P, cs, x, steps[0]["t"])
+        except Exception as e:                                   # noqa: BLE001  (capture is an optimisation only)
+            ops.graph_error = f"{type(e).__name__}: {str(e)[:200]}"
+            graphed = None
     for i, st in enumerate(steps):
-        eps = unet_forward(ops, P, cs, x, st["t"])
+        # with a graph, every `eager_every`-th step still runs eagerly so that per-kernel HIP events (bench.py's
+        # live roofline measurement) sample the timed region
+        if graphed is not None and not (eager_every and ops.prof is not None and i % eager_every == 0):
+            eps = graphed(x, st["t"])
+        else:
+            eps = unet_forward(ops, P, cs, x, st["t"])
         if cond_scale != 1.0:
             eps_null = unet_forward(ops, P, cs_null, x, st["t"])
             eps = ops.cfg_combine(eps_null, eps, cond_scale)

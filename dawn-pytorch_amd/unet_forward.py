@@ -156,12 +156,14 @@ def _mid_spatial(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tenso
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W)
 
 
-def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float) -> Tensor:
+def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_all: Optional[Tensor] = None) -> Tensor:
     """x3 (3, F, h, w) latent of one clip in reference layout, t the integer diffusion time ->
     predicted noise (3, F, h, w).  Equivalent to Unet3D.forward(cat[x, fea], t, cond) with
-    null_cond_prob = 0 (MT:892-956)."""
+    null_cond_prob = 0 (MT:892-956).  `film_all` (the only t-dependent input besides x) may be supplied
+    precomputed so that the rest of the evaluation is a fixed launch sequence (see GraphedForward)."""
     F, H, W = cs.F, cs.h, cs.w
-    film_all = time_film(ops, P, t, cs.fea_pre)
+    if film_all is None:
+        film_all = time_film(ops, P, t, cs.fea_pre)
     r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
     x = _temporal(ops, P.init_tattn, r, F, H, W, cs)
     skips: List[Tuple[Tensor, int, int]] = []
@@ -195,3 +197,34 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float) -> Ten
     ho = _resblock(ops, P.head_o, x, r, F, H, W, film_all, cs)
     eps = ops.head_out(hg, ho, P.wg, P.bg, P.wo, P.bo)                        # (3, rows)
     return eps.reshape(3, F, H, W)
+
+
+class GraphedForward:
+    """One UNet evaluation captured ONCE per clip as a HIP graph (torch.cuda.CUDAGraph is only the capture /
+    replay plumbing: every node is one of our kernels launched through the C ABI on the capturing stream) and
+    replayed for each DDIM step.  ~370 launches per evaluation are otherwise host-bound at the deep (small-
+    kernel) levels.  Inputs that change per step live in static buffers: the latent `x` and the FiLM vector."""
+
+    def __init__(self, ops, P: PackedUNet, cs: ClipState, x_like: Tensor, t0: float):
+        self.ops, self.P, self.cs = ops, P, cs
+        self.x = torch.empty_like(x_like)
+        self.film = time_film(ops, P, t0, cs.fea_pre).clone()
+        prof, ops.prof = ops.prof, None                      # no event records inside a capture
+        try:
+            self.x.copy_(x_like)
+            side = torch.cuda.Stream(device=x_like.device)
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                    # warm-up outside capture (allocator, lazy inits)
+                unet_forward(ops, P, cs, self.x, t0, film_all=self.film)
+            torch.cuda.current_stream().wait_stream(side)
+            self.graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph):
+                self.out = unet_forward(ops, P, cs, self.x, t0, film_all=self.film)
+        finally:
+            ops.prof = prof
+
+    def __call__(self, x: Tensor, t: float) -> Tensor:
+        self.x.copy_(x)
+        self.film.copy_(time_film(self.ops, self.P, t, self.cs.fea_pre))
+        self.graph.replay()
+        return self.out

@@ -132,3 +132,23 @@ def test_sharded_code_paths_world1(tiny):
     out = diff.sample(T(d["fea"]).cuda(), T(d["bbox"]).cuda(), cond=T(d["cond"]).cuda(), cond_scale=1.0,
                       x_init=T(d["x_init"]).cuda(), noises=[n.cuda() for n in T(d["noises"])], comm=_LoopbackComm())
     assert log("tiny_ddim_sharded_paths", out, T(d["out"])) < 5e-4
+
+
+def test_graph_replay_equals_eager():
+    """HIP-graph replay of the UNet evaluation launches the same kernels as the eager path: bit-identical output."""
+    Tn, h = 40, 16
+    unet = D.DynamicNfUnet3D(default_num_frames=Tn, dim=64, cond_dim=40, cond_aud=32, cond_pose=6, cond_eye=2,
+                             num_frames=Tn, channels=35, out_grid_dim=2, out_conf_dim=1, dim_mults=(1, 2, 4),
+                             use_hubert_audio_cond=True, win_width=10).cuda()
+    diff = D.DynamicNfGaussianDiffusion(default_num_frames=Tn, denoise_fn=unet, num_frames=Tn, image_size=h,
+                                        sampling_timesteps=4, timesteps=1000, loss_type='l2', use_dynamic_thres=True,
+                                        ddim_sampling_eta=1.0).cuda()
+    diff.noise_seed = 99
+    g = torch.Generator().manual_seed(5)
+    fea, bbox = torch.randn(1, 28, h, h, generator=g).cuda(), torch.randn(1, 4, h, h, generator=g).cuda()
+    cond = torch.randn(1, Tn, 40, generator=g).cuda()
+    eager = diff.sample(fea, bbox, cond=cond, cond_scale=1.0)
+    diff.use_graph = True
+    graphed = diff.sample(fea, bbox, cond=cond, cond_scale=1.0)
+    assert unet._ops().graph_error is None, unet._ops().graph_error
+    assert torch.equal(eager, graphed)
