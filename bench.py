@@ -205,7 +205,8 @@ def main():
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (random-init DAWN weights, N(0,1) fea/bbox/cond, Philox noise)",
         "config": {"workload": f"{args.res}x{args.res}, {T}-frame clip per GPU, {S} DDIM steps, window 40, eta 1.0, "
-                               f"cond_scale 1.0 (BASELINE configs[2])",
+                               f"cond_scale 1.0" + {(256, 200, 50): " (BASELINE configs[2])", (128, 400, 50): " (BASELINE configs[1])",
+                                                   (128, 16, 10): " (BASELINE configs[0] shape)"}.get((args.res, T, S), ""),
                    "frames_per_gpu": T, "clip_frames": Ttotal, "latent": [h, h], "ddim_steps": S,
                    "parallelism": {"single": "1 GPU", "tshard": f"T-shard x{n_gpus}: one {Ttotal}-frame clip, RCCL neighbour halo exchange + GroupNorm/quantile all-reduces",
                                    "replica": f"{n_gpus} independent clips"}[mode]},
