@@ -34,12 +34,14 @@ class ConvDesc(C.Structure):
         ("tr", c_f), ("ld_tr", _i),
         ("tr_a", c_f), ("tr_b", c_f),
         ("out", c_f), ("ld_out", _i),
+        ("gn_part", c_f),
     ]
 
 
 # name -> argtypes (every function returns int; `stream` is the trailing void*)
 SIGNATURES = {
     "dawn_conv_gemm": [C.POINTER(ConvDesc), c_f],
+    "dawn_conv_gemm_nblocks": [_l, _i],
     "dawn_gn_partial": [c_f, _l, _i, _i, c_f, _i, c_f],
     "dawn_gn_reduce": [c_f, _i, c_f, c_f],
     "dawn_gn_finalize": [c_f, _d, c_f, c_f, c_f, c_f, _i, _f, c_f, c_f, c_f],

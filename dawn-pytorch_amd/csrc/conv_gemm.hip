@@ -225,6 +225,9 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
     }
 
     // ---- epilogue: C layout col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    float gs[TN], gss[TN];            // per-column sums of the stored values (GroupNorm statistics fused here)
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gss[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -248,8 +251,28 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const dawn_conv_desc d, 
                 if (d.res) v += d.res[orow * d.ld_res + n];
                 if (d.tr) v += dawn_silu(d.tr[orow * d.ld_tr + n] * d.tr_a[n] + d.tr_b[n]);
                 d.out[orow * d.ld_out + n] = v;
+                gs[j] += v;
+                gss[j] += v * v;
             }
         }
+    }
+    if (d.gn_part) {
+        // fp64 (sum, sumsq) per GroupNorm group of this block's columns -> gn_part[block][16] (MT:230,235)
+        double* red = reinterpret_cast<double*>(smem);       // every LDS read of the main loop has retired
+        if (tid < 16) red[tid] = 0.0;
+        __syncthreads();
+        const int cpg = d.N >> 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + l31;
+            if (n < d.N) {
+                const int g = n / cpg;
+                atomicAdd(&red[2 * g], (double)gs[j]);
+                atomicAdd(&red[2 * g + 1], (double)gss[j]);
+            }
+        }
+        __syncthreads();
+        if (tid < 16) d.gn_part[((long)blockIdx.z * gridDim.x + blockIdx.x) * 16 + tid] = red[tid];
     }
 }
 
@@ -430,6 +453,9 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const dawn_conv_des
         }
     }
 
+    float gs[TN], gss[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gss[j] = 0.f; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -453,8 +479,28 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const dawn_conv_des
                 if (d.res) v += d.res[orow * d.ld_res + n];
                 if (d.tr) v += dawn_silu(d.tr[orow * d.ld_tr + n] * d.tr_a[n] + d.tr_b[n]);
                 d.out[orow * d.ld_out + n] = v;
+                gs[j] += v;
+                gss[j] += v * v;
             }
         }
+    }
+    if (d.gn_part) {
+        // fp64 (sum, sumsq) per GroupNorm group of this block's columns -> gn_part[block][16] (MT:230,235)
+        double* red = reinterpret_cast<double*>(smem);       // every LDS read of the main loop has retired
+        if (tid < 16) red[tid] = 0.0;
+        __syncthreads();
+        const int cpg = d.N >> 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + l31;
+            if (n < d.N) {
+                const int g = n / cpg;
+                atomicAdd(&red[2 * g], (double)gs[j]);
+                atomicAdd(&red[2 * g + 1], (double)gss[j]);
+            }
+        }
+        __syncthreads();
+        if (tid < 16) d.gn_part[((long)blockIdx.z * gridDim.x + blockIdx.x) * 16 + tid] = red[tid];
     }
 }
 
@@ -500,6 +546,11 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 }  // namespace
 
 extern "C" void dawn_conv_set_variant(int v) { g_variant = v; }
+
+extern "C" int dawn_conv_gemm_nblocks(long M, int N) {
+    if (N <= 64) return ((g_variant & 2) && M >= 256 * 256) ? dawn_cdiv(M, 256) : dawn_cdiv(M, 128);
+    return dawn_cdiv(M, 128) * dawn_cdiv(N, 128);
+}
 
 extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     const dawn_conv_desc d = *dp;

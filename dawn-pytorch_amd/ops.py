@@ -92,7 +92,8 @@ class HipOps:
                   in1: Optional[Tensor] = None, bias: Optional[Tensor] = None,
                   row_stats: Optional[Tuple[Tensor, Tensor]] = None, ch_ab: Optional[Tuple[Tensor, Tensor]] = None,
                   pro_act: int = 0, pro_add: Optional[Tensor] = None, res: Optional[Tensor] = None,
-                  tr: Optional[Tuple[Tensor, Tensor, Tensor]] = None, out: Optional[Tensor] = None) -> Tensor:
+                  tr: Optional[Tuple[Tensor, Tensor, Tensor]] = None, out: Optional[Tensor] = None,
+                  gn_part: Optional[Tensor] = None) -> Tensor:
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
         rows_out = F * Ho * Wo
@@ -116,6 +117,7 @@ class HipOps:
         if tr is not None:
             d.tr, d.ld_tr, d.tr_a, d.tr_b = _p(tr[0]), _ld(tr[0]), _p(tr[1]), _p(tr[2])
         d.out, d.ld_out = _p(out), _ld(out)
+        d.gn_part = _p(gn_part)
         if self.prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
@@ -131,17 +133,24 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ GroupNorm / LayerNorm
+    def conv_gn_part(self, rows_out: int, N: int, like: Tensor) -> Tensor:
+        """Buffer for the GroupNorm partial sums a conv_gemm launch of this output shape emits (gn_part=...)."""
+        return self.empty(self.L.dawn_conv_gemm_nblocks(rows_out, N), 16, like=like, dtype=torch.float64)
+
     def gn_coeffs(self, x: Tensor, gamma: Tensor, beta: Tensor, film: Optional[Tuple[Tensor, Tensor]],
-                  total_rows: int, eps: float = 1e-5) -> Tuple[Tensor, Tensor]:
+                  total_rows: int, eps: float = 1e-5, part: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
         """Per-channel (a, b) with silu(x*a+b) == SiLU(FiLM(GroupNorm8(x))).  Statistics over all rows of the
-        WHOLE clip: with a T-shard communicator the fp64 partial sums are all-reduced."""
+        WHOLE clip: with a T-shard communicator the fp64 partial sums are all-reduced.  `part` = partial sums
+        already produced by the conv epilogue (conv_gemm(gn_part=...)); otherwise a statistics pass runs."""
         rows, Cc = x.shape
         self._require(x, gamma, beta)
-        nblk = max(1, min(1024, (rows * (Cc // 4) + 255) // 256 // 8))
-        part = self.empty(nblk, 16, like=x, dtype=torch.float64)
         sums = self.empty(16, like=x, dtype=torch.float64) if self.comm is not None else None
         s = self._stream()
-        check(self.L.dawn_gn_partial(_p(x), rows, Cc, _ld(x), _p(part), nblk, s), "dawn_gn_partial")
+        if part is None:
+            nblk = max(1, min(1024, (rows * (Cc // 4) + 255) // 256 // 8))
+            part = self.empty(nblk, 16, like=x, dtype=torch.float64)
+            check(self.L.dawn_gn_partial(_p(x), rows, Cc, _ld(x), _p(part), nblk, s), "dawn_gn_partial")
+        nblk = part.shape[0]
         a = self.empty(Cc, like=x)
         b = self.empty(Cc, like=x)
         fs, fsh = (film if film is not None else (None, None))

@@ -103,8 +103,10 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
         return ops.xattn_ln_sum(y3, rb.g3, Co)
 
     def conv1_and_stats():
-        c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, **g)
-        return c, ops.gn_coeffs(c, rb.g1, rb.be1, film, total_rows)
+        # GroupNorm partial sums come out of the conv epilogue (no separate statistics pass over c)
+        part = ops.conv_gn_part(F * H * W, Co, x)
+        c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, gn_part=part, **g)
+        return c, ops.gn_coeffs(c, rb.g1, rb.be1, film, total_rows, part=part)
 
     if rb.conditioned:
         film = (film_all[rb.film_off:rb.film_off + Co], film_all[rb.film_off + Co:rb.film_off + 2 * Co])
@@ -117,8 +119,9 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     # the 3x3 loader: an implicit GEMM reads every input element 9x, and 9x exp/div per element cost the conv
     # ~35 % of its MFMA rate (profiles/r1_b_conv_shapes.txt) -- far more than the extra 3 x C x 4 B per pixel.
     h1 = ops.gn_apply_res(c1, ab1[0], ab1[1], hcond)
-    c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, **g)
-    a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows)
+    part2 = ops.conv_gn_part(F * H * W, Co, x)
+    c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, **g)
+    a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows, part=part2)
     if rb.wr is not None:
         return ops.conv_gemm(x, rb.wr, Co, in1=x2, bias=rb.br, tr=(c2, a2, b2), **g)
     assert x2 is None

@@ -49,8 +49,12 @@ typedef struct dawn_conv_desc {
     const float* tr; int ld_tr;                    /* epilogue: out += silu(tr[row][n]*tr_a[n]+tr_b[n]) */
     const float* tr_a; const float* tr_b;
     float* out; int ld_out;
+    double* gn_part;                               /* optional: per-block GroupNorm(8) partial sums of the output,
+                                                      [gridDim.x][16] = (sum, sumsq) per group (see dawn_gn_reduce) */
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
+/* number of thread blocks (= rows of gn_part) dawn_conv_gemm will launch for an (M rows, N columns) output */
+int dawn_conv_gemm_nblocks(long M, int N);
 /* tuning knob for A/B measurements: bit0 BK=32 tiles, bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order */
 void dawn_conv_set_variant(int v);
 

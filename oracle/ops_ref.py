@@ -42,7 +42,8 @@ class RefOps:
 
     # ------------------------------------------------------------------ conv / linear
     def conv_gemm(self, in0, w, N, *, F, Hi, Wi, Ho=None, Wo=None, KH=1, KW=1, stride=1, pad=0, mode=0, in1=None,
-                  bias=None, row_stats=None, ch_ab=None, pro_act=0, pro_add=None, res=None, tr=None, out=None):
+                  bias=None, row_stats=None, ch_ab=None, pro_act=0, pro_add=None, res=None, tr=None, out=None,
+                  gn_part=None):
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
         x = in0 if in1 is None else torch.cat((in0, in1), dim=1)
@@ -78,16 +79,26 @@ class RefOps:
             y = y + res
         if tr is not None:
             y = y + F_.silu(tr[0] * tr[1][None, :] + tr[2][None, :])
+        if gn_part is not None:
+            yg = y.double().reshape(y.shape[0], 8, N // 8)
+            gn_part.zero_()
+            gn_part[0] = torch.stack((yg.sum(dim=(0, 2)), (yg * yg).sum(dim=(0, 2))), dim=1).reshape(16)
         if out is not None:
             out.copy_(y)
             return out
         return y.contiguous()
 
+    def conv_gn_part(self, rows_out, N, like):
+        return torch.zeros(3, 16, device=like.device, dtype=torch.float64)
+
     # ------------------------------------------------------------------ norms
-    def gn_coeffs(self, x, gamma, beta, film, total_rows, eps=1e-5):
+    def gn_coeffs(self, x, gamma, beta, film, total_rows, eps=1e-5, part=None):
         rows, C = x.shape
-        xg = x.double().reshape(rows, 8, C // 8)
-        sums = torch.stack((xg.sum(dim=(0, 2)), (xg * xg).sum(dim=(0, 2))), dim=1).reshape(16)
+        if part is not None:
+            sums = part.sum(dim=0)
+        else:
+            xg = x.double().reshape(rows, 8, C // 8)
+            sums = torch.stack((xg.sum(dim=(0, 2)), (xg * xg).sum(dim=(0, 2))), dim=1).reshape(16)
         if self.comm is not None:
             self.comm.all_reduce_sum(sums)
         sums = sums.reshape(8, 2)

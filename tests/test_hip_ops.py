@@ -119,6 +119,23 @@ def _conv_case(hip, name, in0, in1, w, N, kw, want):
     check("conv_gemm/" + name, got, want)
 
 
+@pytest.mark.parametrize("F,H,W,C0,N", [(3, 16, 16, 64, 64), (2, 8, 8, 128, 256), (5, 8, 8, 16, 16), (1, 40, 37, 32, 128)])
+def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
+    """GroupNorm partial sums emitted by the conv epilogue == statistics pass over the conv output."""
+    rows = F * H * W
+    x, w, b = rnd(rows, C0, seed=1), packw(9 * C0, N, seed=2), rnd(N, seed=3)
+    gamma, beta = rnd(N, seed=4) * 0.2 + 1, rnd(N, seed=5) * 0.2
+    for variant in (5, 13):
+        hip.L.dawn_conv_set_variant(variant)
+        xg = x.cuda()
+        part = hip.conv_gn_part(rows, N, xg)
+        c = hip.conv_gemm(xg, w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=b.cuda(), gn_part=part)
+        a1, b1 = hip.gn_coeffs(c, gamma.cuda(), beta.cuda(), None, rows, part=part)
+        a2, b2 = hip.gn_coeffs(c, gamma.cuda(), beta.cuda(), None, rows)
+        check(f"conv_gn_stats/a_{C0}_{N}_v{variant}", a1, a2, 1e-5)
+        check(f"conv_gn_stats/b_{C0}_{N}_v{variant}", b1, b2, 1e-5)
+
+
 def test_conv_gemm_transposed(hip, ref):
     from dawn_pytorch_amd.pack import pack_kn, deconv_w_kn_phases
     F, H, W, Cc = 3, 8, 8, 64
