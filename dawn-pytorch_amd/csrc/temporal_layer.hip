@@ -101,6 +101,14 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
     f32x16 outT[2];
     outT[0] = zero16();
     outT[1] = zero16();
+    // rotary cos/sin of this lane's query row: head-independent, loaded once (pairs 4c + 2*half + {0,1})
+    float2 qcs[4], qsn[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        qcs[c] = *reinterpret_cast<const float2*>(rcos + iqc * 16 + 4 * c + 2 * half);
+        qsn[c] = *reinterpret_cast<const float2*>(rsin + iqc * 16 + 4 * c + 2 * half);
+    }
+    constexpr float LOG2E = 1.4426950408889634f;
 
     // weight prefetch (WLDS): thread t carries float4 #(t + 512 i), i < 4, of the head's 2048-float4 weight image
     f32x4 wpre[4];
@@ -160,8 +168,8 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             f32x16 qT = proj_T(wq_p, wN, l31, half, Xs + iqc * XLD + 4 * half);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float2 cc = *reinterpret_cast<const float2*>(rcos + iqc * 16 + 4 * c + 2 * half);
-                const float2 sn = *reinterpret_cast<const float2*>(rsin + iqc * 16 + 4 * c + 2 * half);
+                const float2 cc = qcs[c];
+                const float2 sn = qsn[c];
                 const float a0 = qT[4 * c] * scale, a1 = qT[4 * c + 1] * scale;
                 const float a2 = qT[4 * c + 2] * scale, a3 = qT[4 * c + 3] * scale;
                 qT[4 * c] = a0 * cc.x - a1 * sn.x;
@@ -212,7 +220,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             for (int t = 0; t < NKT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = expf(st[t][r] - m);
+                    const float pv = exp2f((st[t][r] - m) * LOG2E);     // == exp(s - m); one v_exp_f32
                     st[t][r] = pv;
                     l += pv;
                 }
