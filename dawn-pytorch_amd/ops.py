@@ -135,7 +135,7 @@ class HipOps:
     # ------------------------------------------------------------------ GroupNorm / LayerNorm
     def conv_gn_part(self, rows_out: int, N: int, like: Tensor) -> Tensor:
         """Buffer for the GroupNorm partial sums a conv_gemm launch of this output shape emits (gn_part=...)."""
-        return self.empty(self.L.dawn_conv_gemm_nblocks(rows_out, N), 16, like=like, dtype=torch.float64)
+        return torch.zeros(self.L.dawn_conv_gemm_nblocks(rows_out, N), 16, device=like.device, dtype=torch.float64)
 
     def gn_coeffs(self, x: Tensor, gamma: Tensor, beta: Tensor, film: Optional[Tuple[Tensor, Tensor]],
                   total_rows: int, eps: float = 1e-5, part: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:

@@ -106,7 +106,7 @@ def test_conv_gemm(hip, ref, case):
     if ex.get("tr"):
         kw["tr"] = (rnd(F * Ho * Wo, N, seed=9), rnd(N, seed=10) * 0.3 + 1.0, rnd(N, seed=11) * 0.3)
     want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
-    for variant in (0, 7, 141, 269, 13):               # every tile configuration; 13 = shipped policy (left active)
+    for variant in (0, 7, 141, 269, 525, 1037, 13):    # every tile configuration; 13 = shipped policy (left active)
         hip.L.dawn_conv_set_variant(variant)
         _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
 
@@ -125,7 +125,7 @@ def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
     rows = F * H * W
     x, w, b = rnd(rows, C0, seed=1), packw(9 * C0, N, seed=2), rnd(N, seed=3)
     gamma, beta = rnd(N, seed=4) * 0.2 + 1, rnd(N, seed=5) * 0.2
-    for variant in (5, 13):
+    for variant in (5, 525, 13):
         hip.L.dawn_conv_set_variant(variant)
         xg = x.cuda()
         part = hip.conv_gn_part(rows, N, xg)
