@@ -24,8 +24,9 @@ namespace {
 // off), bit2 XCD-contiguous tile order for multi-tap convs on >= 32x32 frames (+7..17 %; hurts pure streaming
 // 1x1 GEMMs, so not used there), bit3 direct-to-LDS staging for prologue-free GEMMs (+5..15 %; BK=32 there when
 // K >= 2304 and N >= 256), 0x80 force BK=32 on that path, 0x100 its 3-stage counted-vmcnt pipeline (no gain:
-// the loop is bound by the per-CU fetch rate, not by load latency), 0x10/0x20 perf ablations.
-static int g_variant = 0xD;
+// the loop is bound by the per-CU fetch rate, not by load latency), 0x800 LDS-halo kernel for prologue-free
+// 3x3/s1/p1 convs whose tile geometry fits (+5..19 %, profiles/r1_l_conv_halo.txt), 0x10/0x20 perf ablations.
+static int g_variant = 0x80D;
 
 struct RowInfo {
     long rowoff;  // (f*Hi + yb)*Wi + xb : input pixel index of tap (0,0) (may point outside; bounds via yb/xb)
@@ -504,6 +505,228 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const dawn_conv_des
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with an LDS HALO tile: the loop is channel-chunk-major -- for each 16-channel
+// chunk the block stages its input patch (TR+2 rows x (W+2) pixels per frame part, zero-padded) ONCE and runs
+// all nine taps out of it; only the 16 x BN weight chunk changes per tap.  The implicit-GEMM kernels above
+// re-fetch the A tile for every tap (9x; they are bound by the per-CU fetch rate, profiles/r1_j_conv_glds.txt);
+// here the A fetch drops to (TR+2)(W+2)/(TR W) ~ 1.1-2x.  Staging is direct-to-LDS (global_load_lds) with the
+// same source-side XOR swizzle as conv_gemm_glds_kernel; the A fragment of tap (ky,kx) is read at position
+// pos(pixel) + (ky-1)(W+2) + (kx-1).
+// Tile = BM consecutive output pixels = TR full rows of one frame (or nf whole frames when a frame is < BM).
+template <int BN, int WN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const dawn_conv_desc d, const int xcd_remap, const int TR,
+                                                           const int nf, const int P16) {
+    constexpr int BM = 64 * (4 / WN), BK = 16, KQ = 4;
+    constexpr int WTN = BN / WN;
+    constexpr int TM = 2, TN = WTN / 32;
+    constexpr int NBI = BN * KQ / 64 / 4;
+    constexpr int MAXS = 7;                         // A wave-instructions per wave per channel chunk (P16/16/4 <= 7)
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* As = smem;                               // [2][P16][16]
+    float* Bs = smem + 2 * P16 * BK;                // [2][4][BN][4]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int H = d.Hi, W = d.Wi, PW = W + 2, PP = (TR + 2) * PW;
+    const int Cin = d.C0 + d.C1;
+    const int nC = Cin / BK;
+    const long M = (long)d.F * H * W;
+    const int nNt = (d.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    if (xcd_remap) {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / nNt, nt = bid - mt * nNt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+    // tile origin: frame f0, first row y0
+    const int f0 = (int)(m0 / ((long)H * W));
+    const int y0 = (int)((m0 - (long)f0 * H * W) / W);
+
+    // ---- staging slots of this lane: position -> source pixel (or -1 = zero padding), logical k-slot
+    const int nInstr = P16 >> 4;
+    long spix[MAXS];
+    int skq[MAXS];
+#pragma unroll
+    for (int sidx = 0; sidx < MAXS; ++sidx) {
+        const int ii = sidx * 4 + wave;
+        const int pos = ii * 16 + (lane >> 2);
+        skq[sidx] = (lane & 3) ^ ((pos >> 2) & 3);
+        long pix = -1;
+        if (ii < nInstr && pos < nf * PP) {
+            const int fi = pos / PP;
+            const int rem = pos - fi * PP;
+            const int pyy = rem / PW, pxx = rem - pyy * PW;
+            const int y = y0 + pyy - 1, x = pxx - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) pix = ((long)(f0 + fi) * H + y) * W + x;
+        }
+        spix[sidx] = pix;
+    }
+    // ---- A fragment base positions of this lane's output pixels (centre tap)
+    int pc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        const int fi = r / (TR * W);
+        const int rem = r - fi * TR * W;
+        const int ty = rem / W, x = rem - ty * W;
+        pc[i] = fi * PP + (ty + 1) * PW + (x + 1);
+    }
+
+    // one staging slot (<= 1 wave-instruction per wave) of channel chunk cc; the 7 slots of the next chunk are
+    // spread over taps 0..6 of the current one so the fetch stream is even
+    auto issueA = [&](int cc, int buf, int sidx) {
+        const int cbase = cc * BK;
+        const bool src1 = cbase >= d.C0;
+        const float* src = src1 ? d.in1 : d.in0;
+        const int ld = src1 ? d.ld1 : d.ld0;
+        const int cs0 = src1 ? cbase - d.C0 : cbase;
+        const int ii = sidx * 4 + wave;
+        if (ii < nInstr) {
+            const float* g = spix[sidx] >= 0 ? src + spix[sidx] * ld + cs0 + skq[sidx] * 4 : dawn_zero_block;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(As + buf * P16 * BK + ii * 256),
+                                             16, 0, 0);
+        }
+    };
+    auto issueB = [&](int chunk, int buf) {
+#pragma unroll
+        for (int j = 0; j < NBI; ++j) {
+            const int q = wave * NBI + j;
+            const int idx = q * 64 + lane;
+            const int kq = idx / BN, n = idx % BN;
+            const int gn = n0 + n;
+            const float* g = gn < d.N ? d.w + ((size_t)(chunk * KQ + kq) * d.N + gn) * 4 : dawn_zero_block;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(Bs + buf * KQ * BN * 4 + q * 256),
+                                             16, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int sidx = 0; sidx < MAXS; ++sidx) issueA(0, 0, sidx);
+    issueB(0, 0);           // step (cc=0, tap=0): weight chunk tap*nC + cc = 0
+    __syncthreads();
+    int bufA = 0, bufB = 0;
+    for (int cc = 0; cc < nC; ++cc) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < MAXS && cc + 1 < nC) issueA(cc + 1, bufA ^ 1, tap);
+            {   // next step's weight chunk
+                int ntap = tap + 1, ncc = cc;
+                if (ntap == 9) { ntap = 0; ncc = cc + 1; }
+                if (ncc < nC) issueB(ntap * nC + ncc, bufB ^ 1);
+            }
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int toff = (ky - 1) * PW + (kx - 1);
+            const float* Ab = As + bufA * P16 * BK;
+            const float* Bb = Bs + bufB * KQ * BN * 4;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) {
+                const int kq = kk * 2 + half;
+                f32x4 a[TM], b[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int pos = pc[i] + toff;
+                    a[i] = *reinterpret_cast<const f32x4*>(Ab + pos * BK + ((kq ^ ((pos >> 2) & 3)) << 2));
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j] = *reinterpret_cast<const f32x4*>(Bb + (kq * BN + wn * WTN + j * 32 + l31) * 4);
+#pragma unroll
+                for (int s = 0; s < 4; ++s)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+            }
+            __syncthreads();
+            bufB ^= 1;
+        }
+        bufA ^= 1;
+    }
+
+    float gs[TN], gss[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gss[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                if (n >= d.N) continue;
+                float v = acc[i][j][r];
+                if (d.bias) v += d.bias[n];
+                if (d.res) v += d.res[m * d.ld_res + n];
+                if (d.tr) v += dawn_silu(d.tr[m * d.ld_tr + n] * d.tr_a[n] + d.tr_b[n]);
+                d.out[m * d.ld_out + n] = v;
+                gs[j] += v;
+                gss[j] += v * v;
+            }
+        }
+    }
+    if (d.gn_part) {
+        double* red = reinterpret_cast<double*>(smem);
+        if (tid < 16) red[tid] = 0.0;
+        __syncthreads();
+        const int cpg = d.N >> 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + l31;
+            if (n < d.N) {
+                const int g = n / cpg;
+                atomicAdd(&red[2 * g], (double)gs[j]);
+                atomicAdd(&red[2 * g + 1], (double)gss[j]);
+            }
+        }
+        __syncthreads();
+        if (tid < 16) d.gn_part[(long)blockIdx.x * 16 + tid] = red[tid];
+    }
+}
+
+// host-side geometry test + launch; returns false when the shape does not fit the halo tiling
+template <int BN, int WN>
+bool try_launch_halo(const dawn_conv_desc& d, long M, hipStream_t s) {
+    constexpr int BM = 64 * (4 / WN);
+    const int H = d.Hi, W = d.Wi;
+    if (M % BM != 0 || W > BM || BM % W != 0) return false;
+    int TR = BM / W, nf = 1;
+    if (TR <= H) { if (H % TR != 0) return false; }
+    else { if (TR % H != 0) return false; nf = TR / H; TR = H; if (d.F % nf != 0) return false; }
+    const int P = nf * (TR + 2) * (W + 2);
+    const int P16 = (P + 15) / 16 * 16;
+    if (P16 / 16 > 7 * 4) return false;
+    const size_t lds = ((size_t)2 * P16 * 16 + (size_t)2 * 4 * BN * 4) * sizeof(float);
+    if (lds > 160 * 1024) return false;
+    const int nwg = (int)(M / BM) * dawn_cdiv(d.N, BN);
+    const int remap = ((g_variant & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
+    if (lds > 65536)
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN, WN>), dim3(nwg), dim3(256), lds, s, d, remap, TR, nf, P16);
+    return true;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int PRO>
 void launch_pro(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
@@ -555,7 +778,8 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 extern "C" void dawn_conv_set_variant(int v) { g_variant = v; }
 
 extern "C" int dawn_conv_gemm_nblocks(long M, int N) {
-    if (N <= 64) return dawn_cdiv(M, 128);   // upper bound (the 256-row tile variants launch half as many blocks)
+    if (N <= 64) return dawn_cdiv(M, 128);   // upper bound (the 256-row tile variants launch fewer blocks; the
+                                             // caller zero-fills the buffer)
     return dawn_cdiv(M, 128) * dawn_cdiv(N, 128);
 }
 
@@ -573,6 +797,14 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     const long M = (d.mode == 0) ? (long)d.F * d.Ho * d.Wo : (long)d.F * d.Hi * d.Wi;
     if (M <= 0 || d.N <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if ((g_variant & 0x800) && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.Hi &&
+        d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
+        const bool ok = d.N <= 64 ? try_launch_halo<64, 1>(d, M, s) : try_launch_halo<128, 2>(d, M, s);
+        if (ok) {
+            DAWN_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     const bool k32 = (g_variant & 1) && (d.C0 % 32 == 0) && (d.C1 % 32 == 0) && (d.KH * d.KW * Cin >= 4096);
     if (d.N <= 64) {
         if ((g_variant & 2) && M >= 256 * 256) launch<256, 64, 16, 4, 1>(d, M, s);

@@ -77,6 +77,10 @@ CONV_CASES = [
     ("c1x1_bigM_N64_rowstats_res", 3, 160, 150, 32, 32, 64, 1, 1, 0, {"row_stats": True, "res": True}),
     ("c3x3_k32_cat_N128", 2, 24, 24, 64, 32, 128, 3, 1, 1, {"bias": True}),
     ("c3x3_k32_cat_256p256_N128_deepK", 3, 8, 8, 256, 256, 128, 3, 1, 1, {"bias": True}),
+    ("c3x3_halo_W64_rows4", 1, 64, 64, 32, 0, 64, 3, 1, 1, {"bias": True}),
+    ("c3x3_halo_cat_W32_N128", 2, 32, 32, 64, 64, 128, 3, 1, 1, {"bias": True}),
+    ("c3x3_halo_multiframe_tile", 8, 4, 4, 64, 0, 128, 3, 1, 1, {}),
+    ("c3x3_halo_N192_ragged_ntile", 4, 8, 8, 32, 0, 192, 3, 1, 1, {"bias": True}),
 ]
 
 
@@ -106,7 +110,7 @@ def test_conv_gemm(hip, ref, case):
     if ex.get("tr"):
         kw["tr"] = (rnd(F * Ho * Wo, N, seed=9), rnd(N, seed=10) * 0.3 + 1.0, rnd(N, seed=11) * 0.3)
     want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
-    for variant in (0, 7, 141, 269, 525, 1037, 13):    # every tile configuration; 13 = shipped policy (left active)
+    for variant in (0, 7, 141, 269, 525, 1037, 13, 2061):   # every tile configuration; 2061 = shipped policy (left active)
         hip.L.dawn_conv_set_variant(variant)
         _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
 
@@ -125,7 +129,7 @@ def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
     rows = F * H * W
     x, w, b = rnd(rows, C0, seed=1), packw(9 * C0, N, seed=2), rnd(N, seed=3)
     gamma, beta = rnd(N, seed=4) * 0.2 + 1, rnd(N, seed=5) * 0.2
-    for variant in (5, 525, 13):
+    for variant in (5, 525, 13, 2061):
         hip.L.dawn_conv_set_variant(variant)
         xg = x.cuda()
         part = hip.conv_gn_part(rows, N, xg)
