@@ -142,7 +142,8 @@ __global__ __launch_bounds__(256) void gn_apply_res_kernel(const float* __restri
 template <int L>
 __global__ __launch_bounds__(256) void ln_rowstats_kernel(const float* __restrict__ in0, int C0, int ld0,
                                                           const float* __restrict__ in1, int C1, int ld1, long rows,
-                                                          float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+                                                          float eps, float* __restrict__ mean, float* __restrict__ rstd,
+                                                          float* __restrict__ xn) {
     constexpr int RPB = 256 / L;
     const int tid = threadIdx.x;
     const int sub = tid % L;
@@ -176,9 +177,17 @@ __global__ __launch_bounds__(256) void ln_rowstats_kernel(const float* __restric
         }
     }
     ssq = wave_sum(ssq, L);
-    if (ok && sub == 0) {
+    const float rs = 1.0f / sqrtf(ssq / (float)C + eps);
+    if (ok && sub == 0 && mean) {
         mean[row] = mu;
-        rstd[row] = 1.0f / sqrtf(ssq / (float)C + eps);
+        rstd[row] = rs;
+    }
+    if (xn) {   // normalised rows (both sources concatenated), consumed by a prologue-free GEMM
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int qd = sub + i * L;
+            if (ok && qd < nq) *reinterpret_cast<f32x4*>(xn + row * C + qd * 4) = (v[i] - mu) * rs;
+        }
     }
 }
 
@@ -223,16 +232,16 @@ extern "C" int dawn_gn_apply_res(const float* x, const float* a, const float* b,
     DAWN_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int dawn_ln_rowstats(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
-                                float eps, float* mean, float* rstd, void* stream) {
+static int ln_launch(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows, float eps,
+                     float* mean, float* rstd, float* xn, void* stream) {
     const int C = C0 + C1;
     if (C % 4 != 0 || C0 % 4 != 0 || C > 1024 || C < 16)
-        return dawn_set_error_msg(-21, "dawn_ln_rowstats: need 16 <= C <= 1024, C % 4 == 0");
+        return dawn_set_error_msg(-21, "dawn_ln_rowstats/dawn_ln_rows: need 16 <= C <= 1024, C % 4 == 0");
     hipStream_t s = (hipStream_t)stream;
     const int nq = C / 4;
 #define LAUNCH_LN(L)                                                                                         \
     hipLaunchKernelGGL(ln_rowstats_kernel<L>, dim3(dawn_cdiv(rows, 256 / L)), dim3(256), 0, s, in0, C0, ld0, \
-                       in1, C1, ld1, rows, eps, mean, rstd)
+                       in1, C1, ld1, rows, eps, mean, rstd, xn)
     if (nq >= 64) LAUNCH_LN(64);
     else if (nq >= 32) LAUNCH_LN(32);
     else if (nq >= 16) LAUNCH_LN(16);
@@ -241,4 +250,14 @@ extern "C" int dawn_ln_rowstats(const float* in0, int C0, int ld0, const float* 
 #undef LAUNCH_LN
     DAWN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int dawn_ln_rowstats(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
+                                float eps, float* mean, float* rstd, void* stream) {
+    return ln_launch(in0, C0, ld0, in1, C1, ld1, rows, eps, mean, rstd, nullptr, stream);
+}
+
+extern "C" int dawn_ln_rows(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows, float eps,
+                            float* xn, void* stream) {
+    return ln_launch(in0, C0, ld0, in1, C1, ld1, rows, eps, nullptr, nullptr, xn, stream);
 }

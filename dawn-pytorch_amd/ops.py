@@ -181,6 +181,16 @@ class HipOps:
                                       _ld(in1), rows, eps, _p(mean), _p(rstd), self._stream()), "dawn_ln_rowstats")
         return mean, rstd
 
+    def ln_rows(self, in0: Tensor, in1: Optional[Tensor] = None, eps: float = 1e-5) -> Tensor:
+        """LayerNorm without gain of [in0|in1] rows, materialised (the gain lives in the next projection)."""
+        rows = in0.shape[0]
+        self._require(in0, in1)
+        C = in0.shape[1] + (0 if in1 is None else in1.shape[1])
+        xn = self.empty(rows, C, like=in0)
+        check(self.L.dawn_ln_rows(_p(in0), in0.shape[1], _ld(in0), _p(in1), 0 if in1 is None else in1.shape[1],
+                                  _ld(in1), rows, eps, _p(xn), self._stream()), "dawn_ln_rows")
+        return xn
+
     # ------------------------------------------------------------------ cross attention
     def xattn_prep(self, kv: Tensor, k_scale: Tensor, null_kv: Tensor, kvtab: Tensor, branch: int,
                    nulltab: Tensor) -> None:

@@ -94,8 +94,8 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
         if ops.can_fuse_xattn(rb.Cin, Co, x.shape[1]):
             return ops.xattn_layer_c64(x, x2, H * W, rb.wq, rb.wo, rb.g3, rb.q_scale, cs.kvtab[rb.cond_index],
                                        cs.nulltab[rb.cond_index])
-        stats = ops.ln_rowstats(x, x2)
-        q = ops.conv_gemm(x, rb.wq, 192, in1=x2, row_stats=stats, **g)
+        # LayerNorm_img is materialised (one streaming pass) so that to_q runs as a prologue-free GEMM
+        q = ops.conv_gemm(ops.ln_rows(x, x2), rb.wq, 192, **g)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)
         y3 = ops.empty(F * H * W, 3 * Co, like=x)
         for b in range(3):
@@ -137,8 +137,7 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
     Fext = xe.shape[0] // HW
     if ops.can_fuse_temporal(a.C, Fext, F, cs.win):
         return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band)
-    stats = ops.ln_rowstats(xe)
-    qkv = ops.conv_gemm(xe, a.wqkv, 768, row_stats=stats, F=Fext, Hi=H, Wi=W)
+    qkv = ops.conv_gemm(ops.ln_rows(xe), a.wqkv, 768, F=Fext, Hi=H, Wi=W)
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W)
 
@@ -146,15 +145,13 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
 def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
     if a.C == 64:
         return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout)
-    stats = ops.ln_rowstats(x)
-    qkv = ops.conv_gemm(x, a.wqkv, 768, row_stats=stats, F=F, Hi=H, Wi=W)
+    qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W)
     o = ops.sla(qkv, F, H * W)
     return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W)
 
 
 def _mid_spatial(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
-    stats = ops.ln_rowstats(x)
-    qkv = ops.conv_gemm(x, a.wqkv, 768, row_stats=stats, F=F, Hi=H, Wi=W)
+    qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W)
     o = ops.frame_attn(qkv, F, H * W)
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W)
 

@@ -78,6 +78,10 @@ int dawn_gn_apply_res(const float* x, const float* a, const float* b, const floa
 /* ---- PreNorm LayerNorm / LayerNorm_img statistics per pixel over [in0|in1] channels (MT:179-203) */
 int dawn_ln_rowstats(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
                      float eps, float* mean, float* rstd, void* stream);
+/* same statistics, but writes the normalised rows xn (rows, C0+C1) = (x - mean) * rstd, so that the consuming
+ * projection (gain folded into its weights) runs as a prologue-free direct-to-LDS GEMM */
+int dawn_ln_rows(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows, float eps,
+                 float* xn, void* stream);
 
 /* ---- A5 tri-modal CrossAttention (MT:516-559) ------------------------------------------------
  * prep (once per clip): kv (F,128) from to_kv -> kvtab[f][branch] = [l2norm(k_h)*k_scale | v]  */

@@ -125,6 +125,11 @@ class RefOps:
         var = x.var(dim=1, unbiased=False)
         return mean, 1.0 / torch.sqrt(var + eps)
 
+    def ln_rows(self, in0, in1=None, eps=1e-5):
+        x = in0 if in1 is None else torch.cat((in0, in1), dim=1)
+        mean, rstd = self.ln_rowstats(in0, in1, eps)
+        return (x - mean[:, None]) * rstd[:, None]
+
     # ------------------------------------------------------------------ cross attention
     def xattn_prep(self, kv, k_scale, null_kv, kvtab, branch, nulltab):
         Fn = kv.shape[0]

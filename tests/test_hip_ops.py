@@ -198,6 +198,7 @@ def test_ln_rowstats(hip, ref, C0, C1, rows):
     gm, gr = hip.ln_rowstats(a.cuda(), None if b is None else b.cuda())
     check(f"ln_rowstats/mean_{C0}_{C1}", gm, wm, 1e-5)
     check(f"ln_rowstats/rstd_{C0}_{C1}", gr, wr, 1e-5)
+    check(f"ln_rows/{C0}_{C1}", hip.ln_rows(a.cuda(), None if b is None else b.cuda()), ref.ln_rows(a, b), 1e-5)
 
 
 # ---------------------------------------------------------------------------------------------- cross attention
