@@ -225,7 +225,8 @@ def main():
         result["roofline"] = {"bound": "mfma", "achieved": ach, "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
                               "frac": ach / PEAK_FP32_MFMA_TFLOPS, "traffic": traffic,
                               "algorithmic_bytes_per_launch_avg": sum(p[4] for p in prof) / len(prof),
-                              "kernel": "conv_gemm_kernel<64|128> (fp32 MFMA implicit GEMM)",
+                              "kernel": "dawn_conv_gemm family: conv3x3_halo_kernel / conv_gemm_glds_kernel / conv_gemm_kernel "
+                                        "(fp32 MFMA implicit GEMM)",
                               "launches": len(prof), "avg_launch_us": t_ms * 1e3 / len(prof),
                               "timing": (f"HIP events around every conv_gemm launch of every {args.eager_every}th DDIM step "
                                          "(those steps run eagerly inside the timed region; the others replay a HIP graph)"
