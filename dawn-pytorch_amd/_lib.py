@@ -35,6 +35,7 @@ class ConvDesc(C.Structure):
         ("tr_a", c_f), ("tr_b", c_f),
         ("out", c_f), ("ld_out", _i),
         ("gn_part", c_f),
+        ("w_bf3", c_f),
     ]
 
 

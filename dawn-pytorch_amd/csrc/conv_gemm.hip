@@ -25,8 +25,10 @@ namespace {
 // 1x1 GEMMs, so not used there), bit3 direct-to-LDS staging for prologue-free GEMMs (+5..15 %; BK=32 there when
 // K >= 2304 and N >= 256), 0x80 force BK=32 on that path, 0x100 its 3-stage counted-vmcnt pipeline (no gain:
 // the loop is bound by the per-CU fetch rate, not by load latency), 0x800 LDS-halo kernel for prologue-free
-// 3x3/s1/p1 convs whose tile geometry fits (+5..19 %, profiles/r1_l_conv_halo.txt), 0x10/0x20 perf ablations.
-static int g_variant = 0x80D;
+// 3x3/s1/p1 convs whose tile geometry fits (+5..19 %, profiles/r1_l_conv_halo.txt), 0x1000 split-operand bf16
+// MFMA version of that kernel when the caller supplies w_bf3 (6 cross terms; 0x2000: all 9), 0x10/0x20 and
+// bits 16-18 perf ablations.
+static int g_variant = 0x180D;
 
 struct RowInfo {
     long rowoff;  // (f*Hi + yb)*Wi + xb : input pixel index of tap (0,0) (may point outside; bounds via yb/xb)
@@ -727,6 +729,279 @@ bool try_launch_halo(const dawn_conv_desc& d, long M, hipStream_t s) {
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// fp32 3x3 convolution on the bf16 matrix pipe by exact operand splitting ("bf16x3" emulation of fp32):
+// every fp32 operand is written as x = x1 + x2 + x3 with x1 = bf16(x), x2 = bf16(x - x1), x3 = bf16(x - x1 - x2)
+// (round-to-nearest-even; the residuals are exact in fp32, and 3 x 8 significand bits cover the fp32
+// significand), every bf16 x bf16 product is exact in the fp32 accumulator, and the NT largest cross terms are
+// accumulated (NT = 6: all terms down to 2^-16 relative, i.e. x1w1, x1w2, x2w1, x2w2, x1w3, x3w1; the dropped terms
+// are <= 2^-24 relative -- the size of one fp32 rounding; NT = 9: every term).  v_mfma_f32_32x32x16_bf16 runs at
+// 16x the fp32 MFMA rate, so 6 terms cost 3/8 of the fp32 instruction time.
+// Structure = conv3x3_halo_kernel; the staged fp32 patch is split ONCE per channel chunk into three bf16 planes
+// in LDS ([plane][k-half][pos][8 ch], conflict-free ds_read_b128), the weights arrive pre-split from the host
+// ([chunk][plane][k-half][N][8]).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3(const f32x4 v, uint2& p1, uint2& p2, uint2& p3) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 h1, h2, h3;
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h1[i] = (__bf16)v[i]; r[i] = v[i] - (float)h1[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h2[i] = (__bf16)r[i]; r[i] = r[i] - (float)h2[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h3[i] = (__bf16)r[i];
+    p1 = *reinterpret_cast<uint2*>(&h1);
+    p2 = *reinterpret_cast<uint2*>(&h2);
+    p3 = *reinterpret_cast<uint2*>(&h3);
+}
+
+template <int BN, int WN, int NT, int ABL>
+__global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_desc d, const int xcd_remap,
+                                                                const int TR, const int nf, const int P16) {
+    constexpr int BM = 64 * (4 / WN);
+    constexpr int WTN = BN / WN;
+    constexpr int TM = 2, TN = WTN / 32;
+    constexpr int NBI = 6 * BN / 64;                // weight wave-instructions per stage (3 planes x BN x 32 B)
+    constexpr int MAXS = 7;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    float* raw = reinterpret_cast<float*>(smem_b);                               // [P16][16] fp32
+    const int HPS = P16 * 16 + 128;                                              // half-plane stride (+32 banks)
+    unsigned char* planes = smem_b + (size_t)P16 * 64;                           // [3 planes][2 k-halves][HPS]: pos x 16 B
+    unsigned char* Bs = planes + (size_t)6 * HPS;                                // [2][3][2][BN][16 B]
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int H = d.Hi, W = d.Wi, PW = W + 2, PP = (TR + 2) * PW;
+    const int Cin = d.C0 + d.C1;
+    const int nC = Cin / 16;
+    const long M = (long)d.F * H * W;
+    const int nNt = (d.N + BN - 1) / BN;
+    int bid = blockIdx.x;
+    if (xcd_remap) {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / nNt, nt = bid - mt * nNt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+    const int f0 = (int)(m0 / ((long)H * W));
+    const int y0 = (int)((m0 - (long)f0 * H * W) / W);
+
+    const int nInstr = P16 >> 4;
+    long spix[MAXS];
+#pragma unroll
+    for (int sidx = 0; sidx < MAXS; ++sidx) {
+        const int ii = sidx * 4 + wave;
+        const int pos = ii * 16 + (lane >> 2);
+        long pix = -1;
+        if (ii < nInstr && pos < nf * PP) {
+            const int fi = pos / PP;
+            const int rem = pos - fi * PP;
+            const int pyy = rem / PW, pxx = rem - pyy * PW;
+            const int y = y0 + pyy - 1, x = pxx - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) pix = ((long)(f0 + fi) * H + y) * W + x;
+        }
+        spix[sidx] = pix;
+    }
+    int pc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        const int fi = r / (TR * W);
+        const int rem = r - fi * TR * W;
+        const int ty = rem / W, x = rem - ty * W;
+        pc[i] = fi * PP + (ty + 1) * PW + (x + 1);
+    }
+
+    const float* zb = dawn_zero_block;
+    asm volatile("" : "+s"(zb));                    // keep the address in SGPRs (no GOT reload per tap)
+    auto issueA = [&](int cc, int sidx) -> bool {
+        const int cbase = cc * 16;
+        const bool src1 = cbase >= d.C0;
+        const float* src = src1 ? d.in1 : d.in0;
+        const int ld = src1 ? d.ld1 : d.ld0;
+        const int cs0 = src1 ? cbase - d.C0 : cbase;
+        const int ii = sidx * 4 + wave;
+        if (ii < nInstr) {
+            const float* g = spix[sidx] >= 0 ? src + spix[sidx] * ld + cs0 + (lane & 3) * 4 : zb;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                             (__attribute__((address_space(3))) void*)(raw + ii * 256), 16, 0, 0);
+        }
+        return ii < nInstr;
+    };
+    const unsigned short* wsp = reinterpret_cast<const unsigned short*>(d.w_bf3);
+    auto issueB = [&](int chunk, int buf) {
+#pragma unroll
+        for (int j = 0; j < (NBI + 3) / 4; ++j) {
+            const int q = j * 4 + wave;
+            if (q < NBI) {
+                const int idx = q * 64 + lane;
+                const int ph = idx / BN, n = idx - ph * BN;       // ph = plane*2 + k-half
+                const int gn = n0 + n;
+                const void* g = gn < d.N ? (const void*)(wsp + (((size_t)chunk * 6 + ph) * d.N + gn) * 8)
+                                         : (const void*)zb;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                                 (__attribute__((address_space(3))) void*)(Bs + (size_t)buf * 3 * BN * 32 + q * 1024),
+                                                 16, 0, 0);
+            }
+        }
+    };
+    auto split_pass = [&]() {
+        const int nq = P16 * 4;
+        for (int q = tid; q < nq; q += 256) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(raw + q * 4);
+            uint2 p1, p2, p3;
+            split3(v, p1, p2, p3);
+            const int pos = q >> 2, slot = q & 3;
+            unsigned char* dst = planes + (size_t)(slot >> 1) * HPS + pos * 16 + (slot & 1) * 8;
+            *reinterpret_cast<uint2*>(dst) = p1;
+            *reinterpret_cast<uint2*>(dst + 2 * HPS) = p2;
+            *reinterpret_cast<uint2*>(dst + 4 * HPS) = p3;
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int sidx = 0; sidx < MAXS; ++sidx) issueA(0, sidx);
+    issueB(0, 0);
+    int bufB = 0;
+    for (int cc = 0; cc < nC; ++cc) {
+        __syncthreads();            // raw(cc) and the first weight chunk have landed; planes are free
+        if (!(ABL & 4) || cc == 0) split_pass();
+        __syncthreads();
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            // weights of the next tap first, then one slot of the next chunk's patch: the vmcnt wait at the end of
+            // this tap then leaves the patch load in flight (it gets two taps of latency budget)
+            {
+                int ntap = tap + 1, ncc = cc;
+                if (ntap == 9) { ntap = 0; ncc = cc + 1; }
+                if (ncc < nC && !((ABL & 1) && (cc || tap))) issueB(ntap * nC + ncc, bufB ^ 1);
+            }
+            bool issuedA = false;
+            if (tap < MAXS && cc + 1 < nC) issuedA = issueA(cc + 1, tap);
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int toff = (ky - 1) * PW + (kx - 1);
+            const unsigned char* Bb = Bs + (size_t)bufB * 3 * BN * 32;
+            bf16x8 a[TM][3], b[TN][3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    a[i][pl] = *reinterpret_cast<const bf16x8*>(planes + (size_t)(pl * 2 + half) * HPS + (pc[i] + toff) * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    b[j][pl] = *reinterpret_cast<const bf16x8*>(Bb + ((size_t)((pl * 2 + half) * BN + wn * WTN + j * 32 + l31)) * 16);
+            }
+            // smallest terms first
+            constexpr int PA9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+            constexpr int PB9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 9 - NT; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA9[t]], b[j][PB9[t]], acc[i][j], 0, 0, 0);
+            if (tap < 8 && !(ABL & 2)) {
+                if (issuedA) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+            }
+            bufB ^= 1;
+        }
+    }
+
+    float gs[TN], gss[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gss[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (m >= M) continue;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * WTN + j * 32 + l31;
+                if (n >= d.N) continue;
+                float v = acc[i][j][r];
+                if (d.bias) v += d.bias[n];
+                if (d.res) v += d.res[m * d.ld_res + n];
+                if (d.tr) v += dawn_silu(d.tr[m * d.ld_tr + n] * d.tr_a[n] + d.tr_b[n]);
+                d.out[m * d.ld_out + n] = v;
+                gs[j] += v;
+                gss[j] += v * v;
+            }
+        }
+    }
+    if (d.gn_part) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem_b);
+        if (tid < 16) red[tid] = 0.0;
+        __syncthreads();
+        const int cpg = d.N >> 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * WTN + j * 32 + l31;
+            if (n < d.N) {
+                const int g = n / cpg;
+                atomicAdd(&red[2 * g], (double)gs[j]);
+                atomicAdd(&red[2 * g + 1], (double)gss[j]);
+            }
+        }
+        __syncthreads();
+        if (tid < 16) d.gn_part[(long)blockIdx.x * 16 + tid] = red[tid];
+    }
+}
+
+template <int BN, int WN>
+bool try_launch_halo_bf16(const dawn_conv_desc& d, long M, hipStream_t s, bool nine) {
+    constexpr int BM = 64 * (4 / WN);
+    const int H = d.Hi, W = d.Wi;
+    if (M % BM != 0 || W > BM || BM % W != 0 || d.C0 % 16 != 0 || d.C1 % 16 != 0) return false;
+    int TR = BM / W, nf = 1;
+    if (TR <= H) { if (H % TR != 0) return false; }
+    else { if (TR % H != 0) return false; nf = TR / H; TR = H; if (d.F % nf != 0) return false; }
+    const int P = nf * (TR + 2) * (W + 2);
+    const int P16 = (P + 15) / 16 * 16;
+    if (P16 / 16 > 7 * 4) return false;
+    const size_t lds = (size_t)P16 * 64 + (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 3 * BN * 32;
+    if (lds > 160 * 1024) return false;
+    const int nwg = (int)(M / BM) * dawn_cdiv(d.N, BN);
+    const int remap = ((g_variant & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
+    const int abl = (g_variant >> 16) & 7;
+#define LAUNCH_BF(NTV, ABLV)                                                                                        \
+    do {                                                                                                            \
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_bf16_kernel<BN, WN, NTV, ABLV>,                         \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
+        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, WN, NTV, ABLV>), dim3(nwg), dim3(256), lds, s, d, remap, TR, \
+                           nf, P16);                                                                                \
+    } while (0)
+    if (nine) LAUNCH_BF(9, 0);
+    else if (abl == 1) LAUNCH_BF(6, 1);
+    else if (abl == 2) LAUNCH_BF(6, 2);
+    else if (abl == 4) LAUNCH_BF(6, 4);
+    else if (abl == 7) LAUNCH_BF(6, 7);
+    else LAUNCH_BF(6, 0);
+#undef LAUNCH_BF
+    return true;
+}
+
 template <int BM, int BN, int BK, int WM, int WN, int PRO>
 void launch_pro(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
@@ -797,6 +1072,15 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     const long M = (d.mode == 0) ? (long)d.F * d.Ho * d.Wo : (long)d.F * d.Hi * d.Wi;
     if (M <= 0 || d.N <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if ((g_variant & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 &&
+        d.Ho == d.Hi && d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
+        const bool nine = (g_variant & 0x2000) != 0;
+        const bool ok = d.N <= 64 ? try_launch_halo_bf16<64, 1>(d, M, s, nine) : try_launch_halo_bf16<128, 2>(d, M, s, nine);
+        if (ok) {
+            DAWN_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if ((g_variant & 0x800) && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.Hi &&
         d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool ok = d.N <= 64 ? try_launch_halo<64, 1>(d, M, s) : try_launch_halo<128, 2>(d, M, s);

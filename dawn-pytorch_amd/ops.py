@@ -93,7 +93,7 @@ class HipOps:
                   row_stats: Optional[Tuple[Tensor, Tensor]] = None, ch_ab: Optional[Tuple[Tensor, Tensor]] = None,
                   pro_act: int = 0, pro_add: Optional[Tensor] = None, res: Optional[Tensor] = None,
                   tr: Optional[Tuple[Tensor, Tensor, Tensor]] = None, out: Optional[Tensor] = None,
-                  gn_part: Optional[Tensor] = None) -> Tensor:
+                  gn_part: Optional[Tensor] = None, w_bf3: Optional[Tensor] = None) -> Tensor:
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
         rows_out = F * Ho * Wo
@@ -118,6 +118,7 @@ class HipOps:
             d.tr, d.ld_tr, d.tr_a, d.tr_b = _p(tr[0]), _ld(tr[0]), _p(tr[1]), _p(tr[2])
         d.out, d.ld_out = _p(out), _ld(out)
         d.gn_part = _p(gn_part)
+        d.w_bf3 = _p(w_bf3)
         if self.prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()

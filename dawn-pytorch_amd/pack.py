@@ -25,6 +25,20 @@ def pack_kn(w_kn: Tensor) -> Tensor:
     return w_kn.float().reshape(K // 4, 4, N).permute(0, 2, 1).contiguous()
 
 
+def pack_bf3(w_kn: Tensor) -> Tensor:
+    """(K, N) fp32 -> [K/16][3][2][N][8] int16: the exact three-way bf16 split w = w1 + w2 + w3 (round-to-nearest
+    -even at every level; residuals are exact in fp32) consumed by the split-operand bf16-MFMA 3x3 kernel."""
+    K, N = w_kn.shape
+    assert K % 16 == 0, K
+    w = w_kn.float()
+    w1 = w.to(torch.bfloat16)
+    r1 = w - w1.float()
+    w2 = r1.to(torch.bfloat16)
+    w3 = (r1 - w2.float()).to(torch.bfloat16)
+    planes = torch.stack((w1, w2, w3), 0).view(torch.int16)            # (3, K, N)
+    return planes.reshape(3, K // 16, 2, 8, N).permute(1, 0, 2, 4, 3).contiguous()
+
+
 def unpack_kn(wp: Tensor) -> Tensor:
     K4, N, _ = wp.shape
     return wp.permute(0, 2, 1).reshape(K4 * 4, N)
@@ -80,6 +94,8 @@ class PackedResBlock:
     be2: Tensor
     wr: Optional[Tensor] = None
     br: Optional[Tensor] = None
+    w1s: Optional[Tensor] = None          # pack_bf3 images of w1 / w2 (split-operand bf16 MFMA path)
+    w2s: Optional[Tensor] = None
     conditioned: bool = False
     cond_index: int = -1
     film_off: int = 0
@@ -196,6 +212,9 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
             g1=dev(g(p + "block1.norm.weight")), be1=dev(g(p + "block1.norm.bias")),
             w2=dev(pack_kn(conv_w_kn(g(p + "block2.proj.weight")))), b2=dev(g(p + "block2.proj.bias")),
             g2=dev(g(p + "block2.norm.weight")), be2=dev(g(p + "block2.norm.bias")))
+        if Cin % 16 == 0 and Co % 16 == 0:
+            rb.w1s = pack_bf3(conv_w_kn(w1)).to(device)
+            rb.w2s = pack_bf3(conv_w_kn(g(p + "block2.proj.weight"))).to(device)
         if has(p + "res_conv.weight"):
             rb.wr = dev(pack_kn(conv_w_kn(g(p + "res_conv.weight"))))
             rb.br = dev(g(p + "res_conv.bias"))

@@ -105,7 +105,7 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     def conv1_and_stats():
         # GroupNorm partial sums come out of the conv epilogue (no separate statistics pass over c)
         part = ops.conv_gn_part(F * H * W, Co, x)
-        c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, gn_part=part, **g)
+        c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, gn_part=part, w_bf3=rb.w1s, **g)
         return c, ops.gn_coeffs(c, rb.g1, rb.be1, film, total_rows, part=part)
 
     if rb.conditioned:
@@ -120,7 +120,7 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     # ~35 % of its MFMA rate (profiles/r1_b_conv_shapes.txt) -- far more than the extra 3 x C x 4 B per pixel.
     h1 = ops.gn_apply_res(c1, ab1[0], ab1[1], hcond)
     part2 = ops.conv_gn_part(F * H * W, Co, x)
-    c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, **g)
+    c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, w_bf3=rb.w2s, **g)
     a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows, part=part2)
     if rb.wr is not None:
         return ops.conv_gemm(x, rb.wr, Co, in1=x2, bias=rb.br, tr=(c2, a2, b2), **g)

@@ -36,7 +36,7 @@ def test_conv_desc_layout_matches_c():
         if not decl:
             continue
         is_ptr = "*" in decl
-        for name in re.sub(r"^(const\s+)?(float|int|double)\s*\*?", "", decl).split(","):
+        for name in re.sub(r"^(const\s+)?(float|int|double|void)\s*\*?", "", decl).split(","):
             fields.append((name.strip().lstrip("*").strip(), 8 if is_ptr else 4))
     off, expect = 0, {}
     for name, size in fields:

@@ -110,9 +110,16 @@ def test_conv_gemm(hip, ref, case):
     if ex.get("tr"):
         kw["tr"] = (rnd(F * Ho * Wo, N, seed=9), rnd(N, seed=10) * 0.3 + 1.0, rnd(N, seed=11) * 0.3)
     want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
-    for variant in (0, 7, 141, 269, 525, 1037, 13, 2061):   # every tile configuration; 2061 = shipped policy (left active)
+    for variant in (0, 7, 141, 269, 525, 1037, 13, 2061):   # every fp32-MFMA tile configuration
         hip.L.dawn_conv_set_variant(variant)
         _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
+    if k == 3 and C0 % 16 == 0 and C1 % 16 == 0:
+        from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+        kw["w_bf3"] = pack_bf3(unpack_kn(w)).cuda()
+        for variant in (14349, 6157):                         # split-operand bf16 MFMA: 9 terms, 6 terms
+            hip.L.dawn_conv_set_variant(variant)
+            _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
+    hip.L.dawn_conv_set_variant(6157)                         # shipped policy (left active)
 
 
 def _conv_case(hip, name, in0, in1, w, N, kw, want):
@@ -129,15 +136,45 @@ def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
     rows = F * H * W
     x, w, b = rnd(rows, C0, seed=1), packw(9 * C0, N, seed=2), rnd(N, seed=3)
     gamma, beta = rnd(N, seed=4) * 0.2 + 1, rnd(N, seed=5) * 0.2
-    for variant in (5, 525, 13, 2061):
+    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+    ws = pack_bf3(unpack_kn(w)).cuda() if C0 % 16 == 0 else None
+    for variant in (5, 525, 13, 2061, 6157):
         hip.L.dawn_conv_set_variant(variant)
         xg = x.cuda()
         part = hip.conv_gn_part(rows, N, xg)
-        c = hip.conv_gemm(xg, w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=b.cuda(), gn_part=part)
+        c = hip.conv_gemm(xg, w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=b.cuda(), gn_part=part, w_bf3=ws)
         a1, b1 = hip.gn_coeffs(c, gamma.cuda(), beta.cuda(), None, rows, part=part)
         a2, b2 = hip.gn_coeffs(c, gamma.cuda(), beta.cuda(), None, rows)
         check(f"conv_gn_stats/a_{C0}_{N}_v{variant}", a1, a2, 1e-5)
         check(f"conv_gn_stats/b_{C0}_{N}_v{variant}", b1, b2, 1e-5)
+
+
+def test_conv_bf16_split_is_fp32_accurate(hip, ref):
+    """The split-operand bf16-MFMA 3x3 path is an fp32 computation: against an fp64 reference its error is
+    no larger than the fp32-MFMA path's (both are dominated by fp32 accumulation rounding)."""
+    import torch.nn.functional as F_
+    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+    F, H, W, Cc, N = 4, 32, 32, 128, 128
+    rows = F * H * W
+    x, w = rnd(rows, Cc, seed=1), packw(9 * Cc, N, seed=2)
+    # a few large-magnitude and tiny entries: the split must stay exact across the exponent range
+    x[::7, ::5] *= 1.0e4
+    x[::11, ::3] *= 1.0e-6
+    wkn = unpack_kn(w).double()                                              # (9*Cc, N), k = tap*Cc + c
+    w4 = wkn.reshape(3, 3, Cc, N).permute(3, 2, 0, 1)
+    want = F_.conv2d(x.double().reshape(F, H, W, Cc).permute(0, 3, 1, 2), w4, padding=1).permute(0, 2, 3, 1).reshape(rows, N)
+    errs = {}
+    for variant, ws in ((2061, None), (6157, pack_bf3(unpack_kn(w)).cuda()), (14349, pack_bf3(unpack_kn(w)).cuda())):
+        hip.L.dawn_conv_set_variant(variant)
+        got = hip.conv_gemm(x.cuda(), w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, w_bf3=ws)
+        torch.cuda.synchronize()
+        errs[variant] = float((got.cpu().double() - want).abs().max() / want.abs().max())
+    with open(LOG, "a") as f:
+        f.write(json.dumps({"op": "conv_bf16_split/rel_err_vs_fp64", "fp32_mfma": errs[2061], "bf16x6": errs[6157],
+                            "bf16x9": errs[14349]}) + "\n")
+    hip.L.dawn_conv_set_variant(6157)
+    assert errs[6157] <= 2.0 * errs[2061] + 1e-7, errs
+    assert errs[14349] <= 2.0 * errs[2061] + 1e-7, errs
 
 
 def test_conv_gemm_transposed(hip, ref):

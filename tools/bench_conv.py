@@ -7,7 +7,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dawn_pytorch_amd.ops import HipOps
-from dawn_pytorch_amd.pack import pack_kn
+from dawn_pytorch_amd.pack import pack_kn, pack_bf3
 
 CASES = {   # name: (F, H, W, C0, C1, N, k, stride, pad, rowstats)
     "l0_3x3": (200, 64, 64, 64, 0, 64, 3, 1, 1, False),
@@ -33,12 +33,17 @@ for variant, name in itertools.product([int(v) for v in a.variants.split(",")], 
     ops.L.dawn_conv_set_variant(variant)
     F, H, W, C0, C1, N, k, st, pad, rs = CASES[name]
     rows = F * H * W
+    torch.manual_seed(0)
     x0 = torch.randn(rows, C0, device=dev)
     x1 = torch.randn(rows, C1, device=dev) if C1 else None
     K = k * k * (C0 + C1)
-    w = pack_kn(torch.randn(K, N) * K ** -0.5).to(dev)
+    torch.manual_seed(0)
+    w_kn = torch.randn(K, N) * K ** -0.5
+    w = pack_kn(w_kn).to(dev)
     b = torch.randn(N, device=dev)
     kw = dict(F=F, Hi=H, Wi=W, KH=k, KW=k, stride=st, pad=pad, in1=x1, bias=b)
+    if k == 3 and (variant & 0x1000):
+        kw["w_bf3"] = pack_bf3(w_kn).to(dev)
     if rs:
         kw["row_stats"] = (torch.randn(rows, device=dev) * 0.1, torch.rand(rows, device=dev) + 0.5)
     out = torch.empty(rows, N, device=dev)
@@ -52,5 +57,10 @@ for variant, name in itertools.product([int(v) for v in a.variants.split(",")], 
     torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / a.iters
     fl = 2.0 * rows * N * K
+    ref_key = (name,)
+    refs = globals().setdefault("_refs", {})
+    diff = float((out - refs[ref_key]).abs().max()) if ref_key in refs else 0.0
+    refs.setdefault(ref_key, out.clone())
+    print(f"maxdiff_vs_first_variant={diff:.2e} ", end="")
     print(f"v{variant} {name:12s} M={rows} N={N} K={K}: {us:9.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  "
           f"({(rows * (C0 + C1) + rows * N) * 4 / us / 1e6:6.2f} TB/s min-traffic)")
