@@ -26,9 +26,11 @@ namespace {
 // K >= 2304 and N >= 256), 0x80 force BK=32 on that path, 0x100 its 3-stage counted-vmcnt pipeline (no gain:
 // the loop is bound by the per-CU fetch rate, not by load latency), 0x800 LDS-halo kernel for prologue-free
 // 3x3/s1/p1 convs whose tile geometry fits (+5..19 %, profiles/r1_l_conv_halo.txt), 0x1000 split-operand bf16
-// MFMA version of that kernel when the caller supplies w_bf3 (6 cross terms; 0x2000: all 9), 0x10/0x20 and
-// bits 16-18 perf ablations.
-static int g_variant = 0x180D;
+// MFMA version of that kernel when the caller supplies w_bf3 (6 cross terms; 0x2000: all 9), 0x4000 its second
+// generation (conv3x3_bf16_v2_kernel: +5..20 %, profiles/r1_n_conv_bf16.txt), 0x10/0x20 and bits 16-19 perf
+// ablations / the s_memtime build.
+static int g_variant = 0x580D;
+__device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
 
 struct RowInfo {
     long rowoff;  // (f*Hi + yb)*Wi + xb : input pixel index of tap (0,0) (may point outside; bounds via yb/xb)
@@ -969,6 +971,353 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_
     }
 }
 
+// Second-generation split-operand kernel for the large-M levels: BM = 256 output pixels x BN = 64*WN channels,
+// 64*4*WN threads (every wave owns a 64 x 64 tile).  Differences from conv3x3_halo_bf16_kernel:
+//  * the fp32 patch of the NEXT channel chunk is prefetched into registers during stages 0-1 of the current chunk,
+//    split into its three bf16 pieces BETWEEN the MFMAs of stages 1-2 (VALU work hidden in the matrix pipe's
+//    shadow) and only written to the LDS planes at the chunk boundary -- no raw LDS buffer, no split pass;
+//  * the weights are staged one KERNEL ROW (3 taps) at a time, double-buffered: one barrier per 72 MFMAs per wave
+//    instead of one per 24, and every load has a whole stage (>= 2300 MFMA cycles) to land;
+//  * all loads are buffer instructions (SGPR descriptor + precomputed 32-bit lane offsets + scalar chunk offset):
+//    padding and out-of-tile lanes are out-of-range offsets that return 0, so issuing a stage's loads is ~20
+//    instructions with no branches and no 64-bit address arithmetic.
+// (measured with the s_memtime build, tools/conv_phase_timing.py: per chunk the first version spent 3 x 1650 cycles
+//  issuing loads and 2400 in the split pass next to 3 x 2300 cycles of MFMA.)
+template <int WN, int NT, int ABL>
+__global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_conv_desc d, const int xcd_remap,
+                                                                    const int TR, const int nf, const int P16) {
+#if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; buffer-resource builtins are device-only)
+    constexpr int NTHR = 256 * WN, BM = 256, BN = 64 * WN;
+    constexpr int TM = 2, TN = 2;
+    constexpr int MAXQ = (28 * 16 * 4 + NTHR - 1) / NTHR;      // patch quads per thread (P16 <= 448)
+    constexpr int L0 = (MAXQ + 1) / 2;                         // quads loaded in stage 0 (the rest in stage 1)
+    constexpr int SB = 18 * BN * 16;                           // bytes of one weight stage (3 taps x 3 planes x 2 halves)
+    constexpr int NBI = SB / 1024;                             // DMA wave-instructions per stage
+    constexpr int NW = 4 * WN;
+    constexpr int NBJ = (NBI + NW - 1) / NW;
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int HPS = P16 * 16 + 128;
+    const size_t DBG_OFF = (size_t)6 * HPS + 2 * SB;           // instrumented build only: 64 stamps
+    unsigned char* planes = smem_b;                            // [3][2][HPS]
+    unsigned char* Bs = smem_b + (size_t)6 * HPS;              // [2][3 taps][3 planes][2 halves][BN][16 B]
+
+    int tix = 0;
+#define TSTAMP()                                                                                       \
+    do {                                                                                               \
+        if ((ABL & 8) && threadIdx.x == 0 && tix < 64)                                                 \
+            reinterpret_cast<unsigned long long*>(smem_b + DBG_OFF)[tix++] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int H = d.Hi, W = d.Wi, PW = W + 2, PP = (TR + 2) * PW;
+    const int Cin = d.C0 + d.C1;
+    const int nC = Cin / 16;
+    const int nNt = d.N / BN;
+    int bid = blockIdx.x;
+    if (xcd_remap) {
+        const int nwg = gridDim.x;
+        const int xcd = bid & 7, idx = bid >> 3;
+        const int q = nwg >> 3, r = nwg & 7;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int mt = bid / nNt, nt = bid - mt * nNt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+    const int f0 = (int)(m0 / ((long)H * W));
+    const int y0 = (int)((m0 - (long)f0 * H * W) / W);
+    TSTAMP();   // 0: start
+
+    // ---- buffer descriptors: the patch window of each source (first pixel = row y0-1 of frame f0), the weights
+    const long pb = ((long)f0 * H + y0 - 1) * W;
+    const int ext = nf * H * W + (nf > 1 ? 2 * W : (TR + 2) * W - H * W);    // pixels spanned by the window
+    const __amdgpu_buffer_rsrc_t rs0 =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + pb * d.ld0), 0, ext * d.ld0 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((d.in1 ? d.in1 : d.in0) + pb * (d.in1 ? d.ld1 : d.ld0)), 0, ext * (d.in1 ? d.ld1 : d.ld0) * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, 9 * nC * 6 * d.N * 16, 0x00020000);
+
+    // ---- this thread's patch quads: q = tid + NTHR*i -> (pos = q>>2, 4-channel slot = q&3); rel = window pixel
+    const int nq = P16 * 4;
+    const float rPP = 1.0f / (float)PP, rPW = 1.0f / (float)PW, rTW = 1.0f / (float)(TR * W), rW = 1.0f / (float)W;
+    int rel[MAXQ];
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) {
+        const int q = tid + NTHR * i;
+        const int pos = q >> 2;
+        int r = -1;
+        if (q < nq && pos < nf * PP) {
+            const int fi = (int)(((float)pos + 0.5f) * rPP);
+            const int rem = pos - fi * PP;
+            const int pyy = (int)(((float)rem + 0.5f) * rPW), pxx = rem - pyy * PW;
+            const int y = y0 + pyy - 1, x = pxx - 1;
+            if (y >= 0 && y < H && x >= 0 && x < W) r = fi * H * W + pyy * W + x;
+        }
+        rel[i] = r;
+    }
+    int pc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        const int fi = (int)(((float)r + 0.5f) * rTW);
+        const int rem = r - fi * TR * W;
+        const int ty = (int)(((float)rem + 0.5f) * rW), x = rem - ty * W;
+        pc[i] = fi * PP + (ty + 1) * PW + (x + 1);
+    }
+    // weight DMA lane offsets (bytes) within a (chunk cc, kernel row ky) stage
+    unsigned voffB[NBJ];
+#pragma unroll
+    for (int j = 0; j < NBJ; ++j) {
+        const int q = j * NW + wave;
+        const int idx = q * 64 + lane;
+        const int tp = idx / (6 * BN);
+        const int rem = idx - tp * (6 * BN);
+        const int ph = rem / BN, n = rem - ph * BN;
+        voffB[j] = q < NBI ? (unsigned)(((tp * nC * 6 + ph) * d.N + n0 + n) * 16) : OOB;
+    }
+
+    f32x4 araw[MAXQ];
+    uint2 ap[MAXQ][3];
+    auto loadA = [&](int cc, int i) {
+        const int cbase = cc * 16;
+        const bool src1 = cbase >= d.C0;
+        const int ldb = (src1 ? d.ld1 : d.ld0) * 4;
+        const int soff = (src1 ? cbase - d.C0 : cbase) * 4;
+        const unsigned voff = rel[i] < 0 ? OOB : (unsigned)(rel[i] * ldb + (tid & 3) * 16);
+        typedef int i32x4 __attribute__((ext_vector_type(4)));
+        const i32x4 v = src1 ? __builtin_amdgcn_raw_buffer_load_b128(rs1, voff, soff, 0)
+                             : __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, soff, 0);
+        araw[i] = __builtin_bit_cast(f32x4, v);
+    };
+    auto convA = [&](int i) { split3(araw[i], ap[i][0], ap[i][1], ap[i][2]); };
+    auto writeA = [&]() {
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int q = tid + NTHR * i;
+            if (q < nq) {
+                const int pos = q >> 2, slot = q & 3;
+                unsigned char* dst = planes + (size_t)(slot >> 1) * HPS + pos * 16 + (slot & 1) * 8;
+                *reinterpret_cast<uint2*>(dst) = ap[i][0];
+                *reinterpret_cast<uint2*>(dst + 2 * HPS) = ap[i][1];
+                *reinterpret_cast<uint2*>(dst + 4 * HPS) = ap[i][2];
+            }
+        }
+    };
+    auto issueB = [&](int cc, int ky, int buf) {
+        const int soff = (ky * 3 * nC + cc) * 6 * d.N * 16;
+#pragma unroll
+        for (int j = 0; j < NBJ; ++j) {
+            const int q = j * NW + wave;
+            if (q < NBI)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                    rsw, (__attribute__((address_space(3))) void*)(Bs + (size_t)buf * SB + q * 1024), 16, voffB[j], soff, 0, 0);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    TSTAMP();   // 1: index math done
+    issueB(0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) loadA(0, i);
+#pragma unroll
+    for (int i = 0; i < MAXQ; ++i) convA(i);
+    writeA();
+    TSTAMP();   // 2: first patch landed + split
+    int bufB = 0;
+    for (int cc = 0; cc < nC; ++cc) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                   // planes(cc) written, weight stage (cc, 0) landed
+        TSTAMP();   // chunk top
+        const bool more = cc + 1 < nC && !(ABL & 4);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+            // prefetch: the next weight stage, then (stages 0, 1) the next chunk's patch quads
+            {
+                int nky = ky + 1, ncc = cc;
+                if (nky == 3) { nky = 0; ncc = cc + 1; }
+                if (ncc < nC && !(ABL & 2)) issueB(ncc, nky, bufB ^ 1);
+            }
+            if (more) {
+#pragma unroll
+                for (int i = 0; i < MAXQ; ++i)
+                    if ((ky == 0 && i < L0) || (ky == 1 && i >= L0)) loadA(cc + 1, i);
+            }
+            TSTAMP();   // stage: loads issued
+            const unsigned char* Bb = Bs + (size_t)bufB * SB;
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int toff = (ky - 1) * PW + (kx - 1);
+                bf16x8 fa[TM][3], fb[TN][3];
+                // fragment reads in the order the terms consume them (a3,b1 | a1,b3 | a2,b2): the LDS returns in
+                // order, so the first MFMAs start after 4 of the 12 reads (counted lgkmcnt) while the rest stream in
+                constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
+#pragma unroll
+                for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+                        fa[i][RA[g]] = *reinterpret_cast<const bf16x8*>(planes + (size_t)(RA[g] * 2 + half) * HPS + (pc[i] + toff) * 16);
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        fb[j][RB[g]] = *reinterpret_cast<const bf16x8*>(
+                            Bb + ((size_t)((kx * 6 + RB[g] * 2 + half) * BN + wn * 64 + j * 32 + l31)) * 16);
+                }
+                constexpr int PA9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+                constexpr int PB9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+                for (int t = 9 - NT; t < 9; ++t)
+#pragma unroll
+                    for (int i = 0; i < TM; ++i)
+#pragma unroll
+                        for (int j = 0; j < TN; ++j)
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA9[t]], fb[j][PB9[t]], acc[i][j], 0, 0, 0);
+                // split the quads that landed during the previous stage, in the shadow of the MFMAs above
+                if (more && ky > 0) {
+#pragma unroll
+                    for (int i = 0; i < MAXQ; ++i) {
+                        const bool mine = ky == 1 ? i < L0 : i >= L0;
+                        const int ord = ky == 1 ? i : i - L0;
+                        if (mine && ord % 3 == kx) convA(i);
+                    }
+                }
+                if (NT == 6) {
+                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);       // the 12 fragment reads first
+#pragma unroll
+                    for (int t = 0; t < 24; ++t) {
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // then MFMA, 2 VALU (split), MFMA, ...
+                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+                    }
+                }
+            }
+            TSTAMP();   // stage: MFMAs issued
+            if (ky < 2 && !(ABL & 1)) {
+                // (the register operands pin the split of these quads behind the wait)
+                if (MAXQ == 7)
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                                 : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]), "+v"(araw[4]), "+v"(araw[5]),
+                                   "+v"(araw[6])
+                                 :: "memory");
+                else
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                                 : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[MAXQ - 1])
+                                 :: "memory");
+                __builtin_amdgcn_s_barrier();           // next weight stage landed; this one may be overwritten
+            }
+            TSTAMP();   // stage: barrier passed
+            bufB ^= 1;
+        }
+        if (more) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // every wave is done reading planes(cc)
+            TSTAMP();   // planes-free barrier passed
+            writeA();
+            TSTAMP();   // planes written
+        }
+    }
+    TSTAMP();   // main loop done
+
+    // ---- epilogue: bias, store, GroupNorm partial sums (8-lane shuffle reduction, then one LDS atomic per group)
+    float gs[TN], gss[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gss[j] = 0.f; }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = n0 + wn * 64 + j * 32 + l31;
+                float v = acc[i][j][r];
+                if (d.bias) v += d.bias[n];
+                if (d.res) v += d.res[m * d.ld_res + n];
+                if (d.tr) v += dawn_silu(d.tr[m * d.ld_tr + n] * d.tr_a[n] + d.tr_b[n]);
+                d.out[m * d.ld_out + n] = v;
+                gs[j] += v;
+                gss[j] += v * v;
+            }
+        }
+    }
+    TSTAMP();   // stores issued
+    if (d.gn_part) {
+        __syncthreads();
+        double* red = reinterpret_cast<double*>(smem_b);
+        if (tid < 16) red[tid] = 0.0;
+        __syncthreads();
+        const int cpg = d.N >> 3;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + wn * 64 + j * 32 + l31;
+            double a = (double)gs[j], b2 = (double)gss[j];
+            a += __shfl_xor(a, 32, 64);
+            b2 += __shfl_xor(b2, 32, 64);
+#pragma unroll
+            for (int o = 1; o < 8; o <<= 1) {           // N % 64 == 0: the 8 aligned lanes share a group
+                a += __shfl_xor(a, o, 64);
+                b2 += __shfl_xor(b2, o, 64);
+            }
+            if ((lane & 39) == 0) {
+                atomicAdd(&red[2 * (n / cpg)], a);
+                atomicAdd(&red[2 * (n / cpg) + 1], b2);
+            }
+        }
+        __syncthreads();
+        if (tid < 16) d.gn_part[(long)blockIdx.x * 16 + tid] = red[tid];
+    }
+    TSTAMP();   // end
+#undef TSTAMP
+    if ((ABL & 8) && threadIdx.x == 0 && blockIdx.x < 4096)
+        for (int i = 0; i < 64; ++i)
+            g_dbg[(size_t)blockIdx.x * 64 + i] = i < tix ? reinterpret_cast<unsigned long long*>(smem_b + DBG_OFF)[i] : 0ull;
+#endif
+}
+
+template <int WN>
+bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nine) {
+    constexpr int BM = 256, BN = 64 * WN;
+    const int H = d.Hi, W = d.Wi;
+    if (M % BM != 0 || W > BM || BM % W != 0 || d.C0 % 16 != 0 || d.C1 % 16 != 0 || d.N % BN != 0) return false;
+    if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (long)9 * (d.C0 + d.C1) * d.N * 6 >= (1L << 31)) return false;
+    int TR = BM / W, nf = 1;
+    if (TR <= H) { if (H % TR != 0) return false; }
+    else { if (TR % H != 0) return false; nf = TR / H; TR = H; if (d.F % nf != 0) return false; }
+    const int P = nf * (TR + 2) * (W + 2);
+    const int P16 = (P + 15) / 16 * 16;
+    if (P16 > 448) return false;
+    const bool timing = ((g_variant >> 16) & 15) == 8;
+    const size_t lds = (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 18 * BN * 16 + (timing ? 512 : 0);
+    if (lds > 160 * 1024) return false;
+    const int nwg = (int)(M / BM) * (d.N / BN);
+    const int remap = ((g_variant & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
+#define LAUNCH_V2(NTV, ABLV)                                                                                          \
+    do {                                                                                                              \
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_v2_kernel<WN, NTV, ABLV>,                                 \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
+        hipLaunchKernelGGL((conv3x3_bf16_v2_kernel<WN, NTV, ABLV>), dim3(nwg), dim3(256 * WN), lds, s, d, remap, TR, nf, \
+                           P16);                                                                                      \
+    } while (0)
+    const int abl = (g_variant >> 16) & 15;
+    if (nine) LAUNCH_V2(9, 0);
+    else if (timing) LAUNCH_V2(6, 8);
+    else if (abl == 1) LAUNCH_V2(6, 1);
+    else if (abl == 2) LAUNCH_V2(6, 2);
+    else if (abl == 4) LAUNCH_V2(6, 4);
+    else if (abl == 7) LAUNCH_V2(6, 7);
+    else LAUNCH_V2(6, 0);
+#undef LAUNCH_V2
+    return true;
+}
+
 template <int BN, int WN>
 bool try_launch_halo_bf16(const dawn_conv_desc& d, long M, hipStream_t s, bool nine) {
     constexpr int BM = 64 * (4 / WN);
@@ -1051,6 +1400,9 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 }  // namespace
 
 extern "C" void dawn_conv_set_variant(int v) { g_variant = v; }
+extern "C" int dawn_conv_set_debug(void* p) {
+    return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &p, sizeof(p));
+}
 
 extern "C" int dawn_conv_gemm_nblocks(long M, int N) {
     if (N <= 64) return dawn_cdiv(M, 128);   // upper bound (the 256-row tile variants launch fewer blocks; the
@@ -1075,7 +1427,11 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     if ((g_variant & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 &&
         d.Ho == d.Hi && d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool nine = (g_variant & 0x2000) != 0;
-        const bool ok = d.N <= 64 ? try_launch_halo_bf16<64, 1>(d, M, s, nine) : try_launch_halo_bf16<128, 2>(d, M, s, nine);
+        bool ok = false;
+        if (g_variant & 0x4000) {           // v2 structure (row-of-taps weight stages, register-prefetched patch)
+            ok = d.N <= 64 ? try_launch_bf16_v2<1>(d, M, s, nine) : try_launch_bf16_v2<2>(d, M, s, nine);
+        }
+        if (!ok) ok = d.N <= 64 ? try_launch_halo_bf16<64, 1>(d, M, s, nine) : try_launch_halo_bf16<128, 2>(d, M, s, nine);
         if (ok) {
             DAWN_LAUNCH_CHECK();
             return 0;

@@ -116,10 +116,10 @@ def test_conv_gemm(hip, ref, case):
     if k == 3 and C0 % 16 == 0 and C1 % 16 == 0:
         from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
         kw["w_bf3"] = pack_bf3(unpack_kn(w)).cuda()
-        for variant in (14349, 6157):                         # split-operand bf16 MFMA: 9 terms, 6 terms
+        for variant in (14349, 30733, 6157, 22541):           # split-operand bf16 MFMA: 9 / 6 terms, v1 / v2 kernels
             hip.L.dawn_conv_set_variant(variant)
             _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
-    hip.L.dawn_conv_set_variant(6157)                         # shipped policy (left active)
+    hip.L.dawn_conv_set_variant(22541)                        # shipped policy (left active)
 
 
 def _conv_case(hip, name, in0, in1, w, N, kw, want):
@@ -138,7 +138,7 @@ def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
     gamma, beta = rnd(N, seed=4) * 0.2 + 1, rnd(N, seed=5) * 0.2
     from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
     ws = pack_bf3(unpack_kn(w)).cuda() if C0 % 16 == 0 else None
-    for variant in (5, 525, 13, 2061, 6157):
+    for variant in (5, 525, 13, 2061, 6157, 22541):
         hip.L.dawn_conv_set_variant(variant)
         xg = x.cuda()
         part = hip.conv_gn_part(rows, N, xg)
@@ -164,16 +164,18 @@ def test_conv_bf16_split_is_fp32_accurate(hip, ref):
     w4 = wkn.reshape(3, 3, Cc, N).permute(3, 2, 0, 1)
     want = F_.conv2d(x.double().reshape(F, H, W, Cc).permute(0, 3, 1, 2), w4, padding=1).permute(0, 2, 3, 1).reshape(rows, N)
     errs = {}
-    for variant, ws in ((2061, None), (6157, pack_bf3(unpack_kn(w)).cuda()), (14349, pack_bf3(unpack_kn(w)).cuda())):
+    for variant, ws in ((2061, None), (6157, pack_bf3(unpack_kn(w)).cuda()), (14349, pack_bf3(unpack_kn(w)).cuda()),
+                        (22541, pack_bf3(unpack_kn(w)).cuda())):
         hip.L.dawn_conv_set_variant(variant)
         got = hip.conv_gemm(x.cuda(), w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, w_bf3=ws)
         torch.cuda.synchronize()
         errs[variant] = float((got.cpu().double() - want).abs().max() / want.abs().max())
     with open(LOG, "a") as f:
         f.write(json.dumps({"op": "conv_bf16_split/rel_err_vs_fp64", "fp32_mfma": errs[2061], "bf16x6": errs[6157],
-                            "bf16x9": errs[14349]}) + "\n")
-    hip.L.dawn_conv_set_variant(6157)
+                            "bf16x9": errs[14349], "bf16x6_v2": errs[22541]}) + "\n")
+    hip.L.dawn_conv_set_variant(22541)
     assert errs[6157] <= 2.0 * errs[2061] + 1e-7, errs
+    assert errs[22541] <= 2.0 * errs[2061] + 1e-7, errs
     assert errs[14349] <= 2.0 * errs[2061] + 1e-7, errs
 
 

@@ -12,6 +12,8 @@ from dawn_pytorch_amd.pack import pack_kn, pack_bf3
 CASES = {   # name: (F, H, W, C0, C1, N, k, stride, pad, rowstats)
     "l0_3x3": (200, 64, 64, 64, 0, 64, 3, 1, 1, False),
     "l0_3x3_cat": (200, 64, 64, 64, 64, 64, 3, 1, 1, False),
+    "l0_3x3_k2304": (200, 64, 64, 128, 128, 64, 3, 1, 1, False),
+    "l0_3x3_k288": (200, 64, 64, 32, 0, 64, 3, 1, 1, False),
     "l1_3x3": (200, 32, 32, 128, 0, 128, 3, 1, 1, False),
     "l2_3x3": (200, 16, 16, 256, 0, 256, 3, 1, 1, False),
     "l3_3x3": (200, 8, 8, 512, 0, 512, 3, 1, 1, False),
@@ -25,11 +27,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default=",".join(CASES))
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--variants", default="7")
+ap.add_argument("--stagger", default="0")
 a = ap.parse_args()
 ops = HipOps()
 dev = "cuda"
 import itertools
-for variant, name in itertools.product([int(v) for v in a.variants.split(",")], a.cases.split(",")):
+for variant, name, stg in itertools.product([int(v) for v in a.variants.split(",")], a.cases.split(","), [int(v, 0) for v in a.stagger.split(",")]):
     ops.L.dawn_conv_set_variant(variant)
     F, H, W, C0, C1, N, k, st, pad, rs = CASES[name]
     rows = F * H * W
@@ -62,5 +65,5 @@ for variant, name in itertools.product([int(v) for v in a.variants.split(",")], 
     diff = float((out - refs[ref_key]).abs().max()) if ref_key in refs else 0.0
     refs.setdefault(ref_key, out.clone())
     print(f"maxdiff_vs_first_variant={diff:.2e} ", end="")
-    print(f"v{variant} {name:12s} M={rows} N={N} K={K}: {us:9.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  "
+    print(f"v{variant} stg={stg:#x} {name:12s} M={rows} N={N} K={K}: {us:9.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  "
           f"({(rows * (C0 + C1) + rows * N) * 4 / us / 1e6:6.2f} TB/s min-traffic)")
