@@ -1003,9 +1003,10 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
     unsigned char* Bs = smem_b + (size_t)6 * HPS;              // [2][3 taps][3 planes][2 halves][BN][16 B]
 
     int tix = 0;
+    bool tstamp_on = true;                                     // (stamps of chunks >= 2 are skipped: 64 slots)
 #define TSTAMP()                                                                                       \
     do {                                                                                               \
-        if ((ABL & 8) && threadIdx.x == 0 && tix < 64)                                                 \
+        if ((ABL & 8) && threadIdx.x == 0 && tix < 64 && tstamp_on)                                    \
             reinterpret_cast<unsigned long long*>(smem_b + DBG_OFF)[tix++] = __builtin_amdgcn_s_memtime(); \
     } while (0)
     const int tid = threadIdx.x;
@@ -1136,6 +1137,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
     TSTAMP();   // 2: first patch landed + split
     int bufB = 0;
     for (int cc = 0; cc < nC; ++cc) {
+        tstamp_on = cc < 2;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // planes(cc) written, weight stage (cc, 0) landed
         TSTAMP();   // chunk top
@@ -1180,7 +1182,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
                     for (int i = 0; i < TM; ++i)
 #pragma unroll
                         for (int j = 0; j < TN; ++j)
-                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i][PA9[t]], fb[j][PB9[t]], acc[i][j], 0, 0, 0);
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB9[t]], fa[i][PA9[t]], acc[i][j], 0, 0, 0);
                 // split the quads that landed during the previous stage, in the shadow of the MFMAs above
                 if (more && ky > 0) {
 #pragma unroll
@@ -1224,55 +1226,76 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
             TSTAMP();   // planes written
         }
     }
+    tstamp_on = true;
     TSTAMP();   // main loop done
 
-    // ---- epilogue: bias, store, GroupNorm partial sums (8-lane shuffle reduction, then one LDS atomic per group)
-    float gs[TN], gss[TN];
+    // ---- epilogue.  The products are accumulated TRANSPOSED (A = weights, B = pixels): lane = output pixel, registers
+    // 4g..4g+3 = channels 8g + 4*half + {0..3} of the 32-channel tile, so every store is a 16-byte row segment
+    // (16 dwordx4 stores per wave instead of 64 scalar ones) and the GroupNorm partial sums are in-register per
+    // 8-channel group until one cross-lane reduction at the end.
+    float gs[TN][4], gss[TN][4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gss[j] = 0.f; }
+    for (int j = 0; j < TN; ++j)
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
+        for (int g = 0; g < 4; ++g) { gs[j][g] = 0.f; gss[j][g] = 0.f; }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * 64 + j * 32 + l31;
-                float v = acc[i][j][r];
-                if (d.bias) v += d.bias[n];
-                if (d.res) v += d.res[m * d.ld_res + n];
-                if (d.tr) v += dawn_silu(d.tr[m * d.ld_tr + n] * d.tr_a[n] + d.tr_b[n]);
-                d.out[m * d.ld_out + n] = v;
-                gs[j] += v;
-                gss[j] += v * v;
+        for (int g = 0; g < 4; ++g) {
+            const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const long m = m0 + wm * 64 + i * 32 + l31;
+                f32x4 v = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + bv;
+                if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
+                if (d.tr) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(d.tr + m * d.ld_tr + n);
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(d.tr_a + n), tb = *reinterpret_cast<const f32x4*>(d.tr_b + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += dawn_silu(t4[e] * ta[e] + tb[e]);
+                }
+                *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n) = v;
+                gs[j][g] += (v.x + v.y) + (v.z + v.w);
+                gss[j][g] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
         }
     }
     TSTAMP();   // stores issued
     if (d.gn_part) {
+        // block reduction through LDS: fp32 per-lane partials (8 values each) -> fp64 from there on
         __syncthreads();
-        double* red = reinterpret_cast<double*>(smem_b);
-        if (tid < 16) red[tid] = 0.0;
+        float* pf = reinterpret_cast<float*>(smem_b);                        // [16 columns][NTHR]
+        double* pd = reinterpret_cast<double*>(smem_b + 16 * NTHR * 4);       // [16 columns][NTHR / 32]
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                pf[((j * 4 + g) * 2) * NTHR + tid] = gs[j][g];
+                pf[((j * 4 + g) * 2 + 1) * NTHR + tid] = gss[j][g];
+            }
         __syncthreads();
-        const int cpg = d.N >> 3;
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * 64 + j * 32 + l31;
-            double a = (double)gs[j], b2 = (double)gss[j];
-            a += __shfl_xor(a, 32, 64);
-            b2 += __shfl_xor(b2, 32, 64);
-#pragma unroll
-            for (int o = 1; o < 8; o <<= 1) {           // N % 64 == 0: the 8 aligned lanes share a group
-                a += __shfl_xor(a, o, 64);
-                b2 += __shfl_xor(b2, o, 64);
-            }
-            if ((lane & 39) == 0) {
-                atomicAdd(&red[2 * (n / cpg)], a);
-                atomicAdd(&red[2 * (n / cpg) + 1], b2);
-            }
+        constexpr int NP = NTHR / 32;
+        if (tid < 16 * NP) {
+            const int c = tid / NP, p = tid - c * NP;
+            double a = 0.0;
+#pragma unroll 8
+            for (int e = 0; e < 32; ++e) a += (double)pf[c * NTHR + p * 32 + e];
+            pd[c * NP + p] = a;
         }
         __syncthreads();
-        if (tid < 16) d.gn_part[(long)blockIdx.x * 16 + tid] = red[tid];
+        if (tid < 16) {
+            const int grp = tid >> 1, which = tid & 1;
+            const int cpg = d.N >> 3;
+            double a = 0.0;
+            for (int w = 0; w < NW; ++w)
+#pragma unroll
+                for (int jg = 0; jg < 8; ++jg)
+                    if ((n0 + (w % WN) * 64 + (jg >> 2) * 32 + 8 * (jg & 3)) / cpg == grp)
+                        a += pd[(jg * 2 + which) * NP + w * 2] + pd[(jg * 2 + which) * NP + w * 2 + 1];
+            d.gn_part[(long)blockIdx.x * 16 + tid] = a;
+        }
     }
     TSTAMP();   // end
 #undef TSTAMP
@@ -1287,7 +1310,9 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     constexpr int BM = 256, BN = 64 * WN;
     const int H = d.Hi, W = d.Wi;
     if (M % BM != 0 || W > BM || BM % W != 0 || d.C0 % 16 != 0 || d.C1 % 16 != 0 || d.N % BN != 0) return false;
-    if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (long)9 * (d.C0 + d.C1) * d.N * 6 >= (1L << 31)) return false;
+    if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) || (d.tr && (d.ld_tr & 3)) ||
+        (long)9 * (d.C0 + d.C1) * d.N * 6 >= (1L << 31))
+        return false;
     int TR = BM / W, nf = 1;
     if (TR <= H) { if (H % TR != 0) return false; }
     else { if (TR % H != 0) return false; nf = TR / H; TR = H; if (d.F % nf != 0) return false; }
