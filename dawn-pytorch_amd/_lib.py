@@ -36,6 +36,7 @@ class ConvDesc(C.Structure):
         ("out", c_f), ("ld_out", _i),
         ("gn_part", c_f),
         ("w_bf3", c_f),
+        ("gn_rows", C.POINTER(C.c_int)),
     ]
 
 

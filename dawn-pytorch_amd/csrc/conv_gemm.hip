@@ -30,6 +30,7 @@ namespace {
 // generation (conv3x3_bf16_v2_kernel: +5..20 %, profiles/r1_n_conv_bf16.txt), 0x10/0x20 and bits 16-19 perf
 // ablations / the s_memtime build.
 static int g_variant = 0x580D;
+static thread_local int g_last_nwg = 0;   // gridDim.x of the last launch (= rows of gn_part it writes)
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
 
 struct RowInfo {
@@ -727,6 +728,7 @@ bool try_launch_halo(const dawn_conv_desc& d, long M, hipStream_t s) {
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
+    g_last_nwg = nwg;
     hipLaunchKernelGGL((conv3x3_halo_kernel<BN, WN>), dim3(nwg), dim3(256), lds, s, d, remap, TR, nf, P16);
     return true;
 }
@@ -1332,6 +1334,7 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
                            P16);                                                                                      \
     } while (0)
     const int abl = (g_variant >> 16) & 15;
+    g_last_nwg = nwg;
     if (nine) LAUNCH_V2(9, 0);
     else if (timing) LAUNCH_V2(6, 8);
     else if (abl == 1) LAUNCH_V2(6, 1);
@@ -1366,6 +1369,7 @@ bool try_launch_halo_bf16(const dawn_conv_desc& d, long M, hipStream_t s, bool n
         hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, WN, NTV, ABLV>), dim3(nwg), dim3(256), lds, s, d, remap, TR, \
                            nf, P16);                                                                                \
     } while (0)
+    g_last_nwg = nwg;
     if (nine) LAUNCH_BF(9, 0);
     else if (abl == 1) LAUNCH_BF(6, 1);
     else if (abl == 2) LAUNCH_BF(6, 2);
@@ -1382,6 +1386,7 @@ void launch_pro(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int z = d.mode == 1 ? 4 : 1;
     const int nwg = nMt * nNt;
     const int remap = ((g_variant & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
+    g_last_nwg = nwg;
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, PRO>), dim3(nwg, 1, z), dim3(256), 0, s, d, remap);
 }
 
@@ -1390,6 +1395,7 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
     if (g_variant & 0x30) {   // perf ablations only (wrong results): 0x10 no re-staging, 0x20 also no barrier
         const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
         const int nwg = nMt * nNt;
+        g_last_nwg = nwg;
         if (g_variant & 0x20)
             hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, 0, 2>), dim3(nwg, 1, 1), dim3(256), 0, s, d, 0);
         else
@@ -1405,10 +1411,12 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
         if (BN == 64 && M >= 65536 && ((g_variant & 0x200) || (d.KH * d.KW > 1 && d.C0 + d.C1 <= 64 && !(g_variant & 0x400)))) {
             // 256 x 64 tile (weights amortised over 2x the rows): +7 % on the K=576 3x3 convs, not on 1x1 / K>=1152
             const int nwg2 = dawn_cdiv(M, 256);
+            g_last_nwg = nwg2;
             hipLaunchKernelGGL((conv_gemm_glds_kernel<64, 2, 16, 1>), dim3(nwg2, 1, d.mode == 1 ? 4 : 1), dim3(256), 0, s, d,
                                remap);
             return;
         }
+        g_last_nwg = nwg;
         if (((g_variant & 0x80) || deep) && d.C0 % 32 == 0 && d.C1 % 32 == 0)
             hipLaunchKernelGGL((conv_gemm_glds_kernel<BN, 2, 32>), grid, dim3(256), 0, s, d, remap);
         else if (g_variant & 0x100)
@@ -1458,6 +1466,7 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         }
         if (!ok) ok = d.N <= 64 ? try_launch_halo_bf16<64, 1>(d, M, s, nine) : try_launch_halo_bf16<128, 2>(d, M, s, nine);
         if (ok) {
+            if (d.gn_rows) *d.gn_rows = g_last_nwg;
             DAWN_LAUNCH_CHECK();
             return 0;
         }
@@ -1466,6 +1475,7 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool ok = d.N <= 64 ? try_launch_halo<64, 1>(d, M, s) : try_launch_halo<128, 2>(d, M, s);
         if (ok) {
+            if (d.gn_rows) *d.gn_rows = g_last_nwg;
             DAWN_LAUNCH_CHECK();
             return 0;
         }
@@ -1478,6 +1488,7 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         if (k32) launch<128, 128, 32, 2, 2>(d, M, s);
         else launch<128, 128, 16, 2, 2>(d, M, s);
     }
+    if (d.gn_rows) *d.gn_rows = g_last_nwg;
     DAWN_LAUNCH_CHECK();
     return 0;
 }

@@ -119,11 +119,16 @@ class HipOps:
         d.out, d.ld_out = _p(out), _ld(out)
         d.gn_part = _p(gn_part)
         d.w_bf3 = _p(w_bf3)
+        nrows = C.c_int(0)
+        if gn_part is not None:
+            d.gn_rows = C.pointer(nrows)
         if self.prof is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
             e1.record()
+            if gn_part is not None:
+                gn_part.dawn_rows = nrows.value
             rows_gemm = rows_out if mode == 0 else F * Hi * Wi * 4
             self.prof.append((2.0 * rows_gemm * N * KH * KW * (d.C0 + d.C1), e0, e1,
                               f"M={rows_gemm} N={N} K={KH * KW * (d.C0 + d.C1)} k={KH}x{KW} s={stride} mode={mode} "
@@ -131,12 +136,14 @@ class HipOps:
                               4.0 * (F * Hi * Wi * (d.C0 + d.C1) + rows_out * N + KH * KW * (d.C0 + d.C1) * N * (4 if mode else 1))))
             return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
+        if gn_part is not None:
+            gn_part.dawn_rows = nrows.value      # rows the launch wrote (the rest of the buffer is unused)
         return out
 
     # ------------------------------------------------------------------ GroupNorm / LayerNorm
     def conv_gn_part(self, rows_out: int, N: int, like: Tensor) -> Tensor:
         """Buffer for the GroupNorm partial sums a conv_gemm launch of this output shape emits (gn_part=...)."""
-        return torch.zeros(self.L.dawn_conv_gemm_nblocks(rows_out, N), 16, device=like.device, dtype=torch.float64)
+        return torch.empty(self.L.dawn_conv_gemm_nblocks(rows_out, N), 16, device=like.device, dtype=torch.float64)
 
     def gn_coeffs(self, x: Tensor, gamma: Tensor, beta: Tensor, film: Optional[Tuple[Tensor, Tensor]],
                   total_rows: int, eps: float = 1e-5, part: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
@@ -151,7 +158,7 @@ class HipOps:
             nblk = max(1, min(1024, (rows * (Cc // 4) + 255) // 256 // 8))
             part = self.empty(nblk, 16, like=x, dtype=torch.float64)
             check(self.L.dawn_gn_partial(_p(x), rows, Cc, _ld(x), _p(part), nblk, s), "dawn_gn_partial")
-        nblk = part.shape[0]
+        nblk = getattr(part, "dawn_rows", part.shape[0])    # rows written by the conv epilogue (or all of them)
         a = self.empty(Cc, like=x)
         b = self.empty(Cc, like=x)
         fs, fsh = (film if film is not None else (None, None))

@@ -54,6 +54,8 @@ typedef struct dawn_conv_desc {
     const void* w_bf3;                             /* optional (3x3/s1/p1 only): the same weights split exactly into three
                                                       bf16 planes w = w1+w2+w3, [K/16][3][2][N][8] (k = tap*(C0+C1)+c), for
                                                       the split-operand bf16-MFMA kernel; NULL = fp32 MFMA */
+    int* gn_rows;                                  /* optional HOST pointer: receives the number of gn_part rows this launch
+                                                      writes (= its thread-block count; <= dawn_conv_gemm_nblocks) */
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
 /* number of thread blocks (= rows of gn_part) dawn_conv_gemm will launch for an (M rows, N columns) output */
