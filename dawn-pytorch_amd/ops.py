@@ -132,7 +132,8 @@ class HipOps:
             rows_gemm = rows_out if mode == 0 else F * Hi * Wi * 4
             self.prof.append((2.0 * rows_gemm * N * KH * KW * (d.C0 + d.C1), e0, e1,
                               f"M={rows_gemm} N={N} K={KH * KW * (d.C0 + d.C1)} k={KH}x{KW} s={stride} mode={mode} "
-                              f"pro={'r' if row_stats else ''}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}",
+                              f"pro={'r' if row_stats else ''}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}"
+                              + (" split-bf16" if w_bf3 is not None else ""),
                               4.0 * (F * Hi * Wi * (d.C0 + d.C1) + rows_out * N + KH * KW * (d.C0 + d.C1) * N * (4 if mode else 1))))
             return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")

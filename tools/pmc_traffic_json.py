@@ -28,6 +28,12 @@ def main():
     n = sum(v[0] for k, v in fetch.items() if is_conv(k))
     f = sum(v[1] for k, v in fetch.items() if is_conv(k))
     w = sum(v[1] for k, v in write.items() if is_conv(k))
+    def per_class(pred):
+        nn = sum(v[0] for k, v in fetch.items() if pred(k))
+        if not nn:
+            return None
+        return (2.0 * sum(v[1] for k, v in fetch.items() if pred(k)) + sum(v[1] for k, v in write.items() if pred(k))) / nn * 1024.0
+
     out = {
         "command": "rocprofv3 --pmc FETCH_SIZE | WRITE_SIZE --kernel-trace -- python bench.py --ddim-steps 2 --steps 1 "
                    "--warmup 0 --no-cpu-baseline --no-kernel-events --no-overlap (tools/pmc_bench.sh, separate passes)",
@@ -39,6 +45,8 @@ def main():
         "calibration": "streaming 1x1 GEMM reading 819,200 KiB reports FETCH_SIZE 414-423k KiB (x0.51): the gfx950 "
                        "half-count of MI355X_MICROARCH.md holds for 16 B/lane loads; WRITE_SIZE is exact",
         "hbm_bytes_per_launch": (2.0 * f + w) / n * 1024.0,
+        "hbm_bytes_per_launch_split_bf16": per_class(lambda k: is_conv(k) and "bf16" in k),
+        "hbm_bytes_per_launch_fp32": per_class(lambda k: is_conv(k) and "bf16" not in k),
         "per_kernel": {k: {"launches": fetch[k][0], "fetch_kib_raw_avg": fetch[k][1] / fetch[k][0],
                            "write_kib_avg": (write[k][1] / write[k][0]) if k in write else None}
                        for k in sorted(fetch) if is_conv(k)},
