@@ -152,6 +152,161 @@ __global__ __launch_bounds__(512) void sla_c64_context_kernel(const float* __res
     }
 }
 
+// Single-sweep, split-operand version of sla_c64_context_kernel (used when the caller supplies the exact 3-way
+// bf16 split of to_qkv, pack_bf3 layout [K/16][3][2][768][8]):
+//  * K and V projections run on the bf16 matrix pipe: the LayerNorm'ed tile is split ONCE per tile into three bf16
+//    planes in LDS (x = x1+x2+x3, shared by the 8 head-waves), the head's weight pieces live in registers, 6 exact
+//    cross terms accumulate in fp32 (see conv_gemm.hip) -- 48 bf16 MFMAs instead of 64 fp32 ones per tile;
+//  * the softmax over pixels uses a running column max (flash-attention style rescale of ctx / den when it
+//    grows) instead of a first sweep that recomputes K only to find the max: softmax is shift-invariant, so
+//    the result differs from the two-sweep kernel by rounding only.
+typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_quad(const f32x4 v, uint2& p1, uint2& p2, uint2& p3) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 h1, h2, h3;
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h1[i] = (__bf16)v[i]; r[i] = v[i] - (float)h1[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h2[i] = (__bf16)r[i]; r[i] = r[i] - (float)h2[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h3[i] = (__bf16)r[i];
+    p1 = *reinterpret_cast<uint2*>(&h1);
+    p2 = *reinterpret_cast<uint2*>(&h2);
+    p3 = *reinterpret_cast<uint2*>(&h3);
+}
+
+// planes of one 32-pixel tile: [plane 3][chunk 4][k-half 2][px 32] x 16 B (8 channels) = 12 KB
+__device__ __forceinline__ void stage_tile_bf3(const float* __restrict__ xf, int n0, int HW, float eps, unsigned char* Pt, int tid) {
+    const int px = tid >> 4, sub = tid & 15;
+    const int n = n0 + px;
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < HW) v = *reinterpret_cast<const f32x4*>(xf + (long)n * C + sub * 4);
+    float s = v.x + v.y + v.z + v.w;
+    s = wave_sum(s, 16);
+    const float mu = s * (1.0f / C);
+    const f32x4 dl = v - mu;
+    float ss = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w;
+    ss = wave_sum(ss, 16);
+    const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
+    f32x4 o = dl * rs;
+    if (n >= HW) o = f32x4{0.f, 0.f, 0.f, 0.f};
+    uint2 p1, p2, p3;
+    split3_quad(o, p1, p2, p3);
+    const int kc = sub >> 2, qd = sub & 3;
+    unsigned char* dst = Pt + ((size_t)((kc * 2 + (qd >> 1)) * 32 + px)) * 16 + (qd & 1) * 8;
+    *reinterpret_cast<uint2*>(dst) = p1;
+    *reinterpret_cast<uint2*>(dst + 4096) = p2;
+    *reinterpret_cast<uint2*>(dst + 8192) = p3;
+}
+
+__global__ __launch_bounds__(512) void sla_c64_context_bf16_kernel(const float* __restrict__ x, int HW,
+                                                                   const unsigned short* __restrict__ wqkv_s,
+                                                                   const float* __restrict__ wout, float eps,
+                                                                   float* __restrict__ Mout) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ps[2][12288];
+    __shared__ __attribute__((aligned(16))) float cT[HEADS][32 * 36];
+    __shared__ float dens[HEADS * 32];
+    const int tid = threadIdx.x;
+    const int h = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int f = blockIdx.x;
+    const float* xf = x + (long)f * HW * C;
+    const int ntiles = (HW + 31) >> 5;
+
+    // weight pieces of this wave's head (B operands: lane column = feature, 8 channels of the chunk per k-half)
+    bf16x8s wk[4][3], wv[4][3];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const size_t base = ((size_t)((kc * 3 + pl) * 2 + half) * QKVN) * 8;
+            wk[kc][pl] = *reinterpret_cast<const bf16x8s*>(wqkv_s + base + (size_t)(HEADS * DH + h * DH + l31) * 8);
+            wv[kc][pl] = *reinterpret_cast<const bf16x8s*>(wqkv_s + base + (size_t)(2 * HEADS * DH + h * DH + l31) * 8);
+        }
+
+    f32x16 ctx = z16();
+    float den = 0.f, mx = -3.0e38f;
+    stage_tile_bf3(xf, 0, HW, eps, Ps[0], tid);
+    __syncthreads();
+    for (int t = 0; t < ntiles; ++t) {
+        if (t + 1 < ntiles) stage_tile_bf3(xf, 32 * (t + 1), HW, eps, Ps[(t + 1) & 1], tid);
+        const unsigned char* Pt = Ps[t & 1];
+        f32x16 kt = z16(), vt = z16();
+        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
+#pragma unroll
+        for (int kc = 0; kc < 4; ++kc) {
+            bf16x8s xa[3];
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                xa[pl] = *reinterpret_cast<const bf16x8s*>(Pt + pl * 4096 + ((size_t)((kc * 2 + half) * 32 + l31)) * 16);
+#pragma unroll
+            for (int u = 0; u < 6; ++u) {
+                kt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[u]], wk[kc][PB[u]], kt, 0, 0, 0);
+                vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[u]], wv[kc][PB[u]], vt, 0, 0, 0);
+            }
+        }
+        // running column max (lane column = feature d, rows = pixels of the tile)
+        float tm = -3.0e38f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (n < HW) tm = fmaxf(tm, kt[r]);
+        }
+        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
+        const float mnew = fmaxf(mx, tm);
+        if (__builtin_amdgcn_ballot_w64(mnew > mx) != 0ull) {      // rare after the first tiles: rescale ctx rows / den
+            const float alpha = expf(mx - mnew);                   // lane l31 = d (exp(-inf) = 0 on the first tile)
+            den *= alpha;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int d0 = (r & 3) + 8 * (r >> 2);
+                const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), d0));
+                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), d0 + 4));
+                ctx[r] *= half ? a1 : a0;
+            }
+            mx = mnew;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const float e = n < HW ? expf(kt[r] - mx) : 0.f;
+            kt[r] = e;
+            den += e;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[r], vt[r], ctx, 0, 0, 0);
+        __syncthreads();
+    }
+    den += __shfl_xor(den, 32, 64);
+    if (half == 0) dens[h * 32 + l31] = 1.0f / den;
+    __syncthreads();
+    float* ct = cT[h];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+        ct[d * 36 + l31] = ctx[r] * dens[h * 32 + d];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        f32x16 m = z16();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ct + l31 * 36 + 8 * c + 4 * half);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(wout + ((size_t)(h * 8 + 2 * c + half) * C + 32 * nt + l31) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) m = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], m, 0, 0, 0);
+        }
+        float* mo = Mout + (long)f * (HEADS * 8 * C * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(mo + ((size_t)(h * 8 + 2 * g + half) * C + 32 * nt + l31) * 4) =
+                f32x4{m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]};
+    }
+}
+
 // one block per (frame, split): LDS = Wq for all heads [16][256][4] (64 KB) + the frame's M [8][8][64][4] (64 KB)
 __global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* __restrict__ x, int HW,
                                                             const float* __restrict__ wqkv,
@@ -259,11 +414,16 @@ __global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const float* wout,
-                                  const float* bias, float eps, float* M_ws, float* out, void* stream) {
+extern "C" int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const void* wqkv_bf3,
+                                  const float* wout, const float* bias, float eps, float* M_ws, float* out,
+                                  void* stream) {
     if (F <= 0 || HW <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(sla_c64_context_kernel, dim3(F), dim3(512), 0, s, x, HW, wqkv, wout, eps, M_ws);
+    if (wqkv_bf3)
+        hipLaunchKernelGGL(sla_c64_context_bf16_kernel, dim3(F), dim3(512), 0, s, x, HW,
+                           (const unsigned short*)wqkv_bf3, wout, eps, M_ws);
+    else
+        hipLaunchKernelGGL(sla_c64_context_kernel, dim3(F), dim3(512), 0, s, x, HW, wqkv, wout, eps, M_ws);
     const int ntiles = (HW + 31) / 32;
     const int nsplit = (ntiles >= 64) ? 2 : 1;
     const int lds = (16 * 256 * 4 + 64 * 64 * 4) * 4;   // 128 KB

@@ -144,7 +144,7 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
 
 def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
     if a.C == 64:
-        return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout)
+        return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout, wqkv_bf3=a.wqkv_s)
     qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W)
     o = ops.sla(qkv, F, H * W)
     return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W)

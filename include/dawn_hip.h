@@ -126,9 +126,12 @@ int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);
 int dawn_sla_apply(const float* qkv, const float* ctx, int F, int HW, float* out, void* stream); /* out (F*HW,256) */
 
 /* Fused LAYER for 64-channel levels: out = x + to_out(linattn(LayerNorm(x))) + bias, q/k/v never materialised.
- * M_ws: caller workspace of F*8*8*64*4 floats (per-frame folded context . to_out matrices). */
-int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const float* wout, const float* bias,
-                       float eps, float* M_ws, float* out, void* stream);
+ * M_ws: caller workspace of F*8*8*64*4 floats (per-frame folded context . to_out matrices).
+ * wqkv_bf3 (optional): the exact 3-way bf16 split of wqkv, [64/16][3][2][768][8] (pack_bf3 order): the context
+ * kernel then runs its K / V projections on the bf16 matrix pipe (fp32 results) in a single sweep with a running
+ * column max; NULL = two-sweep fp32-MFMA kernel. */
+int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const void* wqkv_bf3, const float* wout,
+                       const float* bias, float eps, float* M_ws, float* out, void* stream);
 
 /* ---- A11 mid spatial attention: full softmax attention over the HW tokens of a frame (MT:841-843) */
 int dawn_frame_attn(const float* qkv, int F, int N, float* out, void* stream);

@@ -321,6 +321,9 @@ def test_sla_layer_c64(hip, ref, F, HW):
     want = ref.sla_layer_c64(x, F, HW, wqkv, wout, bias)
     got = hip.sla_layer_c64(*gpu(x), F, HW, *gpu(wqkv, wout, bias))
     check(f"sla_layer_c64/F{F}_HW{HW}", got, want, 3e-5)
+    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+    got = hip.sla_layer_c64(*gpu(x), F, HW, *gpu(wqkv, wout, bias), wqkv_bf3=pack_bf3(unpack_kn(wqkv)).cuda())
+    check(f"sla_layer_c64_split/F{F}_HW{HW}", got, want, 3e-5)
 
 
 @pytest.mark.parametrize("F,N", [(4, 16), (3, 64), (2, 100)])
