@@ -445,7 +445,7 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const dawn_conv_des
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][s], b[j][s], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[j][s], a[i][s], acc[i][j], 0, 0, 0);   // D^T: lane = row
         }
         if (NST == 3) {
             // chunk+1 must have landed, chunk+2 (just issued) may stay in flight; all reads of `buf` retired
@@ -459,54 +459,116 @@ __global__ __launch_bounds__(256) void conv_gemm_glds_kernel(const dawn_conv_des
         }
     }
 
-    float gs[TN], gss[TN];
+    // ---- epilogue.  The tiles are accumulated TRANSPOSED (A = weights, B = rows): lane = output row, registers
+    // 4g..4g+3 = columns 8g + 4*half + {0..3} of the 32-column tile, so the stores are 16-byte row segments (16
+    // dwordx4 per wave instead of 64 scalar stores -- the store epilogue dominated the small-K GEMMs) and the
+    // GroupNorm partial sums stay in registers per 4-channel piece until one block reduction.
+    const int cpg = d.N >> 3;
+    const bool quad_groups = (cpg & 3) == 0;                 // a 4-channel piece never straddles two groups
+    double* red = reinterpret_cast<double*>(smem);           // slow path (tiny N): LDS atomics per element
+    if (d.gn_part && !quad_groups) {
+        if (tid < 16) red[tid] = 0.0;
+        __syncthreads();
+    }
+    float gs[TN][4], gss[TN][4];
 #pragma unroll
-    for (int j = 0; j < TN; ++j) { gs[j] = 0.f; gss[j] = 0.f; }
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { gs[j][g] = 0.f; gss[j][g] = 0.f; }
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
+        const long m = m0 + wm * 64 + i * 32 + l31;
+        if (m >= M) continue;
+        long orow = m;
+        if (d.mode == 1) {
+            const int hw = d.Hi * d.Wi;
+            const int f = (int)(m / hw);
+            const int rem = (int)(m - (long)f * hw);
+            const int ya = rem / d.Wi, xb = rem - ya * d.Wi;
+            orow = ((long)f * d.Ho + 2 * ya + py) * d.Wo + 2 * xb + px;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const long m = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (m >= M) continue;
-            long orow = m;
-            if (d.mode == 1) {
-                const int hw = d.Hi * d.Wi;
-                const int f = (int)(m / hw);
-                const int rem = (int)(m - (long)f * hw);
-                const int a = rem / d.Wi, b = rem - a * d.Wi;
-                orow = ((long)f * d.Ho + 2 * a + py) * d.Wo + 2 * b + px;
-            }
+        for (int j = 0; j < TN; ++j) {
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = n0 + wn * WTN + j * 32 + l31;
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * WTN + j * 32 + 8 * g + 4 * half;
                 if (n >= d.N) continue;
-                float v = acc[i][j][r];
-                if (d.bias) v += d.bias[n];
-                if (d.res) v += d.res[orow * d.ld_res + n];
-                if (d.tr) v += dawn_silu(d.tr[orow * d.ld_tr + n] * d.tr_a[n] + d.tr_b[n]);
-                d.out[orow * d.ld_out + n] = v;
-                gs[j] += v;
-                gss[j] += v * v;
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (n + 3 < d.N && !(d.ld_out & 3) && !(d.res && (d.ld_res & 3)) && !(d.tr && (d.ld_tr & 3))) {
+                    if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
+                    if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + orow * d.ld_res + n);
+                    if (d.tr) {
+                        const f32x4 t4 = *reinterpret_cast<const f32x4*>(d.tr + orow * d.ld_tr + n);
+                        const f32x4 ta = *reinterpret_cast<const f32x4*>(d.tr_a + n), tb = *reinterpret_cast<const f32x4*>(d.tr_b + n);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) v[e] += dawn_silu(t4[e] * ta[e] + tb[e]);
+                    }
+                    *reinterpret_cast<f32x4*>(d.out + orow * d.ld_out + n) = v;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        if (n + e >= d.N) { v[e] = 0.f; continue; }
+                        if (d.bias) v[e] += d.bias[n + e];
+                        if (d.res) v[e] += d.res[orow * d.ld_res + n + e];
+                        if (d.tr) v[e] += dawn_silu(d.tr[orow * d.ld_tr + n + e] * d.tr_a[n + e] + d.tr_b[n + e]);
+                        d.out[orow * d.ld_out + n + e] = v[e];
+                    }
+                }
+                if (d.gn_part) {
+                    if (quad_groups) {
+                        gs[j][g] += (v.x + v.y) + (v.z + v.w);
+                        gss[j][g] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+                    } else {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (n + e < d.N) {
+                                atomicAdd(&red[2 * ((n + e) / cpg)], (double)v[e]);
+                                atomicAdd(&red[2 * ((n + e) / cpg) + 1], (double)v[e] * (double)v[e]);
+                            }
+                    }
+                }
             }
         }
     }
     if (d.gn_part) {
         // fp64 (sum, sumsq) per GroupNorm group of this block's columns -> gn_part[block][16] (MT:230,235)
-        double* red = reinterpret_cast<double*>(smem);       // every LDS read of the main loop has retired
-        if (tid < 16) red[tid] = 0.0;
-        __syncthreads();
-        const int cpg = d.N >> 3;
+        const long prow = ((long)blockIdx.z * gridDim.x + blockIdx.x) * 16;
+        __syncthreads();                                     // every LDS read of the main loop has retired
+        if (!quad_groups) {
+            if (tid < 16) d.gn_part[prow + tid] = red[tid];
+            return;
+        }
+        constexpr int NCOL = TN * 8;                         // (j, g, which) columns per thread
+        float* pf = smem;                                    // [NCOL][256]
+        double* pd = reinterpret_cast<double*>(smem + NCOL * 256);   // [NCOL][8]
 #pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = n0 + wn * WTN + j * 32 + l31;
-            if (n < d.N) {
-                const int g = n / cpg;
-                atomicAdd(&red[2 * g], (double)gs[j]);
-                atomicAdd(&red[2 * g + 1], (double)gss[j]);
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                pf[((j * 4 + g) * 2) * 256 + tid] = gs[j][g];
+                pf[((j * 4 + g) * 2 + 1) * 256 + tid] = gss[j][g];
             }
+        __syncthreads();
+        if (tid < NCOL * 8) {
+            const int c = tid >> 3, p = tid & 7;
+            double acc2 = 0.0;
+#pragma unroll 8
+            for (int e = 0; e < 32; ++e) acc2 += (double)pf[c * 256 + p * 32 + e];
+            pd[c * 8 + p] = acc2;
         }
         __syncthreads();
-        if (tid < 16) d.gn_part[((long)blockIdx.z * gridDim.x + blockIdx.x) * 16 + tid] = red[tid];
+        if (tid < 16) {
+            const int grp = tid >> 1, which = tid & 1;
+            double acc2 = 0.0;
+            for (int w = 0; w < 4; ++w)
+#pragma unroll
+                for (int jg = 0; jg < TN * 4; ++jg) {
+                    const int n = n0 + (w % WN) * WTN + (jg >> 2) * 32 + 8 * (jg & 3);   // half 0's piece; half 1: n + 4
+                    if (n < d.N && n / cpg == grp) acc2 += pd[(jg * 2 + which) * 8 + w * 2];
+                    if (n + 4 < d.N && (n + 4) / cpg == grp) acc2 += pd[(jg * 2 + which) * 8 + w * 2 + 1];
+                }
+            d.gn_part[prow + tid] = acc2;
+        }
     }
 }
 

@@ -130,7 +130,8 @@ def _conv_case(hip, name, in0, in1, w, N, kw, want):
     check("conv_gemm/" + name, got, want)
 
 
-@pytest.mark.parametrize("F,H,W,C0,N", [(3, 16, 16, 64, 64), (2, 8, 8, 128, 256), (5, 8, 8, 16, 16), (1, 40, 37, 32, 128)])
+@pytest.mark.parametrize("F,H,W,C0,N", [(3, 16, 16, 64, 64), (2, 8, 8, 128, 256), (5, 8, 8, 16, 16), (1, 40, 37, 32, 128),
+                                       (12, 8, 8, 16, 32), (12, 4, 4, 64, 32), (12, 8, 8, 48, 16)])
 def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
     """GroupNorm partial sums emitted by the conv epilogue == statistics pass over the conv output."""
     rows = F * H * W
