@@ -38,7 +38,12 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wq = smem;                         // [CIN/4][192][4]
     float* Wo = smem + (CIN / 4) * 192 * 4;   // [3][16][64][4]
+    float* Cs = Wo + 3 * 16 * 64 * 4;         // constants: g3 [3][64] | q_scale [3][8] | nulltab [3][16]  (264 floats, padded to 272)
+    float* Kv = Cs + 272;                     // per-wave copy of the current frame's table: [8 waves][3][128]
     const int tid = threadIdx.x;
+    for (int i = tid; i < 192; i += 512) Cs[i] = g3[i];
+    if (tid < 24) Cs[192 + tid] = q_scale[tid];
+    if (tid < 48) Cs[216 + tid] = nulltab[tid];
     for (int i = tid; i < (CIN / 4) * 192; i += 512)
         *reinterpret_cast<f32x4*>(Wq + i * 4) = *reinterpret_cast<const f32x4*>(wq + (size_t)i * 4);
     for (int i = tid; i < 3 * 16 * 64; i += 512) {
@@ -72,20 +77,30 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
             ss += xn[c].x * xn[c].x + xn[c].y * xn[c].y + xn[c].z * xn[c].z + xn[c].w * xn[c].w;
         }
         ss = x32(ss);
-        const float rs = 1.0f / sqrtf(ss * (1.0f / CIN) + eps);
+        const float rs = __builtin_amdgcn_rsqf(ss * (1.0f / CIN) + eps);
 #pragma unroll
         for (int c = 0; c < NC; ++c) xn[c] = xn[c] * rs;
 
+        // the frame's [null | condition] k/v table -> this wave's LDS copy (no global-load latency in the head loops);
+        // a 32-pixel tile lies in one frame whenever HW % 32 == 0, otherwise fall back to per-lane global reads
         const long f = rc / HW;
+        const bool one_frame = (HW & 31) == 0;
+        float* kvw = Kv + (tid >> 6) * 384;
+        if (one_frame) {
+            const long f0 = (t * 32) / HW;
+            const float* src = kvtab + f0 * 384;
+            *reinterpret_cast<f32x4*>(kvw + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
+            if (lane < 32) *reinterpret_cast<f32x4*>(kvw + 256 + lane * 4) = *reinterpret_cast<const f32x4*>(src + 256 + lane * 4);
+        }
         f32x16 hc[2];
         hc[0] = zz16();
         hc[1] = zz16();
 #pragma unroll 1
         for (int b = 0; b < 3; ++b) {
-            const float* kvt = kvtab + (f * 3 + b) * 128;
-            const f32x4 qs4 = *reinterpret_cast<const f32x4*>(q_scale + b * 8 + 4 * half);
-            const f32x4 kn4 = *reinterpret_cast<const f32x4*>(nulltab + b * 16 + 4 * half);
-            const f32x4 vn4 = *reinterpret_cast<const f32x4*>(nulltab + b * 16 + 8 + 4 * half);
+            const float* kvt = one_frame ? kvw + b * 128 : kvtab + (f * 3 + b) * 128;
+            const f32x4 qs4 = *reinterpret_cast<const f32x4*>(Cs + 192 + b * 8 + 4 * half);
+            const f32x4 kn4 = *reinterpret_cast<const f32x4*>(Cs + 216 + b * 16 + 4 * half);
+            const f32x4 vn4 = *reinterpret_cast<const f32x4*>(Cs + 216 + b * 16 + 8 + 4 * half);
             f32x16 qT[2];
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
@@ -104,20 +119,19 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
                     const int hd = 4 * tt + c4;
                     const float q0 = acc[4 * c4], q1 = acc[4 * c4 + 1], q2 = acc[4 * c4 + 2], q3 = acc[4 * c4 + 3];
                     const float n2 = x32(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
-                    const float inv = 1.0f / fmaxf(sqrtf(n2), 1e-12f);
+                    const float inv = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));        // 1 / max(|q|, 1e-12)  (F.normalize)
                     const f32x4 kc4 = *reinterpret_cast<const f32x4*>(kvt + hd * 8 + 4 * half);
                     const f32x4 vc4 = *reinterpret_cast<const f32x4*>(kvt + 64 + hd * 8 + 4 * half);
                     const float a0 = q0 * inv * qs4.x, a1 = q1 * inv * qs4.y, a2 = q2 * inv * qs4.z, a3 = q3 * inv * qs4.w;
-                    const float sn = 8.0f * x32(a0 * kn4.x + a1 * kn4.y + a2 * kn4.z + a3 * kn4.w);
-                    const float sc = 8.0f * x32(a0 * kc4.x + a1 * kc4.y + a2 * kc4.z + a3 * kc4.w);
-                    const float mx = fmaxf(sn, sc);
-                    const float en = expf(sn - mx), ec = expf(sc - mx);
-                    const float den = en + ec;
-                    const float an = en / den, ac = ec / den;
-                    acc[4 * c4] = an * vn4.x + ac * vc4.x;
-                    acc[4 * c4 + 1] = an * vn4.y + ac * vc4.y;
-                    acc[4 * c4 + 2] = an * vn4.z + ac * vc4.z;
-                    acc[4 * c4 + 3] = an * vn4.w + ac * vc4.w;
+                    const float sn = x32(a0 * kn4.x + a1 * kn4.y + a2 * kn4.z + a3 * kn4.w);
+                    const float sc = x32(a0 * kc4.x + a1 * kc4.y + a2 * kc4.z + a3 * kc4.w);
+                    // softmax over the 2 keys [null, condition] in closed form: weight of the condition key =
+                    // sigmoid(8 (sc - sn)); one v_exp_f32 + one v_rcp_f32 (1 ulp each) instead of two expf and two divisions
+                    const float ac = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((sn - sc) * (8.0f * 1.4426950408889634f)));
+                    acc[4 * c4] = vn4.x + ac * (vc4.x - vn4.x);
+                    acc[4 * c4 + 1] = vn4.y + ac * (vc4.y - vn4.y);
+                    acc[4 * c4 + 2] = vn4.z + ac * (vc4.z - vn4.z);
+                    acc[4 * c4 + 3] = vn4.w + ac * (vc4.w - vn4.w);
                 }
                 qT[tt] = acc;
             }
@@ -150,12 +164,12 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
                 yv += d0 * d0 + d1 * d1;
             }
             yv = x32(yv);
-            const float yr = rsqrtf(yv * (1.0f / CO) + eps);
+            const float yr = __builtin_amdgcn_rsqf(yv * (1.0f / CO) + eps);
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(g3 + b * CO + 32 * ot + 8 * g + 4 * half);
+                    const f32x4 g4 = *reinterpret_cast<const f32x4*>(Cs + b * CO + 32 * ot + 8 * g + 4 * half);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hc[ot][4 * g + j] += (yT[ot][4 * g + j] - ym) * yr * g4[j];
                 }
@@ -185,8 +199,8 @@ extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const flo
     hipStream_t s = (hipStream_t)stream;
     const long ntiles = (rows + 31) / 32;
     long grid = (ntiles + 7) / 8;
-    if (grid > 512) grid = 512;
-    const int lds = ((Cin / 4) * 192 * 4 + 3 * 16 * 64 * 4) * 4;
+    if (grid > 256) grid = 256;                 // one resident block per CU (LDS-bound): every block gets the same tile count
+    const int lds = ((Cin / 4) * 192 * 4 + 3 * 16 * 64 * 4 + 272 + 8 * 384) * 4;
     if (Cin == 64) {
         (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(xattn_c64_kernel<64>, dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows, HW,

@@ -38,6 +38,7 @@ class HipOps:
         self.L = _lib.lib()          # raises if the extension is missing: no fallback by design
         self.comm = comm             # T-shard communicator (see tshard.py) or None
         self.prof = None             # list -> (algorithmic flops, start event, end event) per conv_gemm launch
+        self.prof_on = True          # sampling switch (the sampler records events on every n-th DDIM step only)
         self.overlap = True          # two-stream overlap of independent branches (fork_join)
         self._side_stream = None
         self.graph_error = None      # set when a HIP-graph capture failed and the sampler fell back to eager
@@ -45,6 +46,8 @@ class HipOps:
     def with_comm(self, comm):
         o = HipOps(comm)
         o.prof = self.prof
+        o.prof_on = self.prof_on
+        o.prof_every = getattr(self, "prof_every", 1)
         o.overlap = self.overlap
         return o
 
@@ -122,7 +125,7 @@ class HipOps:
         nrows = C.c_int(0)
         if gn_part is not None:
             d.gn_rows = C.pointer(nrows)
-        if self.prof is not None:
+        if self.prof is not None and self.prof_on:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")

@@ -84,7 +84,9 @@ def ddim_sample_clip(ops, P: PackedUNet, cs: ClipState, x_init: Tensor, steps: S
         except Exception as e:                                   # noqa: BLE001  (capture is an optimisation only)
             ops.graph_error = f"{type(e).__name__}: {str(e)[:200]}"
             graphed = None
+    prof_every = getattr(ops, "prof_every", 1)
     for i, st in enumerate(steps):
+        ops.prof_on = (i % prof_every == 0)     # per-kernel HIP events (bench.py roofline) on every n-th step only
         # with a graph, every `eager_every`-th step still runs eagerly so that per-kernel HIP events (bench.py's
         # live roofline measurement) sample the timed region
         if graphed is not None and not (eager_every and ops.prof is not None and i % eager_every == 0):

@@ -40,3 +40,16 @@ print(f"temporal_layer_c64 fp32  : {t:8.1f} us   (split-operand Q/K/V projection
 for name, s in (("fp32", None), ("split", wqkv_s)):
     t = timeit(lambda: ops.sla_layer_c64(x, F, HW, wqkv, wout, bias, wqkv_bf3=s))
     print(f"sla_layer_c64      {name:6s}: {t:8.1f} us (context + apply)")
+# fused cross-attention branch (Co = 64), Cin = 64 and 128 (two sources)
+wq64 = pack_kn(torch.randn(64, 192) * 0.125).to(dev)
+wq128 = pack_kn(torch.randn(128, 192) * 0.09).to(dev)
+wo = [pack_kn(torch.randn(64, 64) * 0.125).to(dev) for _ in range(3)]
+g3 = (torch.randn(3, 64) * 0.2 + 1).to(dev)
+q_scale = (torch.rand(3, 8) + 0.5).to(dev)
+kvtab = torch.randn(F, 3, 128, device=dev)
+nulltab = torch.randn(3, 16, device=dev)
+x2 = torch.randn(F * HW, 64, device=dev)
+t = timeit(lambda: ops.xattn_layer_c64(x, None, HW, wq64, wo, g3, q_scale, kvtab, nulltab))
+print(f"xattn_layer_c64 Cin=64   : {t:8.1f} us")
+t = timeit(lambda: ops.xattn_layer_c64(x, x2, HW, wq128, wo, g3, q_scale, kvtab, nulltab))
+print(f"xattn_layer_c64 Cin=64+64: {t:8.1f} us")
