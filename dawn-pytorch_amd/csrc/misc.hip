@@ -44,6 +44,78 @@ __global__ __launch_bounds__(256) void init_conv_x_kernel(const float* __restric
     }
 }
 
+// MFMA version of the same op for the benchmark geometries (Co = 64, 256 % w == 0, h % (256 / w) == 0):
+// implicit GEMM with K = 147 (+1 zero row) on v_mfma_f32_32x32x2_f32, accumulated transposed (A = weights, B = the
+// pixel's tap value) so the epilogue adds fea_pre and stores 16-byte row segments.  A block = 256 output pixels
+// (TR image rows); the 3-channel (TR+6) x (w+6) zero-padded patch and the 148 x 64 weights live in LDS.
+__global__ __launch_bounds__(256) void init_conv_x_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w3,
+                                                               const float* __restrict__ fea_pre, int F, int h, int w,
+                                                               float* __restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int Co = 64, KP = 148;
+    const int TR = 256 / w, PW = w + 6, PS = (TR + 6) * PW;
+    float* Ws = sm;                 // [148][64]
+    float* Ps = sm + KP * Co;       // [3][TR+6][w+6]
+    const int tid = threadIdx.x;
+    const long plane = (long)F * h * w;
+    const int tiles_per_frame = h / TR;
+    const int f = blockIdx.x / tiles_per_frame;
+    const int y0 = (blockIdx.x - f * tiles_per_frame) * TR;
+    for (int i = tid; i < KP * Co; i += 256) Ws[i] = i < 147 * Co ? w3[i] : 0.f;
+    for (int i = tid; i < 3 * PS; i += 256) {
+        const int c = i / PS, rem = i - c * PS;
+        const int py = rem / PW, px = rem - py * PW;
+        const int y = y0 + py - 3, xx = px - 3;
+        Ps[i] = (y >= 0 && y < h && xx >= 0 && xx < w) ? x[c * plane + ((long)f * h + y) * w + xx] : 0.f;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, half = lane >> 5;
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    int pbase[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = wave * 64 + i * 32 + l31;          // pixel within the tile
+        const int ty = p / w, tx = p - ty * w;
+        pbase[i] = ty * PW + tx;
+    }
+#pragma unroll 2
+    for (int s = 0; s < KP / 2; ++s) {
+        const int k = 2 * s + half;                      // this half-wave's k index (147 = zero weight row)
+        const int kk = k < 147 ? k : 0;
+        const int tap = kk / 3, c = kk - tap * 3;
+        const int ky = tap / 7, kx = tap - ky * 7;
+        const int koff = c * PS + ky * PW + kx;
+        const float a0 = Ws[k * Co + l31], a1 = Ws[k * Co + 32 + l31];
+        const float b0 = Ps[pbase[0] + koff], b1 = Ps[pbase[1] + koff];
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    // lane = pixel, registers 4g..4g+3 = channels 32j + 8g + 4half + {0..3}
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int p = wave * 64 + i * 32 + l31;
+        const long rem = (long)y0 * w + p;               // pixel within the frame
+        const float* fp = fea_pre + rem * Co;
+        float* op = out + ((long)f * h * w + rem) * Co;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * j + 8 * g + 4 * half;
+                const f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(op + n) = v + *reinterpret_cast<const f32x4*>(fp + n);
+            }
+    }
+}
+
 // heads (MT:863, 876, 956): eps[0:2] = Wg.hg + bg ; eps[2] = Wo.ho + bo ; output layout (3, rows)
 // 16 lanes per row.
 __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ hg, const float* __restrict__ ho,
@@ -108,6 +180,14 @@ __global__ void sinusoidal_kernel(float t, int dim, const float* __restrict__ fr
 extern "C" int dawn_init_conv_x(const float* x, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
                                 float* out, void* stream) {
     if (Co % 4 != 0 || 147 * Co * 4 > 60000) return dawn_set_error_msg(-60, "dawn_init_conv_x: bad Co");
+    if (Co == 64 && w <= 256 && 256 % w == 0 && h % (256 / w) == 0 && (256 / w) <= h) {
+        const int TR = 256 / w;
+        const int lds = (148 * 64 + 3 * (TR + 6) * (w + 6)) * (int)sizeof(float);
+        hipLaunchKernelGGL(init_conv_x_mfma_kernel, dim3(F * (h / TR)), dim3(256), lds, (hipStream_t)stream, x, w3, fea_pre,
+                           F, h, w, out);
+        DAWN_LAUNCH_CHECK();
+        return 0;
+    }
     const long total = (long)F * h * w * (Co / 4);
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;

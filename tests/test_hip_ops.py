@@ -338,6 +338,10 @@ def test_init_conv_x_and_head(hip, ref):
     F, h, w, Co = 3, 8, 8, 64
     x, w3, fp = rnd(3, F, h, w, seed=1), rnd(147, Co, seed=2) * 0.1, rnd(h * w, Co, seed=3)
     check("init_conv_x", hip.init_conv_x(x.cuda(), w3.cuda(), fp.cuda(), F, h, w, Co), ref.init_conv_x(x, w3, fp, F, h, w, Co), 2e-5)
+    for (F, h, w) in ((2, 32, 32), (1, 64, 64), (3, 16, 16), (2, 12, 64)):   # MFMA kernel geometries (256 % w == 0, rows | h)
+        x, fp = rnd(3, F, h, w, seed=11), rnd(h * w, Co, seed=13)
+        check(f"init_conv_x_mfma/{F}x{h}x{w}", hip.init_conv_x(x.cuda(), w3.cuda(), fp.cuda(), F, h, w, Co),
+              ref.init_conv_x(x, w3, fp, F, h, w, Co), 2e-5)
     for Co in (16, 64):
         hg, ho = rnd(500, Co, seed=4), rnd(500, Co, seed=5)
         wg, bg, wo, bo = rnd(2, Co, seed=6), rnd(2, seed=7), rnd(1, Co, seed=8), rnd(1, seed=9)
