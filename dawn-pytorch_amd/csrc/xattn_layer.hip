@@ -41,6 +41,9 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
     float* Cs = Wo + 3 * 16 * 64 * 4;         // constants: g3 [3][64] | q_scale [3][8] | nulltab [3][16]  (264 floats, padded to 272)
     float* Kv = Cs + 272;                     // per-wave copy of the current frame's table: [8 waves][3][128]
     const int tid = threadIdx.x;
+    // (CIN = 128 keeps its LDS at the 147 KB of the weights: with the extra tables the block would fill the CU's LDS
+    //  and a concurrent single-block kernel of the other stream -- gn_reduce_finalize -- could not be placed)
+    constexpr bool KVLDS = CIN == 64;
     for (int i = tid; i < 192; i += 512) Cs[i] = g3[i];
     if (tid < 24) Cs[192 + tid] = q_scale[tid];
     if (tid < 48) Cs[216 + tid] = nulltab[tid];
@@ -84,7 +87,7 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
         // the frame's [null | condition] k/v table -> this wave's LDS copy (no global-load latency in the head loops);
         // a 32-pixel tile lies in one frame whenever HW % 32 == 0, otherwise fall back to per-lane global reads
         const long f = rc / HW;
-        const bool one_frame = (HW & 31) == 0;
+        const bool one_frame = KVLDS && (HW & 31) == 0;
         float* kvw = Kv + (tid >> 6) * 384;
         if (one_frame) {
             const long f0 = (t * 32) / HW;
@@ -200,7 +203,7 @@ extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const flo
     const long ntiles = (rows + 31) / 32;
     long grid = (ntiles + 7) / 8;
     if (grid > 256) grid = 256;                 // one resident block per CU (LDS-bound): every block gets the same tile count
-    const int lds = ((Cin / 4) * 192 * 4 + 3 * 16 * 64 * 4 + 272 + 8 * 384) * 4;
+    const int lds = ((Cin / 4) * 192 * 4 + 3 * 16 * 64 * 4 + 272 + (Cin == 64 ? 8 * 384 : 0)) * 4;
     if (Cin == 64) {
         (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(xattn_c64_kernel<64>, dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows, HW,
