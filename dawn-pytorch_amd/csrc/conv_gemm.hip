@@ -1408,6 +1408,180 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     return true;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Split-operand GEMM for the large prologue-free 1x1 projections (to_qkv after dawn_ln_rows, to_out + residual):
+// out (M x N) = A (M x K, fp32 rows) . W, on the bf16 matrix pipe with the exact 3-way operand split and 6 cross
+// terms (see conv3x3_halo_bf16_kernel).  256 x 128 tile, 8 waves (64 x 64 each), K consumed 32 channels per stage:
+// the A rows of stage s+2 are in flight as register loads, those of stage s+1 are split between the MFMAs of
+// stage s and written to the idle plane buffer, the pre-split weights arrive by LDS-DMA one stage ahead -- one
+// barrier per 48 MFMAs per wave.  Accumulated transposed (lane = row) -> 16-byte row-segment stores.
+template <int NT>
+__global__ __launch_bounds__(512) void gemm1x1_bf16_kernel(const dawn_conv_desc d, const long M) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int BM = 256, BN = 128, NTHR = 512, TM = 2, TN = 2;
+    constexpr int HPS = BM * 16 + 128;                         // half-plane stride (bytes)
+    constexpr int PSZ = 2 * 6 * HPS;                           // planes of one stage (2 sub-chunks of 16 channels)
+    constexpr int BSZ = 2 * 6 * BN * 16;                       // weights of one stage
+    constexpr int NBI = BSZ / 1024;                            // 24 DMA wave-instructions per stage, 3 per wave
+    constexpr unsigned OOB = 0x80000000u;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* planes = smem_b;                            // [2 stages][2 sub][3 planes][2 halves][HPS]
+    unsigned char* Bs = smem_b + 2 * PSZ;                      // [2 stages][2 sub][3][2][BN][16 B]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int K = d.C0;
+    const int nS = K / 32;
+    const int nNt = d.N / BN;
+    const int mt = blockIdx.x / nNt, nt = blockIdx.x - mt * nNt;
+    const long m0 = (long)mt * BM;
+    const int n0 = nt * BN;
+    const __amdgpu_buffer_rsrc_t rsa =
+        __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + m0 * d.ld0), 0, BM * d.ld0 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, (K / 16) * 6 * d.N * 16, 0x00020000);
+    // A quads of a stage: 256 rows x 8 quads = 2048 -> 4 per thread: q = tid + 512 i -> row = q >> 3, quad = q & 7
+    unsigned voffA[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int q = tid + NTHR * i;
+        voffA[i] = (unsigned)((q >> 3) * d.ld0 * 4 + (q & 7) * 16);
+    }
+    unsigned voffB[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        const int idx = (j * 8 + wave) * 64 + lane;            // 16-byte piece within the stage
+        const int sub = idx / (6 * BN), rem = idx - sub * (6 * BN);
+        const int ph = rem / BN, n = rem - ph * BN;
+        voffB[j] = (unsigned)((((sub * 6 + ph) * d.N) + n0 + n) * 16);
+    }
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    f32x4 araw[2][4];
+    uint2 ap[4][3];
+    auto loadA = [&](int s, int slot) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            araw[slot][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, voffA[i], s * 128, 0));
+    };
+    auto writeA = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int q = tid + NTHR * i;
+            const int row = q >> 3, quad = q & 7;               // quad: sub-chunk = quad >> 2, k-half = (quad >> 1) & 1
+            unsigned char* dst = planes + (size_t)buf * PSZ + (size_t)(quad >> 2) * 6 * HPS + (size_t)((quad >> 1) & 1) * HPS +
+                                 row * 16 + (quad & 1) * 8;
+            *reinterpret_cast<uint2*>(dst) = ap[i][0];
+            *reinterpret_cast<uint2*>(dst + 2 * HPS) = ap[i][1];
+            *reinterpret_cast<uint2*>(dst + 4 * HPS) = ap[i][2];
+        }
+    };
+    auto issueB = [&](int s, int buf) {
+        const int soff = s * 2 * 6 * d.N * 16;
+#pragma unroll
+        for (int j = 0; j < 3; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                rsw, (__attribute__((address_space(3))) void*)(Bs + (size_t)buf * BSZ + (j * 8 + wave) * 1024), 16, voffB[j], soff, 0, 0);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    issueB(0, 0);
+    loadA(0, 0);
+    if (nS > 1) loadA(1, 1);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) split3(araw[0][i], ap[i][0], ap[i][1], ap[i][2]);
+    writeA(0);
+    for (int s = 0; s < nS; ++s) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // planes(s) + weights(s) complete; buffers of stage s-1 are free
+        const int cur = s & 1;
+        if (s + 1 < nS) issueB(s + 1, cur ^ 1);
+        // araw[(s+1)&1] holds stage s+1 (landed: waited above); stage s+2 goes into the slot stage s used
+        const unsigned char* Pb = planes + (size_t)cur * PSZ;
+        const unsigned char* Bb = Bs + (size_t)cur * BSZ;
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            bf16x8 fa[TM][3], fb[TN][3];
+            constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
+#pragma unroll
+            for (int g = 0; g < 3; ++g) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    fa[i][RA[g]] = *reinterpret_cast<const bf16x8*>(Pb + (size_t)sub * 6 * HPS + (size_t)(RA[g] * 2 + half) * HPS +
+                                                                     (wm * 64 + i * 32 + l31) * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    fb[j][RB[g]] = *reinterpret_cast<const bf16x8*>(
+                        Bb + ((size_t)((sub * 6 + RB[g] * 2 + half) * BN + wn * 64 + j * 32 + l31)) * 16);
+            }
+            constexpr int PA9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+            constexpr int PB9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+#pragma unroll
+            for (int t = 9 - NT; t < 9; ++t)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB9[t]], fa[i][PA9[t]], acc[i][j], 0, 0, 0);
+            // split two of the next stage's quads in the shadow of these MFMAs
+            if (s + 1 < nS) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    const int qi = sub * 2 + i;
+                    if ((s + 1) & 1) split3(araw[1][qi], ap[qi][0], ap[qi][1], ap[qi][2]);
+                    else split3(araw[0][qi], ap[qi][0], ap[qi][1], ap[qi][2]);
+                }
+            }
+        }
+        if (s + 1 < nS) {
+            writeA(cur ^ 1);                // readers of that buffer (stage s-1) passed the barrier above
+            if (s + 2 < nS) {
+                if (s & 1) loadA(s + 2, 1); else loadA(s + 2, 0);
+            }
+        }
+    }
+
+    // ---- epilogue (lane = row, registers 4g..4g+3 = columns 8g + 4*half + {0..3})
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const long m = m0 + wm * 64 + i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+                f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
+                if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
+                if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
+                *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n) = v;
+            }
+    }
+#endif
+}
+
+bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
+    if (d.C1 != 0 || d.in1 || d.C0 % 32 != 0 || d.N % 128 != 0 || M % 256 != 0 || M < 51200 || d.tr || d.gn_part) return false;
+    if ((d.ld0 & 3) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) || (long)d.ld0 * 256 * 4 >= (1L << 31)) return false;
+    const size_t lds = (size_t)2 * 2 * 6 * (256 * 16 + 128) + (size_t)2 * 2 * 6 * 128 * 16;
+    const int nwg = (int)(M / 256) * (d.N / 128);
+    g_last_nwg = nwg;
+    if (g_variant & 0x2000) {
+        (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm1x1_bf16_kernel<9>), dim3(nwg), dim3(512), lds, s, d, M);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm1x1_bf16_kernel<6>), dim3(nwg), dim3(512), lds, s, d, M);
+    }
+    return true;
+}
+
 template <int BN, int WN>
 bool try_launch_halo_bf16(const dawn_conv_desc& d, long M, hipStream_t s, bool nine) {
     constexpr int BM = 64 * (4 / WN);
@@ -1519,6 +1693,11 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     const long M = (d.mode == 0) ? (long)d.F * d.Ho * d.Wo : (long)d.F * d.Hi * d.Wi;
     if (M <= 0 || d.N <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if ((g_variant & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ch_a &&
+        !d.pro_act && !d.pro_add && !d.row_mean && try_launch_gemm1x1_bf16(d, M, s)) {
+        DAWN_LAUNCH_CHECK();
+        return 0;
+    }
     if ((g_variant & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 &&
         d.Ho == d.Hi && d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool nine = (g_variant & 0x2000) != 0;

@@ -117,7 +117,8 @@ class PackedAttn:
     wqkv: Tensor
     wout: Tensor
     bout: Optional[Tensor] = None
-    wqkv_s: Optional[Tensor] = None       # pack_bf3 image of wqkv (64-channel spatial-linear layers)
+    wqkv_s: Optional[Tensor] = None       # pack_bf3 images of wqkv / wout (split-operand kernels)
+    wout_s: Optional[Tensor] = None
 
 
 @dataclass
@@ -202,8 +203,9 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
         a = PackedAttn(C=wqkv.shape[1], wqkv=dev(pack_kn(wqkv.t() * gamma[:, None])), wout=dev(pack_kn(wout.t())))
         if spatial_linear:
             a.bout = dev(g(p + inner + "to_out.bias"))
-            if a.C == 64:
-                a.wqkv_s = pack_bf3(wqkv.t() * gamma[:, None]).to(device)
+        # exact 3-way bf16 split images for the split-operand kernels (fused 64-channel layers, large 1x1 GEMMs)
+        a.wqkv_s = pack_bf3(wqkv.t() * gamma[:, None]).to(device)
+        a.wout_s = pack_bf3(wout.t()).to(device)
         return a
 
     def resblock(p: str) -> PackedResBlock:

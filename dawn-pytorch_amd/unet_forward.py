@@ -137,23 +137,23 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
     Fext = xe.shape[0] // HW
     if ops.can_fuse_temporal(a.C, Fext, F, cs.win):
         return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band)
-    qkv = ops.conv_gemm(ops.ln_rows(xe), a.wqkv, 768, F=Fext, Hi=H, Wi=W)
+    qkv = ops.conv_gemm(ops.ln_rows(xe), a.wqkv, 768, F=Fext, Hi=H, Wi=W, w_bf3=a.wqkv_s)
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)
-    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W)
+    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 
 def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
     if a.C == 64:
         return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout, wqkv_bf3=a.wqkv_s)
-    qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W)
+    qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W, w_bf3=a.wqkv_s)
     o = ops.sla(qkv, F, H * W)
-    return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W)
+    return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 
 def _mid_spatial(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
-    qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W)
+    qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W, w_bf3=a.wqkv_s)
     o = ops.frame_attn(qkv, F, H * W)
-    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W)
+    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 
 def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_all: Optional[Tensor] = None) -> Tensor:

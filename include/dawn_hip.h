@@ -51,7 +51,7 @@ typedef struct dawn_conv_desc {
     float* out; int ld_out;
     double* gn_part;                               /* optional: per-block GroupNorm(8) partial sums of the output,
                                                       [gridDim.x][16] = (sum, sumsq) per group (see dawn_gn_reduce) */
-    const void* w_bf3;                             /* optional (3x3/s1/p1 only): the same weights split exactly into three
+    const void* w_bf3;                             /* optional (3x3/s1/p1 convs, large 1x1 GEMMs): the same weights split exactly into three
                                                       bf16 planes w = w1+w2+w3, [K/16][3][2][N][8] (k = tap*(C0+C1)+c), for
                                                       the split-operand bf16-MFMA kernel; NULL = fp32 MFMA */
     int* gn_rows;                                  /* optional HOST pointer: receives the number of gn_part rows this launch

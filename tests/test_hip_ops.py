@@ -180,6 +180,27 @@ def test_conv_bf16_split_is_fp32_accurate(hip, ref):
     assert errs[14349] <= 2.0 * errs[2061] + 1e-7, errs
 
 
+@pytest.mark.parametrize("M,K,N,res,bias", [(51200, 128, 768, False, False), (51200, 256, 128, True, True),
+                                            (102400, 64, 256, True, False), (51200, 512, 384, False, True)])
+def test_gemm1x1_split(hip, ref, M, K, N, res, bias):
+    """Large prologue-free 1x1 GEMMs on the bf16 pipe with exactly split operands == fp32 GEMM."""
+    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+    x, w = rnd(M, K, seed=1), packw(K, N, seed=2)
+    kw = dict(F=M // 64, Hi=8, Wi=8)
+    if res:
+        kw["res"] = rnd(M, N, seed=3)
+    if bias:
+        kw["bias"] = rnd(N, seed=4)
+    want = ref.conv_gemm(x, w, N, **kw)
+    gkw = {k_: (v.cuda() if torch.is_tensor(v) else v) for k_, v in kw.items()}
+    for variant in (22541, 30733):
+        hip.L.dawn_conv_set_variant(variant)
+        got = hip.conv_gemm(x.cuda(), w.cuda(), N, w_bf3=pack_bf3(unpack_kn(w)).cuda(), **gkw)
+        torch.cuda.synchronize()
+        check(f"gemm1x1_split/M{M}_K{K}_N{N}/v{variant}", got, want)
+    hip.L.dawn_conv_set_variant(22541)
+
+
 def test_conv_gemm_transposed(hip, ref):
     from dawn_pytorch_amd.pack import pack_kn, deconv_w_kn_phases
     F, H, W, Cc = 3, 8, 8, 64
