@@ -40,3 +40,21 @@ for n, s, e, q in rows:
 print("idle time by the kernel that FOLLOWS the gap:")
 for k, (n, t) in sorted(gaps.items(), key=lambda kv: -kv[1][1])[:15]:
     print(f"  {k:52s} {n:6d} gaps  {t/1e6:8.3f} ms  avg {t/n/1e3:6.1f} us")
+
+# exclusive / overlapped time per queue (sweep line over kernel start/end events)
+ev = []
+for n, s_, e, q in rows:
+    ev.append((s_, 1, q)); ev.append((e, -1, q))
+ev.sort()
+active = collections.Counter()
+last = ev[0][0]
+excl = collections.Counter(); both = 0
+for t, d, q in ev:
+    qs = [k for k, v in active.items() if v > 0]
+    if len(qs) == 1:
+        excl[qs[0]] += t - last
+    elif len(qs) > 1:
+        both += t - last
+    active[q] += d
+    last = t
+print("time with exactly one queue active:", {k: f"{v/1e6:.2f} ms" for k, v in excl.items()}, f"; several queues active: {both/1e6:.2f} ms")
