@@ -58,10 +58,16 @@ typedef struct dawn_conv_desc {
                                                       writes (= its thread-block count; <= dawn_conv_gemm_nblocks) */
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
-/* number of thread blocks (= rows of gn_part) dawn_conv_gemm will launch for an (M rows, N columns) output */
+/* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;
+ * the launch reports the exact count through dawn_conv_desc.gn_rows */
 int dawn_conv_gemm_nblocks(long M, int N);
-/* tuning knob for A/B measurements: bit0 BK=32 tiles, bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order */
+/* tuning knob for A/B measurements and tests (default 0x580D = shipped policy): bit0 BK=32 tiles, bit1 256x64 tile for
+ * N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel, 0x1000 split-operand
+ * (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000 second-generation split
+ * 3x3 kernel; bits 16-19 select perf ablations / the s_memtime-instrumented build (tools/conv_phase_timing.py). */
 void dawn_conv_set_variant(int v);
+/* instrumented build only: device buffer (4096 x 64 uint64) receiving the per-phase s_memtime stamps */
+int dawn_conv_set_debug(void* device_buffer);
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --
  * partial: per-block fp64 (sum, sumsq) per group -> part[nblk][16]; reduce: fixed-order sum ->
