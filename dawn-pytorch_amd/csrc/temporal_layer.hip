@@ -49,17 +49,83 @@ __device__ __forceinline__ f32x16 proj_T(const float* wp, int Nw, int n, int hal
     return acc;
 }
 
+// ---- WMODE 2: Q/K/V projections on the bf16 matrix pipe with exactly split operands (fp32 results, see
+// conv_gemm.hip).  The LayerNorm'ed rows are split ONCE (phase 0) into three bf16 planes in LDS
+// ([plane 3][chunk 4][k-half 2][row][8 channels], shared by all 8 heads x {q,k,v}), the pre-split weight fragments
+// (pack_bf3 image [4][3][2][768][8]) are read straight from L2 one chunk ahead: 24 bf16 MFMAs (768 cycles) replace
+// 32 fp32 MFMAs (2048 cycles) per 32x32 projection tile, and the per-head weight staging + its barrier disappear.
+typedef __bf16 bf16x8t __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_quad_t(const f32x4 v, uint2& p1, uint2& p2, uint2& p3) {
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    bf16x4 h1, h2, h3;
+    f32x4 r;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h1[i] = (__bf16)v[i]; r[i] = v[i] - (float)h1[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { h2[i] = (__bf16)r[i]; r[i] = r[i] - (float)h2[i]; }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) h3[i] = (__bf16)r[i];
+    p1 = *reinterpret_cast<uint2*>(&h1);
+    p2 = *reinterpret_cast<uint2*>(&h2);
+    p3 = *reinterpret_cast<uint2*>(&h3);
+}
+
+// one (TWO = false) or two 32-feature tiles of D^T = W^T . X^T for 32 rows.  Weight fragments come through a buffer
+// descriptor (SGPRs) + one per-lane byte offset + scalar offsets (feature column, chunk, plane): no 64-bit address
+// VGPRs.  xp = the rows' 16-byte slot of plane 0 / chunk 0 / this lane's k-half.
+template <bool TWO>
+__device__ __forceinline__ void proj_T_split(const __amdgpu_buffer_rsrc_t rw, unsigned wvoff, int col0, int col1,
+                                             const unsigned char* xp, int FP, f32x16& d0, f32x16& d1) {
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
+    constexpr int WS = 2 * 768 * 16;                 // bytes between (chunk, plane) groups of the weight image
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    d0 = zero16();
+    if (TWO) d1 = zero16();
+    bf16x8t w0[2][3], w1[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        w0[0][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, col0 * 16 + pl * WS, 0));
+        if (TWO) w1[0][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, col1 * 16 + pl * WS, 0));
+    }
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        if (kc < 3) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                w0[(kc + 1) & 1][pl] = __builtin_bit_cast(
+                    bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, col0 * 16 + ((kc + 1) * 3 + pl) * WS, 0));
+                if (TWO)
+                    w1[(kc + 1) & 1][pl] = __builtin_bit_cast(
+                        bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, col1 * 16 + ((kc + 1) * 3 + pl) * WS, 0));
+            }
+        }
+        bf16x8t xs[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            xs[pl] = *reinterpret_cast<const bf16x8t*>(xp + (size_t)((pl * 4 + kc) * 2) * FP * 16);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            d0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0[kc & 1][PW[u]], xs[PX[u]], d0, 0, 0, 0);
+            if (TWO) d1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1[kc & 1][PW[u]], xs[PX[u]], d1, 0, 0, 0);
+        }
+    }
+}
+
 // WLDS: stage the head's weight slices (Wq|Wk|Wv 64x96 + Wout 32x64 = 32 KB) in LDS, prefetched one head
 // ahead through registers, so no MFMA waits on an L2 round trip (used when the LDS budget allows: F <= 224).
-template <int NKT, bool WLDS>
+template <int NKT, int WMODE>
 __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
     const float* __restrict__ x, int Fext, int HW, int q0, int Fq, int win, const float* __restrict__ wqkv,
-    const float* __restrict__ wout, const float* __restrict__ rcos, const float* __restrict__ rsin,
+    const unsigned short* __restrict__ wqkv_s, const float* __restrict__ wout, const float* __restrict__ rcos, const float* __restrict__ rsin,
     const float* __restrict__ band, float eps, float* __restrict__ out, int nrt) {
+#if __HIP_DEVICE_COMPILE__   // (buffer-resource builtins are device-only; the host pass only needs the launch stub)
     extern __shared__ __attribute__((aligned(16))) float smem[];
+    constexpr bool WLDS = WMODE == 1;
+    constexpr bool SPLIT = WMODE == 2;
     const int FP = 32 * nrt;                // padded frame rows
-    float* Xs = smem;                       // [FP][XLD]
-    float* Ks = Xs + FP * XLD;              // [FP][KLD]
+    float* Xs = smem;                       // [FP][XLD]   (WMODE 2: bf16 planes [3][4][2][FP] x 16 B = 96 floats per row)
+    float* Ks = Xs + FP * (SPLIT ? 96 : XLD);   // [FP][KLD]
     float* Vs = Ks + FP * KLD;              // [FP][DH]
     float* band_s = Vs + FP * DH;           // [(2*win+1)][8]
     float* Wl = band_s + (((2 * win + 1) * HEADS + 3) & ~3);   // WLDS: [16][96][4] qkv slices, then [8][64][4] out
@@ -86,11 +152,24 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
             f32x4 o = dl * rs;
             if (j >= Fext) o = f32x4{0.f, 0.f, 0.f, 0.f};
-            *reinterpret_cast<f32x4*>(Xs + j * XLD + sub * 4) = o;
+            if (SPLIT) {
+                uint2 p1, p2, p3;
+                split3_quad_t(o, p1, p2, p3);
+                const int kc = sub >> 2, qd = sub & 3;
+                unsigned char* dst = reinterpret_cast<unsigned char*>(Xs) + ((size_t)(kc * 2 + (qd >> 1)) * FP + j) * 16 + (qd & 1) * 8;
+                *reinterpret_cast<uint2*>(dst) = p1;
+                *reinterpret_cast<uint2*>(dst + (size_t)8 * FP * 16) = p2;
+                *reinterpret_cast<uint2*>(dst + (size_t)16 * FP * 16) = p3;
+            } else {
+                *reinterpret_cast<f32x4*>(Xs + j * XLD + sub * 4) = o;
+            }
         }
     }
     __syncthreads();
 
+    // WMODE 2: descriptor of the split weight image + this lane's byte offset (k-half, feature column l31)
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wqkv_s, 0, 4 * 3 * 2 * 768 * 16, 0x00020000);
+    const unsigned wvoff = (unsigned)((half * 768 + l31) * 16);
     const int nqt = (Fq + 31) >> 5;
     const bool has_q = wave < nqt;           // this wave's query tile (8 waves => Fq <= 256)
     const int i0 = q0 + 32 * wave;
@@ -144,8 +223,14 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
         for (int rt = wave; rt < nrt; rt += 8) {
             const int j = 32 * rt + l31;
             const float* xr = Xs + j * XLD + 4 * half;
-            f32x16 kT = proj_T(wk_p, wN, l31, half, xr);
-            f32x16 vT = proj_T(wv_p, wN, l31, half, xr);
+            f32x16 kT, vT;
+            if (SPLIT) {
+                const unsigned char* xp = reinterpret_cast<const unsigned char*>(Xs) + ((size_t)half * FP + j) * 16;
+                proj_T_split<true>(rsw, wvoff, HEADS * DH + h * DH, 2 * HEADS * DH + h * DH, xp, FP, kT, vT);
+            } else {
+                kT = proj_T(wk_p, wN, l31, half, xr);
+                vT = proj_T(wv_p, wN, l31, half, xr);
+            }
             const int jc = j < Fext ? j : Fext - 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
@@ -165,7 +250,14 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
 
         if (has_q) {
             // ---- Q^T for this wave's 32 queries (registers = B fragments), scale + rotary (lane-local)
-            f32x16 qT = proj_T(wq_p, wN, l31, half, Xs + iqc * XLD + 4 * half);
+            f32x16 qT;
+            if (SPLIT) {
+                const unsigned char* xp = reinterpret_cast<const unsigned char*>(Xs) + ((size_t)half * FP + iqc) * 16;
+                f32x16 unused;
+                proj_T_split<false>(rsw, wvoff, h * DH, h * DH, xp, FP, qT, unused);
+            } else {
+                qT = proj_T(wq_p, wN, l31, half, Xs + iqc * XLD + 4 * half);
+            }
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const float2 cc = qcs[c];
@@ -232,7 +324,9 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             for (int t = 0; t < NKT; ++t) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    int j = j0 + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    // (WMODE 2: opaque base so the 64 clamped V addresses are not hoisted out of the head loop and spilled;
+                    //  the other variants allocate better with the plain expression)
+                    int j = (SPLIT ? j0m : j0) + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
                     j = j < 0 ? 0 : (j >= FP ? FP - 1 : j);
                     oT = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[j * DH + l31], st[t][r] * inv, oT, 0, 0, 0);
                 }
@@ -270,35 +364,45 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                 *reinterpret_cast<f32x4*>(orow + n) = o + xv;
             }
     }
+#endif
 }
 
 }  // namespace
 
 extern "C" int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
-                                       const float* wout, const float* rot_cos, const float* rot_sin,
-                                       const float* band, float eps, float* out, void* stream) {
+                                       const void* wqkv_bf3, const float* wout, const float* rot_cos,
+                                       const float* rot_sin, const float* band, float eps, float* out, void* stream) {
     if (Fq <= 0) return 0;
     if (q0 < 0 || q0 + Fq > Fext || win < 0) return dawn_set_error_msg(-32, "dawn_temporal_layer_c64: bad frame range");
     if (Fq > 256 || Fext > 288) return dawn_set_error_msg(-33, "dawn_temporal_layer_c64: Fq <= 256 and Fext <= 288 only");
     const int nkt = (32 + 2 * win + 31) / 32;
     const int nrt = (Fext + 31) / 32;
     const size_t base = ((size_t)32 * nrt * (XLD + KLD + DH) + (size_t)(((2 * win + 1) * HEADS + 3) & ~3)) * sizeof(float);
-    const bool wlds = base + 32768 <= 163840;
-    const size_t lds = base + (wlds ? 32768 : 0);
+    // WMODE 2 (split-operand projections): X as bf16 planes (96 floats per row instead of XLD), no weight region
+    const size_t base2 = ((size_t)32 * nrt * (96 + KLD + DH) + (size_t)(((2 * win + 1) * HEADS + 3) & ~3)) * sizeof(float);
+    const bool split = wqkv_bf3 != nullptr && base2 <= 163840;
+    const bool wlds = !split && base + 32768 <= 163840;
+    const size_t lds = split ? base2 : base + (wlds ? 32768 : 0);
+    const unsigned short* ws = (const unsigned short*)wqkv_bf3;
     if (lds > 163840) return dawn_set_error_msg(-34, "dawn_temporal_layer_c64: LDS budget exceeded");
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TL(N)                                                                                           \
     do {                                                                                                       \
-        if (wlds) {                                                                                            \
-            (void)hipFuncSetAttribute((const void*)temporal_layer_c64_kernel<N, true>,                         \
+        if (split) {                                                                                           \
+            (void)hipFuncSetAttribute((const void*)temporal_layer_c64_kernel<N, 2>,                            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-            hipLaunchKernelGGL((temporal_layer_c64_kernel<N, true>), dim3(HW), dim3(512), lds, s, x, Fext, HW, \
-                               q0, Fq, win, wqkv, wout, rot_cos, rot_sin, band, eps, out, nrt);                \
+            hipLaunchKernelGGL((temporal_layer_c64_kernel<N, 2>), dim3(HW), dim3(512), lds, s, x, Fext, HW,    \
+                               q0, Fq, win, wqkv, ws, wout, rot_cos, rot_sin, band, eps, out, nrt);            \
+        } else if (wlds) {                                                                                     \
+            (void)hipFuncSetAttribute((const void*)temporal_layer_c64_kernel<N, 1>,                            \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
+            hipLaunchKernelGGL((temporal_layer_c64_kernel<N, 1>), dim3(HW), dim3(512), lds, s, x, Fext, HW,    \
+                               q0, Fq, win, wqkv, ws, wout, rot_cos, rot_sin, band, eps, out, nrt);            \
         } else {                                                                                               \
-            (void)hipFuncSetAttribute((const void*)temporal_layer_c64_kernel<N, false>,                        \
+            (void)hipFuncSetAttribute((const void*)temporal_layer_c64_kernel<N, 0>,                            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
-            hipLaunchKernelGGL((temporal_layer_c64_kernel<N, false>), dim3(HW), dim3(512), lds, s, x, Fext,    \
-                               HW, q0, Fq, win, wqkv, wout, rot_cos, rot_sin, band, eps, out, nrt);            \
+            hipLaunchKernelGGL((temporal_layer_c64_kernel<N, 0>), dim3(HW), dim3(512), lds, s, x, Fext,        \
+                               HW, q0, Fq, win, wqkv, ws, wout, rot_cos, rot_sin, band, eps, out, nrt);        \
         }                                                                                                      \
     } while (0)
     switch (nkt) {

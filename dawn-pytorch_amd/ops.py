@@ -256,13 +256,14 @@ class HipOps:
         return C == 64 and Fext <= 288 and Fq <= 256 and win <= 48
 
     def temporal_layer_c64(self, x: Tensor, Fext: int, HW: int, q0: int, Fq: int, win: int, wqkv: Tensor,
-                           wout: Tensor, rcos: Tensor, rsin: Tensor, band: Tensor, eps: float = 1e-5) -> Tensor:
+                           wout: Tensor, rcos: Tensor, rsin: Tensor, band: Tensor, eps: float = 1e-5,
+                           wqkv_bf3: Optional[Tensor] = None) -> Tensor:
         """out = x[q0:q0+Fq] + to_out(attn(LayerNorm(x))) for 64-channel levels, one kernel."""
         assert x.is_contiguous() and x.shape == (Fext * HW, 64)
         self._require(x, wqkv, wout, rcos, rsin, band)
         out = self.empty(Fq * HW, 64, like=x)
-        check(self.L.dawn_temporal_layer_c64(_p(x), Fext, HW, q0, Fq, win, _p(wqkv), _p(wout), _p(rcos), _p(rsin),
-                                             _p(band), eps, _p(out), self._stream()), "dawn_temporal_layer_c64")
+        check(self.L.dawn_temporal_layer_c64(_p(x), Fext, HW, q0, Fq, win, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(rcos),
+                                             _p(rsin), _p(band), eps, _p(out), self._stream()), "dawn_temporal_layer_c64")
         return out
 
     def sla(self, qkv: Tensor, F: int, HW: int) -> Tensor:

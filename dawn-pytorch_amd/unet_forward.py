@@ -136,7 +136,8 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
         xe, q0 = x, 0
     Fext = xe.shape[0] // HW
     if ops.can_fuse_temporal(a.C, Fext, F, cs.win):
-        return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band)
+        return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
+                                      wqkv_bf3=a.wqkv_s)
     qkv = ops.conv_gemm(ops.ln_rows(xe), a.wqkv, 768, F=Fext, Hi=H, Wi=W, w_bf3=a.wqkv_s)
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)

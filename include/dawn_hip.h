@@ -122,10 +122,12 @@ int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, int Fq, int w
 
 /* Fused LAYER for 64-channel levels: out[(i-q0)] = x[i] + to_out(attn(LayerNorm(x)))  (MT:179-188, 665-725,
  * 141-147) -- x (Fext*HW, 64) rows, packed wqkv [(64/4)][768][4] (LayerNorm gain folded), wout [(256/4)][64][4].
- * Limits: Fext <= 288, Fq <= 256, win <= 48; the caller falls back to the unfused ops otherwise. */
+ * Limits: Fext <= 288, Fq <= 256, win <= 48; the caller falls back to the unfused ops otherwise.
+ * wqkv_bf3 (optional): exact 3-way bf16 split of wqkv, [64/16][3][2][768][8] (pack_bf3 order): when the LDS budget
+ * allows (Fext <= 224) the Q/K/V projections run on the bf16 matrix pipe with fp32 results; NULL = fp32 MFMA. */
 int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
-                            const float* wout, const float* rot_cos, const float* rot_sin, const float* band,
-                            float eps, float* out, void* stream);
+                            const void* wqkv_bf3, const float* wout, const float* rot_cos, const float* rot_sin,
+                            const float* band, float eps, float* out, void* stream);
 
 /* ---- A8 SpatialLinearAttention core (MT:611-627) ---------------------------------------------- */
 int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);     /* ctx (F,8,32,32) */

@@ -327,6 +327,10 @@ def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
     want = ref.temporal_layer_c64(x, Fext, HW, q0, Fq, win, wqkv, wout, rc, rs, band)
     got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band))
     check(f"temporal_layer_c64/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 3e-5)
+    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+    got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band),
+                                 wqkv_bf3=pack_bf3(unpack_kn(wqkv)).cuda())
+    check(f"temporal_layer_c64_split/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 3e-5)
 
 
 @pytest.mark.parametrize("F,HW", [(3, 64), (2, 256), (5, 16), (2, 100)])

@@ -34,9 +34,9 @@ def timeit(fn, n=5):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-t = timeit(lambda: ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band))
-print(f"temporal_layer_c64 fp32  : {t:8.1f} us   (split-operand Q/K/V projections were tried: 3366 vs 3266 us, the "
-      "in-register fragment splits cost more than the MFMA time they save; not kept)")
+for name, s in (("fp32", None), ("split", wqkv_s)):
+    t = timeit(lambda: ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band, wqkv_bf3=s))
+    print(f"temporal_layer_c64 {name:6s}: {t:8.1f} us")
 # T-shard geometry: 200 own frames + 40 halo frames on each side (interior shard), 240 for an edge shard
 xe = torch.randn(280 * HW, 64, device=dev)
 rc2, rs2 = torch.cos(torch.arange(280 + 2 * win, dtype=torch.float32)[:, None] * freqs[None, :]).to(dev), torch.sin(torch.arange(280 + 2 * win, dtype=torch.float32)[:, None] * freqs[None, :]).to(dev)
