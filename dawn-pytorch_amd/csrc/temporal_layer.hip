@@ -19,6 +19,11 @@
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 
+#ifdef DAWN_TL_TIMING
+__device__ unsigned long long* dawn_tl_dbg = nullptr;
+extern "C" int dawn_temporal_set_debug(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(dawn_tl_dbg), &p, sizeof(p)); }
+#endif
+
 namespace {
 
 constexpr int C = 64;
@@ -127,17 +132,32 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
     float* Xs = smem;                       // [FP][XLD]   (WMODE 2: bf16 planes [3][4][2][FP] x 16 B = 96 floats per row)
     float* Ks = Xs + FP * (SPLIT ? 96 : XLD);   // [FP][KLD]
     float* Vs = Ks + FP * KLD;              // [FP][DH]
-    float* band_s = Vs + FP * DH;           // [(2*win+1)][8]
-    float* Wl = band_s + (((2 * win + 1) * HEADS + 3) & ~3);   // WLDS: [16][96][4] qkv slices, then [8][64][4] out
+    // per-head relative-position bias as a function of idx = rel + win, padded to idx in [-32, 32*NKT) and filled with
+    // NEG outside the window [0, 2*win]: the bias lookup also applies the window mask, and lane l31 / register r read
+    // band_s[h][32 + 32t + rho(r) - l31] -- consecutive lanes, consecutive addresses, constant offsets per register
+    constexpr int BLD = 32 * NKT + 32;
+    float* band_s = Vs + FP * DH;           // [8 heads][BLD]
+    float* Wl = band_s + HEADS * BLD;   // WLDS: [16][96][4] qkv slices, then [8][64][4] out
     float* Wo = Wl + 16 * 96 * 4;
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
     const long p = blockIdx.x;
+#ifdef DAWN_TL_TIMING
+    unsigned long long* tsb = reinterpret_cast<unsigned long long*>(smem + 40000);   // 160000 B .. (instrumented build)
+    int tix = 0;
+#define TSTAMP() do { if (tid == 0 && tix < 64) tsb[tix++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP() do { } while (0)
+#endif
+    TSTAMP();
 
     // ---- phase 0: LayerNorm rows into LDS (16 lanes per row, float4 each)
-    for (int i = tid; i < (2 * win + 1) * HEADS; i += 512) band_s[i] = band[i];
+    for (int i = tid; i < HEADS * BLD; i += 512) {
+        const int hh = i / BLD, idx = i - hh * BLD - 32;
+        band_s[i] = (idx >= 0 && idx <= 2 * win) ? band[idx * HEADS + hh] : NEG;
+    }
     {
         const int sub = tid & 15;
         for (int j = tid >> 4; j < FP; j += 32) {
@@ -208,6 +228,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
     };
     if (WLDS) wfetch(0);
 
+    TSTAMP();   // phase 0 done (+ setup)
     for (int h = 0; h < HEADS; ++h) {
         if (WLDS) {
 #pragma unroll
@@ -219,6 +240,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
         const float* wk_p = WLDS ? Wl + 32 * 4 : wqkv + (size_t)(HEADS * DH + h * DH) * 4;
         const float* wv_p = WLDS ? Wl + 64 * 4 : wqkv + (size_t)(2 * HEADS * DH + h * DH) * 4;
         const int wN = WLDS ? 96 : 3 * HEADS * DH;
+        if (h < 2) TSTAMP();   // head start (after weight staging)
         // ---- K^T / V^T projection of every frame row, rotary on K, row-major into LDS
         for (int rt = wave; rt < nrt; rt += 8) {
             const int j = 32 * rt + l31;
@@ -246,7 +268,9 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                     f32x4{vT[4 * c], vT[4 * c + 1], vT[4 * c + 2], vT[4 * c + 3]};
             }
         }
+        if (h < 2) TSTAMP();   // K/V projected (before barrier)
         __syncthreads();
+        if (h < 2) TSTAMP();   // barrier passed
 
         if (has_q) {
             // ---- Q^T for this wave's 32 queries (registers = B fragments), scale + rotary (lane-local)
@@ -269,6 +293,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                 qT[4 * c + 2] = a2 * cc.y - a3 * sn.y;
                 qT[4 * c + 3] = a3 * cc.y + a2 * sn.y;
             }
+            if (h < 2) TSTAMP();   // Q projected + rotated
             // ---- S^T tiles: keys j0 + 32t + row
             const int j0 = i0 - win;
             f32x16 st[NKT];
@@ -286,25 +311,38 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                         st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[s], qT[4 * c + s], st[t], 0, 0, 0);
                 }
             }
+            if (h < 2) TSTAMP();   // S issued
             // ---- bias + mask + softmax (lane's query = iq)
             // (opaque copy: keeps the compiler from hoisting the 64 head-invariant mask/index values out of the
             //  head loop, which costs 64+ live VGPRs and spills)
             int j0m = j0;
             asm volatile("" : "+v"(j0m));
             float m = NEG;
+            const float* bb = band_s + h * BLD + 32 - l31 + 4 * half;     // + 32t + (r&3) + 8(r>>2) per register
+            const bool interior = (j0 >= 0) && (j0 + 32 * NKT <= Fext);   // wave-uniform: every staged key is a real frame
+            if (interior) {
 #pragma unroll
-            for (int t = 0; t < NKT; ++t) {
+                for (int t = 0; t < NKT; ++t) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int j = j0m + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    const int rel = j - iq;
-                    const bool ok = (rel >= -win) && (rel <= win) && (j >= 0) && (j < Fext);
-                    const int bi = ok ? (rel + win) * HEADS + h : 0;
-                    const float sv = ok ? st[t][r] + band_s[bi] : NEG;
-                    st[t][r] = sv;
-                    m = fmaxf(m, sv);
+                    for (int r = 0; r < 16; ++r) {
+                        const float sv = st[t][r] + bb[32 * t + (r & 3) + 8 * (r >> 2)];   // out-of-window entries add NEG
+                        st[t][r] = sv;
+                        m = fmaxf(m, sv);
+                    }
                 }
-                __builtin_amdgcn_sched_barrier(0);
+            } else {
+#pragma unroll
+                for (int t = 0; t < NKT; ++t) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int j = j0m + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                        const bool ok = (j >= 0) && (j < Fext);
+                        const float sv = ok ? st[t][r] + bb[32 * t + (r & 3) + 8 * (r >> 2)] : NEG;
+                        st[t][r] = sv;
+                        m = fmaxf(m, sv);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
             m = fmaxf(m, __shfl_xor(m, 32, 64));
             float l = 0.f;
@@ -318,6 +356,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                 }
             l += __shfl_xor(l, 32, 64);
             const float inv = 1.0f / l;
+            if (h < 2) TSTAMP();   // softmax done
             // ---- O^T = V^T . P^T  (A = V column fragments from LDS, B = P from the accumulators)
             f32x16 oT = zero16();
 #pragma unroll
@@ -332,6 +371,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                 }
                 __builtin_amdgcn_sched_barrier(0);   // keep at most one key tile of V fragments in flight
             }
+            if (h < 2) TSTAMP();   // PV issued
             // ---- out^T += Wout_h^T . O^T   (A = to_out rows h*32 + d, columns n)
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
@@ -347,6 +387,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                     if (c == 1) __builtin_amdgcn_sched_barrier(0);
                 }
         }
+        if (h < 2) TSTAMP();   // out-proj issued (before end-of-head barrier)
         __syncthreads();   // Ks / Vs are rewritten by the next head
     }
 
@@ -364,6 +405,11 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                 *reinterpret_cast<f32x4*>(orow + n) = o + xv;
             }
     }
+    TSTAMP();   // end
+#ifdef DAWN_TL_TIMING
+    if (tid == 0 && blockIdx.x < 4096)
+        for (int i = 0; i < 32; ++i) dawn_tl_dbg[(size_t)blockIdx.x * 32 + i] = i < tix ? tsb[i] : 0ull;
+#endif
 #endif
 }
 
@@ -377,12 +423,17 @@ extern "C" int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0,
     if (Fq > 256 || Fext > 288) return dawn_set_error_msg(-33, "dawn_temporal_layer_c64: Fq <= 256 and Fext <= 288 only");
     const int nkt = (32 + 2 * win + 31) / 32;
     const int nrt = (Fext + 31) / 32;
-    const size_t base = ((size_t)32 * nrt * (XLD + KLD + DH) + (size_t)(((2 * win + 1) * HEADS + 3) & ~3)) * sizeof(float);
+    const size_t band_floats = (size_t)HEADS * (32 * nkt + 32);
+    const size_t base = ((size_t)32 * nrt * (XLD + KLD + DH) + band_floats) * sizeof(float);
     // WMODE 2 (split-operand projections): X as bf16 planes (96 floats per row instead of XLD), no weight region
-    const size_t base2 = ((size_t)32 * nrt * (96 + KLD + DH) + (size_t)(((2 * win + 1) * HEADS + 3) & ~3)) * sizeof(float);
+    const size_t base2 = ((size_t)32 * nrt * (96 + KLD + DH) + band_floats) * sizeof(float);
     const bool split = wqkv_bf3 != nullptr && base2 <= 163840;
     const bool wlds = !split && base + 32768 <= 163840;
+#ifdef DAWN_TL_TIMING
+    const size_t lds = 163840;                 // instrumented build: stamps live at byte 160000
+#else
     const size_t lds = split ? base2 : base + (wlds ? 32768 : 0);
+#endif
     const unsigned short* ws = (const unsigned short*)wqkv_bf3;
     if (lds > 163840) return dawn_set_error_msg(-34, "dawn_temporal_layer_c64: LDS budget exceeded");
     hipStream_t s = (hipStream_t)stream;

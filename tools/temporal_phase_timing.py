@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""GPU tool: s_memtime phase profile of temporal_layer_c64_kernel (needs the instrumented build:
+    hipcc ... -DDAWN_TL_TIMING on temporal_layer.hip, see tools/build_timing_lib.sh).  Prints mean cycles between stamps."""
+import ctypes, os, sys
+import numpy as np, torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from dawn_pytorch_amd.ops import HipOps
+from dawn_pytorch_amd.pack import pack_kn, pack_bf3
+ops = HipOps()
+dev = "cuda"
+F, HW, win = 200, 4096, 40
+torch.manual_seed(0)
+x = torch.randn(F * HW, 64, device=dev)
+wqkv_kn = torch.randn(64, 768) * 0.125
+wqkv, wqkv_s = pack_kn(wqkv_kn).to(dev), pack_bf3(wqkv_kn).to(dev)
+wout = pack_kn(torch.randn(256, 64) / 16).to(dev)
+pos = torch.arange(F + 2 * win, dtype=torch.float32)
+freqs = 10000.0 ** (-torch.arange(0, 32, 2, dtype=torch.float32) / 32)
+ang = pos[:, None] * freqs[None, :]
+rc, rs = torch.cos(ang).to(dev), torch.sin(ang).to(dev)
+band = (torch.randn(2 * win + 1, 8) * 0.1).to(dev)
+dbg = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
+ops.L.dawn_temporal_set_debug.argtypes = [ctypes.c_void_p]
+assert ops.L.dawn_temporal_set_debug(dbg.data_ptr()) == 0
+names = ["start", "phase0+setup", "h0 start", "h0 KV proj", "h0 barrier", "h0 Q proj", "h0 S", "h0 softmax", "h0 PV", "h0 out",
+         "h1 start", "h1 KV proj", "h1 barrier", "h1 Q proj", "h1 S", "h1 softmax", "h1 PV", "h1 out", "end (6 more heads + store)"]
+for label, s in (("fp32 (WMODE 1)", None), ("split (WMODE 2)", wqkv_s)):
+    for _ in range(2):
+        dbg.zero_()
+        ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band, wqkv_bf3=s)
+        torch.cuda.synchronize()
+    t = dbg.cpu().numpy().reshape(4096, 32).astype(np.float64)
+    n = int((t[0] != 0).sum())
+    d = np.diff(t[:, :n], axis=1)
+    print(f"--- {label}: {n} stamps; block duration mean {(t[:, n-1] - t[:, 0]).mean():.0f} cycles")
+    for i in range(n - 1):
+        print(f"  {names[i]:14s} -> {names[i+1]:28s}: {d[:, i].mean():9.0f}  (p10 {np.percentile(d[:, i], 10):8.0f}, p90 {np.percentile(d[:, i], 90):8.0f})")
