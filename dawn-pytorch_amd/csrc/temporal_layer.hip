@@ -147,7 +147,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
 #ifdef DAWN_TL_TIMING
     unsigned long long* tsb = reinterpret_cast<unsigned long long*>(smem + 40000);   // 160000 B .. (instrumented build)
     int tix = 0;
-#define TSTAMP() do { if (tid == 0 && tix < 64) tsb[tix++] = __builtin_amdgcn_s_memtime(); } while (0)
+#define TSTAMP() do { if (lane == 0 && tix < 24) tsb[wave * 24 + tix++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
 #define TSTAMP() do { } while (0)
 #endif
@@ -294,11 +294,20 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                 qT[4 * c + 3] = a3 * cc.y + a2 * sn.y;
             }
             if (h < 2) TSTAMP();   // Q projected + rotated
-            // ---- S^T tiles: keys j0 + 32t + row
+            // ---- attention core, software-pipelined in two halves of the key range (online softmax): all waves of a
+            // block run the same phase at the same time (per-head barriers), so a VALU-only softmax phase leaves the
+            // matrix pipe idle and vice versa (measured: two waves on a SIMD took 1.85x the time of one).  Here the
+            // bias/max/exp of half A sits in the shadow of the S MFMAs of half B, and the softmax of half B in the
+            // shadow of the P.V MFMAs of half A (a 64-cycle fp32 MFMA hides ~12 VALU instructions).
             const int j0 = i0 - win;
+            // (opaque copy: keeps the compiler from hoisting the 64 head-invariant mask/index values out of the
+            //  head loop, which costs 64+ live VGPRs and spills)
+            int j0m = j0;
+            asm volatile("" : "+v"(j0m));
+            const float* bb = band_s + h * BLD + 32 - l31 + 4 * half;     // + 32t + (r&3) + 8(r>>2) per register
+            constexpr int HA = (NKT + 1) / 2;                             // key tiles [0, HA) = half A, [HA, NKT) = half B
             f32x16 st[NKT];
-#pragma unroll
-            for (int t = 0; t < NKT; ++t) {
+            auto s_tile = [&](int t) {
                 st[t] = zero16();
                 int j = j0 + 32 * t + l31;
                 j = j < 0 ? 0 : (j >= FP ? FP - 1 : j);
@@ -310,66 +319,96 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                     for (int s = 0; s < 4; ++s)
                         st[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(k4[s], qT[4 * c + s], st[t], 0, 0, 0);
                 }
-            }
-            if (h < 2) TSTAMP();   // S issued
-            // ---- bias + mask + softmax (lane's query = iq)
-            // (opaque copy: keeps the compiler from hoisting the 64 head-invariant mask/index values out of the
-            //  head loop, which costs 64+ live VGPRs and spills)
-            int j0m = j0;
-            asm volatile("" : "+v"(j0m));
-            float m = NEG;
-            const float* bb = band_s + h * BLD + 32 - l31 + 4 * half;     // + 32t + (r&3) + 8(r>>2) per register
-            const bool interior = (j0 >= 0) && (j0 + 32 * NKT <= Fext);   // wave-uniform: every staged key is a real frame
-            if (interior) {
-#pragma unroll
-                for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const float sv = st[t][r] + bb[32 * t + (r & 3) + 8 * (r >> 2)];   // out-of-window entries add NEG
-                        st[t][r] = sv;
-                        m = fmaxf(m, sv);
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int t = 0; t < NKT; ++t) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int j = j0m + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-                        const bool ok = (j >= 0) && (j < Fext);
-                        const float sv = ok ? st[t][r] + bb[32 * t + (r & 3) + 8 * (r >> 2)] : NEG;
-                        st[t][r] = sv;
-                        m = fmaxf(m, sv);
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-            m = fmaxf(m, __shfl_xor(m, 32, 64));
-            float l = 0.f;
-#pragma unroll
-            for (int t = 0; t < NKT; ++t)
+            };
+            // scores += bias (window mask folded into the table) + clip-edge penalty, running max.  Branch-free: the keys
+            // of this wave are slots s = 32t + rho in [0, 32 NKT); those outside [lo, hi) are not frames of the clip.
+            // lo / hi are wave-uniform, so the per-slot test is scalar and only the k-half select is per lane.
+            int lo = __builtin_amdgcn_readfirstlane(j0 < 0 ? -j0 : 0);
+            int hi = __builtin_amdgcn_readfirstlane(Fext - j0 < 32 * NKT ? Fext - j0 : 32 * NKT);
+            asm volatile("" : "+s"(lo), "+s"(hi));        // head-invariant: recompute the 128 penalties per head, do not keep them
+            auto bias_max = [&](int t, float& m) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = exp2f((st[t][r] - m) * LOG2E);     // == exp(s - m); one v_exp_f32
+                    const int c = 32 * t + (r & 3) + 8 * (r >> 2);
+                    const float pen0 = (c >= lo && c < hi) ? 0.f : NEG;
+                    const float pen1 = (c + 4 >= lo && c + 4 < hi) ? 0.f : NEG;
+                    const float sv = st[t][r] + bb[c] + (half ? pen1 : pen0);
+                    st[t][r] = sv;
+                    m = fmaxf(m, sv);
+                }
+            };
+            auto pv_tile = [&](int t, f32x16& o) {       // o^T += V^T . P^T for key tile t (P unnormalised)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    int j = j0m + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    j = j < 0 ? 0 : (j >= FP ? FP - 1 : j);
+                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[j * DH + l31], st[t][r], o, 0, 0, 0);
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < HA; ++t) s_tile(t);
+            if (h < 2) TSTAMP();   // S(A) issued
+            // ---- S of half B  ||  bias + max + exp of half A
+#pragma unroll
+            for (int t = HA; t < NKT; ++t) s_tile(t);
+            float mA = NEG;
+#pragma unroll
+            for (int t = 0; t < HA; ++t) bias_max(t, mA);
+            mA = fmaxf(mA, __shfl_xor(mA, 32, 64));
+            float lA = 0.f;
+#pragma unroll
+            for (int t = 0; t < HA; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = exp2f((st[t][r] - mA) * LOG2E);     // == exp(s - m); one v_exp_f32
+                    st[t][r] = pv;
+                    lA += pv;
+                }
+#pragma unroll
+            for (int i = 0; i < 16 * (NKT - HA); ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // MFMA (S of half B) ...
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);      // ... VALU of half A's softmax in its shadow
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);       // ... and one LDS read
+            }
+            if (h < 2) TSTAMP();   // S(B) issued + softmax(A)
+            // ---- P.V of half A  ||  bias + max + exp of half B (relative to the joint max)
+            f32x16 oA = zero16();
+#pragma unroll
+            for (int t = 0; t < HA; ++t) pv_tile(t, oA);
+            float m = mA;
+#pragma unroll
+            for (int t = HA; t < NKT; ++t) bias_max(t, m);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float alpha = exp2f((mA - m) * LOG2E);                 // rescale of half A (1 when the max did not move)
+            float l = lA * alpha;
+#pragma unroll
+            for (int t = HA; t < NKT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pv = exp2f((st[t][r] - m) * LOG2E);
                     st[t][r] = pv;
                     l += pv;
                 }
+            // (the V fragments of half A -- one ds_read_b32 per MFMA -- are all requested up front: read-then-use per
+            //  MFMA exposes the LDS latency 32 times)
+            __builtin_amdgcn_sched_group_barrier(0x100, 16 * HA, 0);
+#pragma unroll
+            for (int i = 0; i < 16 * HA; ++i) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 10, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            }
             l += __shfl_xor(l, 32, 64);
-            const float inv = 1.0f / l;
-            if (h < 2) TSTAMP();   // softmax done
-            // ---- O^T = V^T . P^T  (A = V column fragments from LDS, B = P from the accumulators)
+            if (h < 2) TSTAMP();   // PV(A) issued + softmax(B)
+            // ---- P.V of half B, combine
             f32x16 oT = zero16();
 #pragma unroll
-            for (int t = 0; t < NKT; ++t) {
+            for (int t = HA; t < NKT; ++t) pv_tile(t, oT);
+            {
+                const float inv = 1.0f / l;
+                const float ia = alpha * inv;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    // (WMODE 2: opaque base so the 64 clamped V addresses are not hoisted out of the head loop and spilled;
-                    //  the other variants allocate better with the plain expression)
-                    int j = (SPLIT ? j0m : j0) + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    j = j < 0 ? 0 : (j >= FP ? FP - 1 : j);
-                    oT = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[j * DH + l31], st[t][r] * inv, oT, 0, 0, 0);
-                }
-                __builtin_amdgcn_sched_barrier(0);   // keep at most one key tile of V fragments in flight
+                for (int r = 0; r < 16; ++r) oT[r] = oA[r] * ia + oT[r] * inv;
             }
             if (h < 2) TSTAMP();   // PV issued
             // ---- out^T += Wout_h^T . O^T   (A = to_out rows h*32 + d, columns n)
@@ -407,8 +446,8 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
     }
     TSTAMP();   // end
 #ifdef DAWN_TL_TIMING
-    if (tid == 0 && blockIdx.x < 4096)
-        for (int i = 0; i < 32; ++i) dawn_tl_dbg[(size_t)blockIdx.x * 32 + i] = i < tix ? tsb[i] : 0ull;
+    if (lane == 0 && blockIdx.x < 512)
+        for (int i = 0; i < 24; ++i) dawn_tl_dbg[((size_t)blockIdx.x * 8 + wave) * 24 + i] = i < tix ? tsb[wave * 24 + i] : 0ull;
 #endif
 #endif
 }

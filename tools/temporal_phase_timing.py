@@ -20,19 +20,22 @@ freqs = 10000.0 ** (-torch.arange(0, 32, 2, dtype=torch.float32) / 32)
 ang = pos[:, None] * freqs[None, :]
 rc, rs = torch.cos(ang).to(dev), torch.sin(ang).to(dev)
 band = (torch.randn(2 * win + 1, 8) * 0.1).to(dev)
-dbg = torch.zeros(4096 * 32, dtype=torch.int64, device=dev)
+dbg = torch.zeros(512 * 8 * 24, dtype=torch.int64, device=dev)
 ops.L.dawn_temporal_set_debug.argtypes = [ctypes.c_void_p]
 assert ops.L.dawn_temporal_set_debug(dbg.data_ptr()) == 0
-names = ["start", "phase0+setup", "h0 start", "h0 KV proj", "h0 barrier", "h0 Q proj", "h0 S", "h0 softmax", "h0 PV", "h0 out",
-         "h1 start", "h1 KV proj", "h1 barrier", "h1 Q proj", "h1 S", "h1 softmax", "h1 PV", "h1 out", "end (6 more heads + store)"]
+names = ["start", "phase0+setup", "h0 start", "h0 KV proj", "h0 barrier", "h0 Q proj", "h0 S(A)", "h0 S(B)+smA", "h0 PV(A)+smB", "h0 PV(B)", "h0 out",
+         "h1 start", "h1 KV proj", "h1 barrier", "h1 Q proj", "h1 S(A)", "h1 S(B)+smA", "h1 PV(A)+smB", "h1 PV(B)", "h1 out", "end (6 more heads + store)"]
 for label, s in (("fp32 (WMODE 1)", None), ("split (WMODE 2)", wqkv_s)):
     for _ in range(2):
         dbg.zero_()
         ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band, wqkv_bf3=s)
         torch.cuda.synchronize()
-    t = dbg.cpu().numpy().reshape(4096, 32).astype(np.float64)
-    n = int((t[0] != 0).sum())
-    d = np.diff(t[:, :n], axis=1)
-    print(f"--- {label}: {n} stamps; block duration mean {(t[:, n-1] - t[:, 0]).mean():.0f} cycles")
-    for i in range(n - 1):
-        print(f"  {names[i]:14s} -> {names[i+1]:28s}: {d[:, i].mean():9.0f}  (p10 {np.percentile(d[:, i], 10):8.0f}, p90 {np.percentile(d[:, i], 90):8.0f})")
+    t = dbg.cpu().numpy().reshape(512, 8, 24).astype(np.float64)
+    print(f"--- {label}: mean cycles between stamps, per wave (columns = waves 0..7; wave 7 has no query tile)")
+    for i in range(20):
+        row = []
+        for w in range(8):
+            a, b = t[:, w, i], t[:, w, i + 1]
+            ok = (a != 0) & (b != 0)
+            row.append(f"{(b[ok] - a[ok]).mean():8.0f}" if ok.any() else "       -")
+        print(f"  {names[i]:14s} -> {names[i+1][:12]:12s}: " + " ".join(row))
