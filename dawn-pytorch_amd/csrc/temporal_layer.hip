@@ -327,23 +327,30 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             int hi = __builtin_amdgcn_readfirstlane(Fext - j0 < 32 * NKT ? Fext - j0 : 32 * NKT);
             asm volatile("" : "+s"(lo), "+s"(hi));        // head-invariant: recompute the 128 penalties per head, do not keep them
             auto bias_max = [&](int t, float& m) {
+                float bz[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) bz[r] = bb[32 * t + (r & 3) + 8 * (r >> 2)];     // all 16 reads first
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = 32 * t + (r & 3) + 8 * (r >> 2);
                     const float pen0 = (c >= lo && c < hi) ? 0.f : NEG;
                     const float pen1 = (c + 4 >= lo && c + 4 < hi) ? 0.f : NEG;
-                    const float sv = st[t][r] + bb[c] + (half ? pen1 : pen0);
+                    const float sv = st[t][r] + bz[r] + (half ? pen1 : pen0);
                     st[t][r] = sv;
                     m = fmaxf(m, sv);
                 }
             };
-            auto pv_tile = [&](int t, f32x16& o) {       // o^T += V^T . P^T for key tile t (P unnormalised)
+            auto v_load = [&](int t, float (&vv)[16]) {   // the 16 V fragments of key tile t (one per MFMA), requested together
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     int j = j0m + 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
                     j = j < 0 ? 0 : (j >= FP ? FP - 1 : j);
-                    o = __builtin_amdgcn_mfma_f32_32x32x2f32(Vs[j * DH + l31], st[t][r], o, 0, 0, 0);
+                    vv[r] = Vs[j * DH + l31];
                 }
+            };
+            auto pv_tile = [&](int t, const float (&vv)[16], f32x16& o) {       // o^T += V^T . P^T (P unnormalised)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o = __builtin_amdgcn_mfma_f32_32x32x2f32(vv[r], st[t][r], o, 0, 0, 0);
             };
 #pragma unroll
             for (int t = 0; t < HA; ++t) s_tile(t);
@@ -373,8 +380,17 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             if (h < 2) TSTAMP();   // S(B) issued + softmax(A)
             // ---- P.V of half A  ||  bias + max + exp of half B (relative to the joint max)
             f32x16 oA = zero16();
+            {
+                float va[16], vb[16];
+                v_load(0, va);
 #pragma unroll
-            for (int t = 0; t < HA; ++t) pv_tile(t, oA);
+                for (int t = 0; t < HA; ++t) {
+                    if (t + 1 < HA) v_load(t + 1, vb);
+                    pv_tile(t, va, oA);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) va[r] = vb[r];
+                }
+            }
             float m = mA;
 #pragma unroll
             for (int t = HA; t < NKT; ++t) bias_max(t, m);
@@ -402,8 +418,17 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             if (h < 2) TSTAMP();   // PV(A) issued + softmax(B)
             // ---- P.V of half B, combine
             f32x16 oT = zero16();
+            if (HA < NKT) {
+                float va[16], vb[16];
+                v_load(HA, va);
 #pragma unroll
-            for (int t = HA; t < NKT; ++t) pv_tile(t, oT);
+                for (int t = HA; t < NKT; ++t) {
+                    if (t + 1 < NKT) v_load(t + 1, vb);
+                    pv_tile(t, va, oT);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) va[r] = vb[r];
+                }
+            }
             {
                 const float inv = 1.0f / l;
                 const float ia = alpha * inv;
