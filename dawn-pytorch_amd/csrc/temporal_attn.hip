@@ -45,7 +45,10 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Ks = smem;                    // [NKP][KLD]
     float* Vs = smem + NKP * KLD;        // [NKP][DH]
-    float* band_s = Vs + NKP * DH;       // [(2*win+1)][8]
+    // this head's relative-position bias as a function of idx = rel + win, padded to [-32, 32 NKT) and filled with NEG
+    // outside the window: lane l31 / register r read band_s[32 + 32t + rho(r) - l31] (conflict-free, constant offsets)
+    constexpr int BLD = 32 * NKT + 32;
+    float* band_s = Vs + NKP * DH;       // [BLD]
 
     const int tid = threadIdx.x;
     const int seg = blockIdx.x % nseg;
@@ -57,8 +60,10 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     const int qend = q0 + Fq;
 
     // ---- stage band, K (rotated), V
-    const int nb = (2 * win + 1) * HEADS;
-    for (int i = tid; i < nb; i += 256) band_s[i] = band[i];
+    for (int i = tid; i < BLD; i += 256) {
+        const int idx = i - 32;
+        band_s[i] = (idx >= 0 && idx <= 2 * win) ? band[idx * HEADS + h] : NEG;
+    }
     const float* kg = qkv + p * QKV + HEADS * DH + h * DH;
     const float* vg = qkv + p * QKV + 2 * HEADS * DH + h * DH;
     for (int i = tid; i < NKP * 8; i += 256) {
@@ -123,26 +128,32 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     // ---- bias + mask + softmax over keys (this lane's query = iq)
     const int j0 = i0 - win;
     float m = NEG;
+    // branch-free: bias (window mask folded into the table) + clip-edge penalty for key slots outside [lo, hi)
+    const float* bb = band_s + 32 - l31 + 4 * half;
+    const int lo = __builtin_amdgcn_readfirstlane(j0 < 0 ? -j0 : 0);
+    const int hi = __builtin_amdgcn_readfirstlane(Fext - j0 < 32 * NKT ? Fext - j0 : 32 * NKT);
 #pragma unroll
-    for (int t = 0; t < NKT; ++t)
+    for (int t = 0; t < NKT; ++t) {
+        float bz[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) bz[r] = bb[32 * t + (r & 3) + 8 * (r >> 2)];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int jj = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int j = j0 + jj;
-            const int rel = j - iq;
-            const bool ok = (rel >= -win) && (rel <= win) && (j >= 0) && (j < Fext);
-            const int bi = ok ? (rel + win) * HEADS + h : 0;
-            const float sv = ok ? st[t][r] + band_s[bi] : NEG;
+            const int c = 32 * t + (r & 3) + 8 * (r >> 2);
+            const float pen0 = (c >= lo && c < hi) ? 0.f : NEG;
+            const float pen1 = (c + 4 >= lo && c + 4 < hi) ? 0.f : NEG;
+            const float sv = st[t][r] + bz[r] + (half ? pen1 : pen0);
             st[t][r] = sv;
             m = fmaxf(m, sv);
         }
+    }
     m = fmaxf(m, __shfl_xor(m, 32, 64));
     float l = 0.f;
 #pragma unroll
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = expf(st[t][r] - m);
+            const float pv = exp2f((st[t][r] - m) * 1.4426950408889634f);   // == exp(s - m); one v_exp_f32
             st[t][r] = pv;
             l += pv;
         }
@@ -182,7 +193,7 @@ extern "C" int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, in
     const long nblk = (long)HW * HEADS * nseg;
     const dim3 grid((unsigned)nblk), block(256);
     const int nkp = 32 * (3 + nkt);
-    const size_t lds = ((size_t)nkp * (KLD + DH) + (size_t)(2 * win + 1) * HEADS) * sizeof(float);
+    const size_t lds = ((size_t)nkp * (KLD + DH) + (size_t)(32 * nkt + 32)) * sizeof(float);
     hipStream_t s = (hipStream_t)stream;
 #define LAUNCH_TA(N)                                                                                        \
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)temporal_attn_kernel<N>,                        \
