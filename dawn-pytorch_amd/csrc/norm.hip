@@ -52,23 +52,25 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 
 // fixed-order (deterministic) column sums of part[nblk][16]; 1024 threads: column t&15, row phase t>>4 (64 phases),
 // four independent accumulators per thread so that the loads of a phase are in flight together.
+template <int NT>
 __device__ __forceinline__ void gn_reduce_block(const double* __restrict__ part, int nblk, double* sh, double* out16) {
+    constexpr int NP = NT / 16;                      // row phases
     const int t = threadIdx.x;
     const int c = t & 15, r = t >> 4;
     double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
     int b = r;
-    for (; b + 192 < nblk; b += 256) {
+    for (; b + 3 * NP < nblk; b += 4 * NP) {
         a0 += part[(long)b * 16 + c];
-        a1 += part[(long)(b + 64) * 16 + c];
-        a2 += part[(long)(b + 128) * 16 + c];
-        a3 += part[(long)(b + 192) * 16 + c];
+        a1 += part[(long)(b + NP) * 16 + c];
+        a2 += part[(long)(b + 2 * NP) * 16 + c];
+        a3 += part[(long)(b + 3 * NP) * 16 + c];
     }
-    for (; b < nblk; b += 64) a0 += part[(long)b * 16 + c];
+    for (; b < nblk; b += NP) a0 += part[(long)b * 16 + c];
     sh[t] = (a0 + a1) + (a2 + a3);
     __syncthreads();
     if (t < 16) {
         double s = 0.0;
-        for (int k = 0; k < 64; ++k) s += sh[k * 16 + t];
+        for (int k = 0; k < NP; ++k) s += sh[k * 16 + t];
         out16[t] = s;
     }
     __syncthreads();
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(1024) void gn_reduce_kernel(const double* __restric
                                                          double* __restrict__ sums) {
     __shared__ double sh[1024];
     __shared__ double res[16];
-    gn_reduce_block(part, nblk, sh, res);
+    gn_reduce_block<1024>(part, nblk, sh, res);
     if (threadIdx.x < 16) sums[threadIdx.x] = res[threadIdx.x];
 }
 
@@ -103,16 +105,18 @@ __device__ __forceinline__ void gn_coeff(const double* sums, double count, const
 }
 
 // single-GPU fast path: reduce + finalize in one launch
-__global__ __launch_bounds__(1024) void gn_reduce_finalize_kernel(const double* __restrict__ part, int nblk, double count,
+// (256 threads = one wave per SIMD: a 16-wave workgroup was often not placed while the persistent cross-attention kernel
+//  of the other stream was resident and waited for that kernel to end -- 400 us instead of 10)
+__global__ __launch_bounds__(256) void gn_reduce_finalize_kernel(const double* __restrict__ part, int nblk, double count,
                                                                  const float* __restrict__ gamma,
                                                                  const float* __restrict__ beta,
                                                                  const float* __restrict__ fs,
                                                                  const float* __restrict__ fsh, int C, float eps,
                                                                  float* __restrict__ a, float* __restrict__ b) {
-    __shared__ double sh[1024];
+    __shared__ double sh[256];
     __shared__ double res[16];
-    gn_reduce_block(part, nblk, sh, res);
-    for (int c = threadIdx.x; c < C; c += 1024) gn_coeff(res, count, gamma, beta, fs, fsh, C, eps, a, b, c);
+    gn_reduce_block<256>(part, nblk, sh, res);
+    for (int c = threadIdx.x; c < C; c += 256) gn_coeff(res, count, gamma, beta, fs, fsh, C, eps, a, b, c);
 }
 
 __global__ void gn_finalize_kernel(const double* __restrict__ sums, double count, const float* __restrict__ gamma,
@@ -216,7 +220,7 @@ extern "C" int dawn_gn_finalize(const double* sums16, double count_per_group, co
 extern "C" int dawn_gn_reduce_finalize(const double* part, int nblk, double count_per_group, const float* gamma,
                                        const float* beta, const float* film_scale, const float* film_shift, int C,
                                        float eps, float* a, float* b, void* stream) {
-    hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, part, nblk,
+    hipLaunchKernelGGL(gn_reduce_finalize_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, part, nblk,
                        count_per_group, gamma, beta, film_scale, film_shift, C, eps, a, b);
     DAWN_LAUNCH_CHECK();
     return 0;
