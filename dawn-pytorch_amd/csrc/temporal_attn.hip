@@ -130,8 +130,10 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     float m = NEG;
     // branch-free: bias (window mask folded into the table) + clip-edge penalty for key slots outside [lo, hi)
     const float* bb = band_s + 32 - l31 + 4 * half;
-    const int lo = __builtin_amdgcn_readfirstlane(j0 < 0 ? -j0 : 0);
-    const int hi = __builtin_amdgcn_readfirstlane(Fext - j0 < 32 * NKT ? Fext - j0 : 32 * NKT);
+    const int lo = j0 < 0 ? -j0 : 0;
+    const int hi = Fext - j0 < 32 * NKT ? Fext - j0 : 32 * NKT;
+    const int vbase = 4 * half - lo;                 // slot - lo for register offset 0 of this lane's k-half
+    const unsigned span = (unsigned)(hi - lo);
 #pragma unroll
     for (int t = 0; t < NKT; ++t) {
         float bz[16];
@@ -140,9 +142,8 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int c = 32 * t + (r & 3) + 8 * (r >> 2);
-            const float pen0 = (c >= lo && c < hi) ? 0.f : NEG;
-            const float pen1 = (c + 4 >= lo && c + 4 < hi) ? 0.f : NEG;
-            const float sv = st[t][r] + bz[r] + (half ? pen1 : pen0);
+            const bool ok = (unsigned)(vbase + c) < span;        // lo <= key slot < hi: a frame of the clip
+            const float sv = ok ? st[t][r] + bz[r] : NEG;
             st[t][r] = sv;
             m = fmaxf(m, sv);
         }
@@ -153,7 +154,7 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
     for (int t = 0; t < NKT; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const float pv = exp2f((st[t][r] - m) * 1.4426950408889634f);   // == exp(s - m); one v_exp_f32
+            const float pv = __builtin_amdgcn_exp2f((st[t][r] - m) * 1.4426950408889634f);   // == exp(s - m); one v_exp_f32
             st[t][r] = pv;
             l += pv;
         }

@@ -323,9 +323,11 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             // scores += bias (window mask folded into the table) + clip-edge penalty, running max.  Branch-free: the keys
             // of this wave are slots s = 32t + rho in [0, 32 NKT); those outside [lo, hi) are not frames of the clip.
             // lo / hi are wave-uniform, so the per-slot test is scalar and only the k-half select is per lane.
-            int lo = __builtin_amdgcn_readfirstlane(j0 < 0 ? -j0 : 0);
-            int hi = __builtin_amdgcn_readfirstlane(Fext - j0 < 32 * NKT ? Fext - j0 : 32 * NKT);
-            asm volatile("" : "+s"(lo), "+s"(hi));        // head-invariant: recompute the 128 penalties per head, do not keep them
+            const int lo = j0 < 0 ? -j0 : 0;
+            const int hi = Fext - j0 < 32 * NKT ? Fext - j0 : 32 * NKT;
+            int vbase = 4 * half - lo;                    // slot - lo for register offset 0 of this lane's k-half
+            asm volatile("" : "+v"(vbase));               // head-invariant: do not keep 64 compare masks across heads
+            const unsigned span = (unsigned)(hi - lo);
             auto bias_max = [&](int t, float& m) {
                 float bz[16];
 #pragma unroll
@@ -333,9 +335,8 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int c = 32 * t + (r & 3) + 8 * (r >> 2);
-                    const float pen0 = (c >= lo && c < hi) ? 0.f : NEG;
-                    const float pen1 = (c + 4 >= lo && c + 4 < hi) ? 0.f : NEG;
-                    const float sv = st[t][r] + bz[r] + (half ? pen1 : pen0);
+                    const bool ok = (unsigned)(vbase + c) < span;                              // lo <= slot < hi
+                    const float sv = ok ? st[t][r] + bz[r] : NEG;
                     st[t][r] = sv;
                     m = fmaxf(m, sv);
                 }
@@ -367,7 +368,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
             for (int t = 0; t < HA; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = exp2f((st[t][r] - mA) * LOG2E);     // == exp(s - m); one v_exp_f32
+                    const float pv = __builtin_amdgcn_exp2f((st[t][r] - mA) * LOG2E);     // == exp(s - m); one v_exp_f32
                     st[t][r] = pv;
                     lA += pv;
                 }
@@ -395,13 +396,13 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
 #pragma unroll
             for (int t = HA; t < NKT; ++t) bias_max(t, m);
             m = fmaxf(m, __shfl_xor(m, 32, 64));
-            const float alpha = exp2f((mA - m) * LOG2E);                 // rescale of half A (1 when the max did not move)
+            const float alpha = __builtin_amdgcn_exp2f((mA - m) * LOG2E);                 // rescale of half A (1 when the max did not move)
             float l = lA * alpha;
 #pragma unroll
             for (int t = HA; t < NKT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const float pv = exp2f((st[t][r] - m) * LOG2E);
+                    const float pv = __builtin_amdgcn_exp2f((st[t][r] - m) * LOG2E);
                     st[t][r] = pv;
                     l += pv;
                 }
