@@ -245,6 +245,15 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
         for (int rt = wave; rt < nrt; rt += 8) {
             const int j = 32 * rt + l31;
             const float* xr = Xs + j * XLD + 4 * half;
+            // rotary cos/sin of this lane's key row: requested BEFORE the projection MFMAs (they were loaded at the
+            // point of use, four exposed L1/L2 round trips per head)
+            const int jc = j < Fext ? j : Fext - 1;
+            float2 kcs[4], ksn[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                kcs[c] = *reinterpret_cast<const float2*>(rcos + jc * 16 + 4 * c + 2 * half);
+                ksn[c] = *reinterpret_cast<const float2*>(rsin + jc * 16 + 4 * c + 2 * half);
+            }
             f32x16 kT, vT;
             if (SPLIT) {
                 const unsigned char* xp = reinterpret_cast<const unsigned char*>(Xs) + ((size_t)half * FP + j) * 16;
@@ -253,11 +262,10 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
                 kT = proj_T(wk_p, wN, l31, half, xr);
                 vT = proj_T(wv_p, wN, l31, half, xr);
             }
-            const int jc = j < Fext ? j : Fext - 1;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const float2 cc = *reinterpret_cast<const float2*>(rcos + jc * 16 + 4 * c + 2 * half);
-                const float2 sn = *reinterpret_cast<const float2*>(rsin + jc * 16 + 4 * c + 2 * half);
+                const float2 cc = kcs[c];
+                const float2 sn = ksn[c];
                 f32x4 k4;
                 k4.x = kT[4 * c] * cc.x - kT[4 * c + 1] * sn.x;
                 k4.y = kT[4 * c + 1] * cc.x + kT[4 * c] * sn.x;
