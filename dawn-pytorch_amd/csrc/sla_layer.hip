@@ -257,7 +257,7 @@ __global__ __launch_bounds__(512) void sla_c64_context_bf16_kernel(const float* 
         tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
         const float mnew = fmaxf(mx, tm);
         if (__builtin_amdgcn_ballot_w64(mnew > mx) != 0ull) {      // rare after the first tiles: rescale ctx rows / den
-            const float alpha = expf(mx - mnew);                   // lane l31 = d (exp(-inf) = 0 on the first tile)
+            const float alpha = __builtin_amdgcn_exp2f((mx - mnew) * 1.4426950408889634f);   // lane l31 = d (0 on the first tile)
             den *= alpha;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(512) void sla_c64_context_bf16_kernel(const float* 
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float e = n < HW ? expf(kt[r] - mx) : 0.f;
+            const float e = n < HW ? __builtin_amdgcn_exp2f((kt[r] - mx) * 1.4426950408889634f) : 0.f;     // one v_exp_f32
             kt[r] = e;
             den += e;
         }
@@ -379,11 +379,11 @@ __global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* __restr
             float l = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                qT[r] = expf(qT[r] - m);
+                qT[r] = __builtin_amdgcn_exp2f((qT[r] - m) * 1.4426950408889634f);   // one v_exp_f32
                 l += qT[r];
             }
             l += __shfl_xor(l, 32, 64);
-            const float inv = scale / l;
+            const float inv = scale * __builtin_amdgcn_rcpf(l);
             // out^T (64 n x 32 px) += M_h^T (n x d) . q^T (d x px): A = M frags (LDS), B = q^T registers
 #pragma unroll
             for (int nt = 0; nt < 2; ++nt)
