@@ -46,7 +46,7 @@ __global__ __launch_bounds__(256) void sla_context_kernel(const float* __restric
         __syncthreads();
 #pragma unroll 8
         for (int n = 0; n < CH; ++n) {
-            const float e = expf(ks[n][d] - mx);
+            const float e = __builtin_amdgcn_exp2f((ks[n][d] - mx) * 1.4426950408889634f);
             const f32x4 v4 = *reinterpret_cast<const f32x4*>(&vs[n][eg * 4]);
             den += e;
             acc[0] += e * v4.x; acc[1] += e * v4.y; acc[2] += e * v4.z; acc[3] += e * v4.w;
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void sla_apply_kernel(const float* __restrict_
         const long row = (long)f * HW + n;
         const float qv = qkv[row * QKV + h * DH + e];
         const float mx = wave_max(qv, 32);
-        const float ex = expf(qv - mx);
+        const float ex = __builtin_amdgcn_exp2f((qv - mx) * 1.4426950408889634f);
         const float sm = wave_sum(ex, 32);
         const float qn = ex / sm * 0.17677669529663687f;
         float acc = 0.f;
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(64) void frame_attn_kernel(const float* __restrict_
 #pragma unroll
             for (int d = 0; d < DH; ++d) s += q[d] * ks[j * DH + d];
             const float mn = fmaxf(m, s);
-            const float corr = expf(m - mn);
-            const float pj = expf(s - mn);
+            const float corr = __builtin_amdgcn_exp2f((m - mn) * 1.4426950408889634f);
+            const float pj = __builtin_amdgcn_exp2f((s - mn) * 1.4426950408889634f);
             l = l * corr + pj;
 #pragma unroll
             for (int d = 0; d < DH; ++d) o[d] = o[d] * corr + pj * vs[j * DH + d];
