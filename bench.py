@@ -245,13 +245,14 @@ def main():
                  "algorithmic_flops_per_launch_avg": flops / len(entries), "algorithmic_tflops": alg,
                  "share_of_conv_time": None}
             if split:
-                r.update({"kernel": "conv3x3_bf16_v2_kernel (3x3 ResBlock convs: fp32 operands split exactly into 3 bf16 "
-                                    "pieces, 6 cross terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
+                r.update({"kernel": "conv3x3_bf16_v2_kernel + gemm1x1_bf16_kernel (3x3 ResBlock convs and the large 1x1 "
+                                    "projections: fp32 operands split exactly into 3 bf16 pieces, 6 cross terms on "
+                                    "v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
                           "achieved": 6.0 * alg, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": 6.0 * alg / PEAK_BF16_MFMA_TFLOPS,
                           "executed_flops_per_algorithmic_flop": 6,
                           "note": "achieved = executed bf16 MFMA rate; algorithmic_tflops = 2*M*N*K / time"})
             else:
-                r.update({"kernel": "conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA implicit GEMM: 1x1, 4x4/s2, "
+                r.update({"kernel": "conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA implicit GEMM: small 1x1, 4x4/s2, "
                                     "transposed 4x4, 7x7)",
                           "achieved": alg, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": alg / PEAK_FP32_MFMA_TFLOPS})
             return r, t_ms

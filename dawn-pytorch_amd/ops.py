@@ -136,13 +136,26 @@ class HipOps:
             self.prof.append((2.0 * rows_gemm * N * KH * KW * (d.C0 + d.C1), e0, e1,
                               f"M={rows_gemm} N={N} K={KH * KW * (d.C0 + d.C1)} k={KH}x{KW} s={stride} mode={mode} "
                               f"pro={'r' if row_stats else ''}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}"
-                              + (" split-bf16" if w_bf3 is not None else ""),
+                              + (" split-bf16" if self._runs_split_kernel(w_bf3, KH, KW, stride, mode, rows_out, N, d.C0, d.C1, tr,
+                                                                          gn_part) else ""),
                               4.0 * (F * Hi * Wi * (d.C0 + d.C1) + rows_out * N + KH * KW * (d.C0 + d.C1) * N * (4 if mode else 1))))
             return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
         if gn_part is not None:
             gn_part.dawn_rows = nrows.value      # rows the launch wrote (the rest of the buffer is unused)
         return out
+
+    @staticmethod
+    def _runs_split_kernel(w_bf3, KH, KW, stride, mode, rows, N, C0, C1, tr, gn_part) -> bool:
+        """Profiling label only: does this launch take a split-operand (bf16 pipe) kernel?  Mirrors the dispatch
+        conditions of dawn_conv_gemm for the shapes of the benchmark (3x3/s1 ResBlock convs; 1x1 GEMMs with
+        M >= 51200, M % 256 == 0, N % 128 == 0, K % 32 == 0, one source, no tr epilogue / GroupNorm sums)."""
+        if w_bf3 is None or mode != 0 or stride != 1:
+            return False
+        if KH == 3 and KW == 3:
+            return True
+        return (KH == 1 and KW == 1 and rows >= 51200 and rows % 256 == 0 and N % 128 == 0 and C1 == 0 and C0 % 32 == 0
+                and tr is None and gn_part is None)
 
     # ------------------------------------------------------------------ GroupNorm / LayerNorm
     def conv_gn_part(self, rows_out: int, N: int, like: Tensor) -> Tensor:

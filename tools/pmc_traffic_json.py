@@ -24,7 +24,7 @@ def sums(path, counter):
 
 def main():
     fetch, write = sums(sys.argv[1], "FETCH_SIZE"), sums(sys.argv[2], "WRITE_SIZE")
-    is_conv = lambda k: k.startswith("conv_gemm") or k.startswith("conv3x3")
+    is_conv = lambda k: k.startswith("conv_gemm") or k.startswith("conv3x3") or k.startswith("gemm1x1")
     n = sum(v[0] for k, v in fetch.items() if is_conv(k))
     f = sum(v[1] for k, v in fetch.items() if is_conv(k))
     w = sum(v[1] for k, v in write.items() if is_conv(k))
