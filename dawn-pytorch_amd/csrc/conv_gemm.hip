@@ -27,8 +27,8 @@ namespace {
 // the loop is bound by the per-CU fetch rate, not by load latency), 0x800 LDS-halo kernel for prologue-free
 // 3x3/s1/p1 convs whose tile geometry fits (+5..19 %, profiles/r1_l_conv_halo.txt), 0x1000 split-operand bf16
 // MFMA version of that kernel when the caller supplies w_bf3 (6 cross terms; 0x2000: all 9), 0x4000 its second
-// generation (conv3x3_bf16_v2_kernel: +5..20 %, profiles/r1_n_conv_bf16.txt), 0x10/0x20 and bits 16-19 perf
-// ablations / the s_memtime build.
+// generation (conv3x3_bf16_v2_kernel: +5..20 %, profiles/r1_n_conv_bf16.txt), 0x10/0x20 fp32-kernel perf ablations,
+// (8 << 16) the s_memtime build of the split kernel.
 static int g_variant = 0x580D;
 static thread_local int g_last_nwg = 0;   // gridDim.x of the last launch (= rows of gn_part it writes)
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
@@ -823,7 +823,7 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& p1, uint2& p2, uint
     p3 = *reinterpret_cast<uint2*>(&h3);
 }
 
-template <int BN, int WN, int NT, int ABL>
+template <int BN, int WN, int NT>
 __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_desc d, const int xcd_remap,
                                                                 const int TR, const int nf, const int P16) {
     constexpr int BM = 64 * (4 / WN);
@@ -947,7 +947,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_
     int bufB = 0;
     for (int cc = 0; cc < nC; ++cc) {
         __syncthreads();            // raw(cc) and the first weight chunk have landed; planes are free
-        if (!(ABL & 4) || cc == 0) split_pass();
+        split_pass();
         __syncthreads();
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
@@ -956,7 +956,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_
             {
                 int ntap = tap + 1, ncc = cc;
                 if (ntap == 9) { ntap = 0; ncc = cc + 1; }
-                if (ncc < nC && !((ABL & 1) && (cc || tap))) issueB(ntap * nC + ncc, bufB ^ 1);
+                if (ncc < nC) issueB(ntap * nC + ncc, bufB ^ 1);
             }
             bool issuedA = false;
             if (tap < MAXS && cc + 1 < nC) issuedA = issueA(cc + 1, tap);
@@ -983,7 +983,7 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i][PA9[t]], b[j][PB9[t]], acc[i][j], 0, 0, 0);
-            if (tap < 8 && !(ABL & 2)) {
+            if (tap < 8) {
                 if (issuedA) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
                 else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -1205,14 +1205,14 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();                   // planes(cc) written, weight stage (cc, 0) landed
         TSTAMP();   // chunk top
-        const bool more = cc + 1 < nC && !(ABL & 4);
+        const bool more = cc + 1 < nC;
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
             // prefetch: the next weight stage, then (stages 0, 1) the next chunk's patch quads
             {
                 int nky = ky + 1, ncc = cc;
                 if (nky == 3) { nky = 0; ncc = cc + 1; }
-                if (ncc < nC && !(ABL & 2)) issueB(ncc, nky, bufB ^ 1);
+                if (ncc < nC) issueB(ncc, nky, bufB ^ 1);
             }
             if (more) {
 #pragma unroll
@@ -1266,7 +1266,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
                 }
             }
             TSTAMP();   // stage: MFMAs issued
-            if (ky < 2 && !(ABL & 1)) {
+            if (ky < 2) {
                 // (the register operands pin the split of these quads behind the wait)
                 if (MAXQ == 7)
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
@@ -1597,22 +1597,16 @@ bool try_launch_halo_bf16(const dawn_conv_desc& d, long M, hipStream_t s, bool n
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * dawn_cdiv(d.N, BN);
     const int remap = ((g_variant & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
-    const int abl = (g_variant >> 16) & 7;
-#define LAUNCH_BF(NTV, ABLV)                                                                                        \
-    do {                                                                                                            \
-        (void)hipFuncSetAttribute((const void*)conv3x3_halo_bf16_kernel<BN, WN, NTV, ABLV>,                         \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                            \
-        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, WN, NTV, ABLV>), dim3(nwg), dim3(256), lds, s, d, remap, TR, \
-                           nf, P16);                                                                                \
-    } while (0)
     g_last_nwg = nwg;
-    if (nine) LAUNCH_BF(9, 0);
-    else if (abl == 1) LAUNCH_BF(6, 1);
-    else if (abl == 2) LAUNCH_BF(6, 2);
-    else if (abl == 4) LAUNCH_BF(6, 4);
-    else if (abl == 7) LAUNCH_BF(6, 7);
-    else LAUNCH_BF(6, 0);
-#undef LAUNCH_BF
+    if (nine) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_bf16_kernel<BN, WN, 9>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, WN, 9>), dim3(nwg), dim3(256), lds, s, d, remap, TR, nf, P16);
+    } else {
+        (void)hipFuncSetAttribute((const void*)conv3x3_halo_bf16_kernel<BN, WN, 6>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+        hipLaunchKernelGGL((conv3x3_halo_bf16_kernel<BN, WN, 6>), dim3(nwg), dim3(256), lds, s, d, remap, TR, nf, P16);
+    }
     return true;
 }
 

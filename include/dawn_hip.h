@@ -64,7 +64,8 @@ int dawn_conv_gemm_nblocks(long M, int N);
 /* tuning knob for A/B measurements and tests (default 0x580D = shipped policy): bit0 BK=32 tiles, bit1 256x64 tile for
  * N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel, 0x1000 split-operand
  * (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000 second-generation split
- * 3x3 kernel; bits 16-19 select perf ablations / the s_memtime-instrumented build (tools/conv_phase_timing.py). */
+ * 3x3 kernel; 0x10/0x20 fp32-kernel perf ablations; (8 << 16) selects the s_memtime-instrumented build of the split
+ * 3x3 kernel (tools/conv_phase_timing.py). */
 void dawn_conv_set_variant(int v);
 /* instrumented build only: device buffer (4096 x 64 uint64) receiving the per-phase s_memtime stamps */
 int dawn_conv_set_debug(void* device_buffer);
