@@ -91,3 +91,23 @@ def test_product_path_fails_loudly_without_gpu(tiny):
     with pytest.raises(Exception) as ei:
         unet.forward_with_cond_scale(T(g["x"]), T(g["time"]), cond=T(g["cond"]), cond_scale=1.0)
     assert "fallback" in str(ei.value) or "libdawn_hip" in str(ei.value)
+
+
+def test_pack_bf3_is_an_exact_three_way_split():
+    """pack_bf3 (host side of the split-operand kernels): the three bf16 planes sum EXACTLY to the fp32 weight,
+    each plane is the round-to-nearest-even bf16 of the running residual, and the layout is [K/16][3][2][N][8]
+    with k = 16*chunk + 8*half + e  (csrc/conv_gemm.hip reads plane p / k-half h / column n at ((c*3+p)*2+h)*N+n)."""
+    from dawn_pytorch_amd.pack import pack_bf3
+    g = torch.Generator().manual_seed(7)
+    K, N = 48, 20
+    w = torch.randn(K, N, generator=g) * torch.logspace(-6, 3, N)[None, :]        # nine decades of magnitude
+    p = pack_bf3(w)
+    assert p.dtype == torch.int16 and tuple(p.shape) == (K // 16, 3, 2, N, 8)
+    planes = p.view(torch.bfloat16).float()                                       # (K/16, 3, 2, N, 8)
+    rec = planes.permute(1, 0, 2, 4, 3).reshape(3, K, N)                           # plane, k = 16c + 8h + e, n
+    assert torch.equal(rec[0], w.to(torch.bfloat16).float())
+    r1 = w - rec[0]
+    assert torch.equal(rec[1], r1.to(torch.bfloat16).float())
+    assert torch.equal(rec[2], (r1 - rec[1]).to(torch.bfloat16).float())
+    # fp32 has a 24-bit significand = 3 x 8 bits: the split is exact (up to bf16 subnormal flushing, absent here)
+    assert torch.equal(rec[0].double() + rec[1].double() + rec[2].double(), w.double())
