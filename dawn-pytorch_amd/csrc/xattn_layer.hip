@@ -13,6 +13,11 @@
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 
+#ifdef DAWN_XA_TIMING
+__device__ unsigned long long* dawn_xa_dbg = nullptr;
+extern "C" int dawn_xattn_set_debug(void* p) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(dawn_xa_dbg), &p, sizeof(p)); }
+#endif
+
 namespace {
 
 constexpr int CO = 64;
@@ -58,7 +63,15 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
 
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
+#ifdef DAWN_XA_TIMING
+    unsigned long long* tsb = reinterpret_cast<unsigned long long*>(smem + 28160);   // byte 112640.. (CIN = 64 build only)
+    int tix = 0, titer = 0;
+#define TSTAMP() do { if (lane == 0 && titer == 1 && tix < 24) tsb[wave * 24 + tix++] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define TSTAMP() do { } while (0)
+#endif
     for (long t = (long)blockIdx.x * 8 + wave; t < ntiles; t += (long)gridDim.x * 8) {
+        TSTAMP();   // tile start
         const long row = t * 32 + l31;
         const long rc = row < rows ? row : rows - 1;
         // ---- x fragments + LayerNorm (biased variance, eps) in registers
@@ -83,6 +96,7 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
         const float rs = __builtin_amdgcn_rsqf(ss * (1.0f / CIN) + eps);
 #pragma unroll
         for (int c = 0; c < NC; ++c) xn[c] = xn[c] * rs;
+        TSTAMP();   // x loaded + LayerNorm
 
         // the frame's [null | condition] k/v table -> this wave's LDS copy (no global-load latency in the head loops);
         // a 32-pixel tile lies in one frame whenever HW % 32 == 0, otherwise fall back to per-lane global reads
@@ -109,12 +123,15 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
             for (int tt = 0; tt < 2; ++tt) {
                 // ---- Q^T tile: features 64b + 32tt + {0..31}
                 f32x16 acc = zz16();
+                f32x4 wq4[NC];                        // all weight fragments of the tile requested before the MFMA chain
+#pragma unroll
+                for (int c = 0; c < NC; ++c)
+                    wq4[c] = *reinterpret_cast<const f32x4*>(Wq + ((2 * c + half) * 192 + 64 * b + 32 * tt + l31) * 4);
 #pragma unroll
                 for (int c = 0; c < NC; ++c) {
-                    const f32x4 w4 = *reinterpret_cast<const f32x4*>(Wq + ((2 * c + half) * 192 + 64 * b + 32 * tt + l31) * 4);
 #pragma unroll
                     for (int s2 = 0; s2 < 4; ++s2)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s2], xn[c][s2], acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq4[c][s2], xn[c][s2], acc, 0, 0, 0);
                 }
                 // ---- 2-key cosine-sim attention per head (head = 4tt + c4; lane holds features 4half..4half+3)
 #pragma unroll
@@ -137,24 +154,28 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
                     acc[4 * c4 + 3] = vn4.w + ac * (vc4.w - vn4.w);
                 }
                 qT[tt] = acc;
+                TSTAMP();   // Q tile tt + its 4 heads
             }
             // ---- y^T (64 co x 32 px) = Wo_b^T . o^T, then LayerNorm over co and accumulate with gain g3[b]
             f32x16 yT[2];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 f32x16 acc = zz16();
+                f32x4 wo4[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    wo4[e] = *reinterpret_cast<const f32x4*>(Wo + ((b * 16 + 2 * e + half) * CO + 32 * ot + l31) * 4);
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt)
 #pragma unroll
                     for (int c4 = 0; c4 < 4; ++c4) {
-                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(
-                            Wo + ((b * 16 + 8 * tt + 2 * c4 + half) * CO + 32 * ot + l31) * 4);
 #pragma unroll
                         for (int s2 = 0; s2 < 4; ++s2)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s2], qT[tt][4 * c4 + s2], acc, 0, 0, 0);
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wo4[4 * tt + c4][s2], qT[tt][4 * c4 + s2], acc, 0, 0, 0);
                     }
                 yT[ot] = acc;
             }
+            TSTAMP();   // to_out MFMAs issued
             float ys = 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) ys += yT[0][r] + yT[1][r];
@@ -176,6 +197,7 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
 #pragma unroll
                     for (int j = 0; j < 4; ++j) hc[ot][4 * g + j] += (yT[ot][4 * g + j] - ym) * yr * g4[j];
                 }
+            TSTAMP();   // branch LayerNorm + accumulate
         }
         if (row < rows) {
             float* orow = out + row * CO;
@@ -186,7 +208,15 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
                     *reinterpret_cast<f32x4*>(orow + 32 * ot + 8 * g + 4 * half) =
                         f32x4{hc[ot][4 * g], hc[ot][4 * g + 1], hc[ot][4 * g + 2], hc[ot][4 * g + 3]};
         }
+        TSTAMP();   // stored
+#ifdef DAWN_XA_TIMING
+        ++titer;
+#endif
     }
+#ifdef DAWN_XA_TIMING
+    if (lane == 0 && blockIdx.x < 256)
+        for (int i = 0; i < 24; ++i) dawn_xa_dbg[((size_t)blockIdx.x * 8 + wave) * 24 + i] = i < tix ? tsb[wave * 24 + i] : 0ull;
+#endif
 }
 
 }  // namespace
@@ -203,7 +233,11 @@ extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const flo
     const long ntiles = (rows + 31) / 32;
     long grid = (ntiles + 7) / 8;
     if (grid > 256) grid = 256;                 // one resident block per CU (LDS-bound): every block gets the same tile count
+#ifdef DAWN_XA_TIMING
+    const int lds = Cin == 64 ? 116736 : ((Cin / 4) * 192 * 4 + 3 * 16 * 64 * 4 + 272) * 4;
+#else
     const int lds = ((Cin / 4) * 192 * 4 + 3 * 16 * 64 * 4 + 272 + (Cin == 64 ? 8 * 384 : 0)) * 4;
+#endif
     if (Cin == 64) {
         (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(xattn_c64_kernel<64>, dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows, HW,
