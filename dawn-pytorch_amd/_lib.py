@@ -72,6 +72,10 @@ SIGNATURES = {
     "dawn_ddim_update": [c_f, c_f, c_f, c_f, _f, _f, _f, _l, c_f, c_f],
     "dawn_cfg_combine": [c_f, c_f, _f, _l, c_f, c_f],
     "dawn_philox_normal": [c_f, _i, _i, _i, _i, _i, C.c_uint64, C.c_uint32, c_f],
+    "dawn_affine_act": [c_f, _i, c_f, c_f, _i, c_f, _l, _i, c_f],
+    "dawn_bn_relu_pool2": [c_f, c_f, c_f, c_f, _i, _i, _i, _i, c_f],
+    "dawn_warp_blend": [c_f, _i, _i, _i, c_f, _l, c_f, _i, _i, _i, c_f, c_f, c_f, _i, c_f, c_f],
+    "dawn_final_conv_blend": [c_f, _i, _i, _i, _i, c_f, c_f, c_f, c_f, _l, c_f, _i, _i, c_f, c_f, _l, c_f],
 }
 
 _lib = None

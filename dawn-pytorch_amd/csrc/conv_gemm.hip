@@ -1049,7 +1049,8 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_
 //  issuing loads and 2400 in the split pass next to 3 x 2300 cycles of MFMA.)
 template <int WN, int NT, int ABL>
 __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_conv_desc d, const int xcd_remap,
-                                                                    const int TR, const int nf, const int P16) {
+                                                                    const int TR, const int nf, const int P16,
+                                                                    const int WT) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; buffer-resource builtins are device-only)
     constexpr int NTHR = 256 * WN, BM = 256, BN = 64 * WN;
     constexpr int TM = 2, TN = 2;
@@ -1078,7 +1079,9 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int H = d.Hi, W = d.Wi, PW = W + 2, PP = (TR + 2) * PW;
+    // tile = TR rows x WT columns of one frame (WT == W: whole rows, possibly nf whole small frames; WT < W: the wide
+    // images of the flow decoder are cut into column tiles so that the halo patch stays (TR+2) x (WT+2))
+    const int H = d.Hi, W = d.Wi, PW = WT + 2, PP = (TR + 2) * PW;
     const int Cin = d.C0 + d.C1;
     const int nC = Cin / 16;
     const int nNt = d.N / BN;
@@ -1090,10 +1093,13 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
         bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
     const int mt = bid / nNt, nt = bid - mt * nNt;
-    const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
-    const int f0 = (int)(m0 / ((long)H * W));
-    const int y0 = (int)((m0 - (long)f0 * H * W) / W);
+    const int ncx = W / WT;
+    const int band = mt / ncx;
+    const int x0 = (mt - band * ncx) * WT;
+    const int grow0 = band * (BM / WT);                 // first image row of the tile, counted over all frames
+    const int f0 = grow0 / H;
+    const int y0 = grow0 - f0 * H;
     TSTAMP();   // 0: start
 
     // ---- buffer descriptors: the patch window of each source (first pixel = row y0-1 of frame f0), the weights
@@ -1108,7 +1114,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
 
     // ---- this thread's patch quads: q = tid + NTHR*i -> (pos = q>>2, 4-channel slot = q&3); rel = window pixel
     const int nq = P16 * 4;
-    const float rPP = 1.0f / (float)PP, rPW = 1.0f / (float)PW, rTW = 1.0f / (float)(TR * W), rW = 1.0f / (float)W;
+    const float rPP = 1.0f / (float)PP, rPW = 1.0f / (float)PW, rTW = 1.0f / (float)(TR * WT), rW = 1.0f / (float)WT;
     int rel[MAXQ];
 #pragma unroll
     for (int i = 0; i < MAXQ; ++i) {
@@ -1119,7 +1125,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
             const int fi = (int)(((float)pos + 0.5f) * rPP);
             const int rem = pos - fi * PP;
             const int pyy = (int)(((float)rem + 0.5f) * rPW), pxx = rem - pyy * PW;
-            const int y = y0 + pyy - 1, x = pxx - 1;
+            const int y = y0 + pyy - 1, x = x0 + pxx - 1;
             if (y >= 0 && y < H && x >= 0 && x < W) r = fi * H * W + pyy * W + x;
         }
         rel[i] = r;
@@ -1129,8 +1135,8 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
     for (int i = 0; i < TM; ++i) {
         const int r = wm * 64 + i * 32 + l31;
         const int fi = (int)(((float)r + 0.5f) * rTW);
-        const int rem = r - fi * TR * W;
-        const int ty = (int)(((float)rem + 0.5f) * rW), x = rem - ty * W;
+        const int rem = r - fi * TR * WT;
+        const int ty = (int)(((float)rem + 0.5f) * rW), x = rem - ty * WT;
         pc[i] = fi * PP + (ty + 1) * PW + (x + 1);
     }
     // weight DMA lane offsets (bytes) within a (chunk cc, kernel row ky) stage
@@ -1302,6 +1308,15 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) { gs[j][g] = 0.f; gss[j][g] = 0.f; }
+    long mrow[TM];                                      // output pixel (row of the (M, N) result) of this lane
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = wm * 64 + i * 32 + l31;
+        const int fi = (int)(((float)r + 0.5f) * rTW);
+        const int rem = r - fi * TR * WT;
+        const int ty = (int)(((float)rem + 0.5f) * rW), x = rem - ty * WT;
+        mrow[i] = ((long)(f0 + fi) * H + y0 + ty) * W + x0 + x;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -1311,7 +1326,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
             if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-                const long m = m0 + wm * 64 + i * 32 + l31;
+                const long m = mrow[i];
                 f32x4 v = f32x4{acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]} + bv;
                 if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
                 if (d.tr) {
@@ -1373,14 +1388,17 @@ template <int WN>
 bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nine) {
     constexpr int BM = 256, BN = 64 * WN;
     const int H = d.Hi, W = d.Wi;
-    if (M % BM != 0 || W > BM || BM % W != 0 || d.C0 % 16 != 0 || d.C1 % 16 != 0 || d.N % BN != 0) return false;
+    // tile width: whole image rows up to W = 64 (every level of the denoiser); wider images (the flow decoder's
+    // 128 / 256-pixel levels) are cut into 32-column tiles of 8 rows -> a 10 x 34 halo patch (1.33x the tile)
+    const int WT = W > 64 ? 32 : W;
+    if (M % BM != 0 || W % WT != 0 || BM % WT != 0 || d.C0 % 16 != 0 || d.C1 % 16 != 0 || d.N % BN != 0) return false;
     if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) || (d.tr && (d.ld_tr & 3)) ||
-        (long)9 * (d.C0 + d.C1) * d.N * 6 >= (1L << 31))
+        (long)9 * (d.C0 + d.C1) * d.N * 6 >= (1L << 31) || (long)d.F * H >= (1L << 31))
         return false;
-    int TR = BM / W, nf = 1;
+    int TR = BM / WT, nf = 1;
     if (TR <= H) { if (H % TR != 0) return false; }
-    else { if (TR % H != 0) return false; nf = TR / H; TR = H; if (d.F % nf != 0) return false; }
-    const int P = nf * (TR + 2) * (W + 2);
+    else { if (WT != W || TR % H != 0) return false; nf = TR / H; TR = H; if (d.F % nf != 0) return false; }
+    const int P = nf * (TR + 2) * (WT + 2);
     const int P16 = (P + 15) / 16 * 16;
     if (P16 > 448) return false;
     const bool timing = ((g_variant >> 16) & 15) == 8;
@@ -1393,7 +1411,7 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
         (void)hipFuncSetAttribute((const void*)conv3x3_bf16_v2_kernel<WN, NTV, ABLV>,                                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
         hipLaunchKernelGGL((conv3x3_bf16_v2_kernel<WN, NTV, ABLV>), dim3(nwg), dim3(256 * WN), lds, s, d, remap, TR, nf, \
-                           P16);                                                                                      \
+                           P16, WT);                                                                                  \
     } while (0)
     const int abl = (g_variant >> 16) & 15;
     g_last_nwg = nwg;

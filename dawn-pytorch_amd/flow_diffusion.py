@@ -1,11 +1,13 @@
 """`FlowDiffusion`: the inference wrapper contract of SURVEY.md §8b B1(iii)
 (FD = DM_3/modules/video_flow_diffusion_model_multiGPU_v0_crema_vgg_floss_plus_faceemb_flow_fast_init_cond_test.py,
-FD:96-201, 325-406): owns `.generator` (the UNCHANGED LFG flow decoder, injected), `.unet`, `.diffusion`,
-`.face_loc_emb`; `update_num_frames`, `generate_bbox_mask`, `sample_one_video` keep the reference's
-signatures and semantics.  The denoising hot path (`self.diffusion.sample`) runs on the HIP kernels; the
-few lines of tensor algebra around it (condition assembly, bbox rasterisation, the 2-conv
-`Face_loc_Encoder`) are once-per-clip host-side plumbing and stay in torch, device-agnostic (the
-reference hard-codes `.cuda()`).
+FD:96-201, 325-406): owns `.generator` (the LFG flow generator, injected: the reference's unchanged module or a
+`FlowDecoder`), `.unet`, `.diffusion`, `.face_loc_emb`; `update_num_frames`, `generate_bbox_mask`,
+`sample_one_video` keep the reference's signatures and semantics.  The denoising hot path
+(`self.diffusion.sample`) runs on the HIP kernels, and so does the flow decode that follows it (SURVEY §8f N1:
+`flow_decoder.FlowDecoder`, built from the injected generator's state_dict, replaces the reference's per-frame
+`forward_with_flow` loop FD:372-385 when the clip lives on the GPU).  The few lines of tensor algebra around them
+(condition assembly, bbox rasterisation, the 2-conv `Face_loc_Encoder`) are once-per-clip host-side plumbing and
+stay in torch, device-agnostic (the reference hard-codes `.cuda()`).
 """
 from __future__ import annotations
 
@@ -17,6 +19,7 @@ import torch.nn as nn
 import torch.nn.functional as F_
 
 from .diffusion import DynamicNfGaussianDiffusion
+from .flow_decoder import FlowDecoder
 from .unet import DynamicNfUnet3D
 
 
@@ -57,7 +60,10 @@ class FlowDiffusion(nn.Module):
     def __init__(self, img_size=32, num_frames=40, sampling_timesteps=250, win_width=40, null_cond_prob=0.1,
                  ddim_sampling_eta=1., pose_dim=7, dim_mults=(1, 2, 4, 8), is_train=True, use_residual_flow=False,
                  learn_null_cond=False, use_deconv=True, padding_mode="zeros", pretrained_pth=None, config_pth=None,
-                 generator=None, device=None):
+                 generator=None, device=None, native_decode: Optional[bool] = None):
+        """`native_decode`: True = decode on the HIP kernels (error without a GPU / the extension), False = call the
+        injected generator's `forward_with_flow` frame by frame exactly like FD:375-383, None (default) = HIP kernels
+        whenever the clip is on the GPU."""
         super().__init__()
         if use_residual_flow:
             raise NotImplementedError("use_residual_flow=True is not used by the shipped configs")
@@ -65,6 +71,8 @@ class FlowDiffusion(nn.Module):
         if generator is None:
             generator = load_reference_lfg(config_pth, pretrained_pth, device or "cuda")
         self.generator = generator
+        self.native_decode = native_decode
+        self._decoder: Optional[FlowDecoder] = generator if isinstance(generator, FlowDecoder) else None
         self.pose_dim = pose_dim
         self.unet = DynamicNfUnet3D(dim=64, cond_dim=1024 + pose_dim + 2, cond_aud=1024, cond_pose=pose_dim,
                                     cond_eye=2, num_frames=num_frames, channels=3 + 256 + 16, out_grid_dim=2,
@@ -83,6 +91,12 @@ class FlowDiffusion(nn.Module):
         """FD:177-180."""
         self.unet.update_num_frames(new_num_frames)
         self.diffusion.update_num_frames(new_num_frames)
+
+    def flow_decoder(self, device) -> FlowDecoder:
+        """The HIP decoder for the injected generator (weights packed once, on first use)."""
+        if self._decoder is None:
+            self._decoder = FlowDecoder.from_generator(self.generator, device)
+        return self._decoder
 
     def generate_bbox_mask(self, bbox, size=32):
         """FD:182-201.  bbox (B,6,1) = [x_min,x_max,y_min,y_max,H,W].  Unlike the reference this does not
@@ -127,6 +141,13 @@ class FlowDiffusion(nn.Module):
         out["sample_vid_grid"] = pred[:, :2]
         out["sample_vid_conf"] = (pred[:, 2].unsqueeze(1) + 1) * 0.5
         out["ddim_seconds"] = time.time() - t0
+        native = self.native_decode
+        if native is None:
+            native = sample_img.is_cuda and (self._decoder is not None or hasattr(self.generator, "state_dict"))
+        if native:                                                                     # FD:372-385 as one batched decode
+            out.update(self.flow_decoder(sample_img.device).decode_clip(sample_img, out["sample_vid_grid"],
+                                                                        out["sample_vid_conf"]))
+            return out
         frames, warped = [], []
         for idx in range(pred.size(2)):                                                # FD:375-383 (unchanged LFG)
             g = self.generator.forward_with_flow(source_image=sample_img,

@@ -396,3 +396,55 @@ class HipOps:
         check(self.L.dawn_philox_normal(_p(out), Cc, F, f0, Ftotal, hw, seed, stream_id, self._stream()),
               "dawn_philox_normal")
         return out
+
+    # ------------------------------------------------------------------ LFG flow decode
+    def affine_act(self, x: Tensor, a: Tensor, b: Tensor, act: int = 1) -> Tensor:
+        """out = act(x*a[c] + b[c]) on (rows, C); act 1 = ReLU (eval-mode BatchNorm + ReLU, UTIL:83-88)."""
+        rows, Cc = x.shape
+        self._require(x, a, b)
+        out = self.empty(rows, Cc, like=x)
+        check(self.L.dawn_affine_act(_p(x), _ld(x), _p(a), _p(b), act, _p(out), rows, Cc, self._stream()),
+              "dawn_affine_act")
+        return out
+
+    def bn_relu_pool2(self, x: Tensor, a: Tensor, b: Tensor, F: int, H: int, W: int) -> Tensor:
+        """(F*H*W, C) -> (F*H/2*W/2, C): AvgPool2x2(ReLU(x*a+b))  (DownBlock2d tail, UTIL:129-133)."""
+        Cc = x.shape[1]
+        assert x.is_contiguous() and x.shape[0] == F * H * W
+        self._require(x, a, b)
+        out = self.empty(F * (H // 2) * (W // 2), Cc, like=x)
+        check(self.L.dawn_bn_relu_pool2(_p(x), _p(a), _p(b), _p(out), F, H, W, Cc, self._stream()), "dawn_bn_relu_pool2")
+        return out
+
+    def warp_blend(self, skip: Tensor, Hs: int, Ws: int, grid: Tensor, conf: Tensor, prev: Optional[Tensor] = None,
+                   prev_ab: Optional[Tuple[Tensor, Tensor]] = None, up2: bool = False) -> Tensor:
+        """Generator.apply_optical (GEN:71-90) for T frames against the clip's single skip map (Hs*Ws, C).
+        grid (2,T,h,w) view (planes may be strided: a frame range of a longer clip), conf (T,h,w) contiguous."""
+        Cc = skip.shape[1]
+        _, T, h, w = grid.shape
+        assert skip.is_contiguous() and skip.shape[0] == Hs * Ws and conf.is_contiguous() and conf.shape == (T, h, w)
+        assert grid.stride(3) == 1 and grid.stride(2) == w and grid.stride(1) == h * w
+        assert prev is None or (prev.is_contiguous() and prev.shape == (T * Hs * Ws, Cc))
+        self._require(skip, grid, conf, prev)
+        k = 2 if up2 else 1
+        out = self.empty(T * Hs * k * Ws * k, Cc, like=skip)
+        pa, pb = prev_ab if prev_ab is not None else (None, None)
+        check(self.L.dawn_warp_blend(_p(skip), Hs, Ws, Cc, _p(grid), grid.stride(0), _p(conf), T, h, w, _p(prev), _p(pa),
+                                     _p(pb), 1 if up2 else 0, _p(out), self._stream()), "dawn_warp_blend")
+        return out
+
+    def final_conv_blend(self, x: Tensor, H: int, W: int, w7: Tensor, bias3: Tensor, src: Tensor, grid: Tensor,
+                         conf: Tensor, out_vid: Tensor, warped_vid: Tensor) -> None:
+        """Generator.final + sigmoid + last apply_optical + `deformed` (GEN:152, 163-167).  x (T*H*W, C);
+        src (3,H,W); out_vid / warped_vid: (3,T,H,W) views of the clip-sized outputs (frame range of (3,Ttot,H,W))."""
+        _, T, h, w = grid.shape
+        Cc = x.shape[1]
+        assert x.is_contiguous() and x.shape[0] == T * H * W and src.is_contiguous() and src.shape == (3, H, W)
+        assert grid.stride(3) == 1 and grid.stride(2) == w and grid.stride(1) == h * w and conf.is_contiguous()
+        for o in (out_vid, warped_vid):
+            assert o.shape == (3, T, H, W) and o.stride(3) == 1 and o.stride(2) == W and o.stride(1) == H * W
+        assert out_vid.stride(0) == warped_vid.stride(0)
+        self._require(x, w7, bias3, src, grid, conf, out_vid, warped_vid)
+        check(self.L.dawn_final_conv_blend(_p(x), T, H, W, Cc, _p(w7), _p(bias3), _p(src), _p(grid), grid.stride(0),
+                                           _p(conf), h, w, _p(out_vid), _p(warped_vid), out_vid.stride(0),
+                                           self._stream()), "dawn_final_conv_blend")

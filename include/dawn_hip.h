@@ -178,6 +178,32 @@ int dawn_cfg_combine(const float* e_null, const float* e_cond, float scale, long
 int dawn_philox_normal(float* out, int C, int F, int f0, int Ftotal, int hw, uint64_t seed, uint32_t stream_id,
                        void* stream);
 
+/* ---- LFG flow decode, batched over the frames of a clip -----------------------------------------
+ * (GEN = LFG/modules/generator.py:62-90, 138-171; blocks UTIL = LFG/modules/util.py:70-150; loop FD:372-385).
+ * Activations are channels-last (rows = T*H*W, C) like everywhere else; every 3x3 convolution of the decoder goes
+ * through dawn_conv_gemm.  Eval-mode BatchNorm is the per-channel affine a = gamma/sqrt(var+eps), b = beta - mean*a. */
+/* out[row][c] = act(x[row][c]*a[c] + b[c]); act 0 none, 1 ReLU   (ResBlock2d norm+relu UTIL:83-88; x has row stride ld) */
+int dawn_affine_act(const float* x, int ld, const float* a, const float* b, int act, float* out, long rows, int C,
+                    void* stream);
+/* DownBlock2d tail UTIL:129-133: out (F,H/2,W/2,C) = AvgPool2x2(ReLU(x*a+b)), x (F,H,W,C) */
+int dawn_bn_relu_pool2(const float* x, const float* a, const float* b, float* out, int F, int H, int W, int C,
+                       void* stream);
+/* Generator.apply_optical GEN:71-90 on one level: skip (Hs,Ws,C) is the clip's single source feature map; grid =
+ * two planes (x then y, `grid_plane` floats apart) of T frames (h,w) in grid_sample's normalised convention, conf (T,h,w)
+ * the occlusion map; both are bilinearly resized to (Hs,Ws) (align_corners=False) when the sizes differ.
+ *   out[t] = grid_sample(skip, flow[t]) * occ[t] + P * (1 - occ[t]),  P = prev[t]  or  relu(prev[t]*prev_a + prev_b)
+ * (prev NULL: first term only).  up2 != 0 additionally applies the following UpBlock2d's nearest x2 upsampling
+ * (UTIL:106): out is then (T,2Hs,2Ws,C). */
+int dawn_warp_blend(const float* skip, int Hs, int Ws, int C, const float* grid, long grid_plane, const float* conf,
+                    int T, int h, int w, const float* prev, const float* prev_a, const float* prev_b, int up2,
+                    float* out, void* stream);
+/* Generator.final (7x7, C->3) + sigmoid + the last apply_optical against the source image, and the `deformed` output
+ * (GEN:152, 163-167).  x (T,H,W,C); w7 packed [49 taps][C/4][3 outputs][4 channels]; src (3,H,W) planar;
+ * out_vid / warped_vid planar: channel ch of frame t at [ch*out_plane + t*H*W]  (== (3,T_total,H,W) slices). */
+int dawn_final_conv_blend(const float* x, int T, int H, int W, int C, const float* w7, const float* bias3,
+                          const float* src, const float* grid, long grid_plane, const float* conf, int h, int w,
+                          float* out_vid, float* warped_vid, long out_plane, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

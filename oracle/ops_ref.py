@@ -324,3 +324,48 @@ class RefOps:
         a1 = np.float32(6.283185307179586) * u[3]
         out = np.stack((r0 * np.cos(a0), r0 * np.sin(a0), r1 * np.cos(a1), r1 * np.sin(a1)), axis=-1)
         return torch.from_numpy(out.reshape(Cc, F, hw).astype(np.float32)).to(device)
+
+    # ------------------------------------------------------------------ LFG flow decode
+    def affine_act(self, x, a, b, act=1):
+        y = x * a + b
+        return F_.relu(y) if act == 1 else y
+
+    def bn_relu_pool2(self, x, a, b, F, H, W):
+        Cc = x.shape[1]
+        y = F_.relu(x * a + b).view(F, H, W, Cc).permute(0, 3, 1, 2)
+        return F_.avg_pool2d(y, 2).permute(0, 2, 3, 1).reshape(-1, Cc)
+
+    @staticmethod
+    def _motion(grid, conf, Hs, Ws):
+        """flow (T,Hs,Ws,2) and occlusion (T,1,Hs,Ws) at the skip's resolution (GEN:63-68, 81-82)."""
+        _, T, h, w = grid.shape
+        flow = grid.permute(1, 0, 2, 3)                       # (T,2,h,w)
+        occ = conf.view(T, 1, h, w)
+        if (h, w) != (Hs, Ws):
+            flow = F_.interpolate(flow, size=(Hs, Ws), mode="bilinear")
+            occ = F_.interpolate(occ, size=(Hs, Ws), mode="bilinear")
+        return flow.permute(0, 2, 3, 1), occ
+
+    def warp_blend(self, skip, Hs, Ws, grid, conf, prev=None, prev_ab=None, up2=False):
+        Cc = skip.shape[1]
+        T = grid.shape[1]
+        flow, occ = self._motion(grid, conf, Hs, Ws)
+        src = skip.view(1, Hs, Ws, Cc).permute(0, 3, 1, 2).expand(T, -1, -1, -1)
+        out = F_.grid_sample(src, flow, mode="bilinear", padding_mode="zeros", align_corners=False) * occ
+        if prev is not None:
+            p = prev if prev_ab is None else F_.relu(prev * prev_ab[0] + prev_ab[1])
+            out = out + p.view(T, Hs, Ws, Cc).permute(0, 3, 1, 2) * (1 - occ)
+        if up2:
+            out = F_.interpolate(out, scale_factor=2)
+        return out.permute(0, 2, 3, 1).reshape(-1, Cc)
+
+    def final_conv_blend(self, x, H, W, w7, bias3, src, grid, conf, out_vid, warped_vid):
+        T = grid.shape[1]
+        Cc = x.shape[1]
+        wt = w7.view(7, 7, Cc // 4, 3, 4).permute(3, 2, 4, 0, 1).reshape(3, Cc, 7, 7)   # [tap][C/4][3][4] -> (3,C,7,7)
+        y = torch.sigmoid(F_.conv2d(x.view(T, H, W, Cc).permute(0, 3, 1, 2), wt, bias3, padding=3))
+        flow, occ = self._motion(grid, conf, H, W)
+        wsrc = F_.grid_sample(src.view(1, 3, H, W).expand(T, -1, -1, -1), flow, mode="bilinear", padding_mode="zeros",
+                              align_corners=False)
+        warped_vid.copy_(wsrc.permute(1, 0, 2, 3))
+        out_vid.copy_((wsrc * occ + y * (1 - occ)).permute(1, 0, 2, 3))
