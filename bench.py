@@ -125,6 +125,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-frames", type=int, default=8)
     ap.add_argument("--no-kernel-events", action="store_true")
+    ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) flow-decode report")
     ap.add_argument("--event-every", type=int, default=5,
                     help="record the per-launch HIP events of the roofline measurement on every n-th DDIM step of the timed "
                          "region (every step costs ~2.5 %% of the run: two marker packets per conv launch)")
@@ -272,6 +273,31 @@ def main():
                             "frac_of_fp32_mfma_peak": alg / dt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * n_gpus)}
     result["config"]["launch"] = ("HIP graph replay per DDIM step" if diff.use_graph and getattr(ops, "graph_error", None) is None
                                   else "eager" + (f" (graph capture failed: {ops.graph_error})" if getattr(ops, "graph_error", None) else ""))
+    if n_gpus == 1 and not args.no_decode:
+        # "report sample_one_video-inclusive separately".  OUTSIDE the timed region: the sampled clip
+        # (grid = pred[:, :2], conf = (pred[:, 2] + 1) / 2, FD:365-366) goes through the HIP flow decode (SURVEY 8f N1,
+        # FlowDecoder.decode_clip == the reference's per-frame loop FD:372-385) with a random-init LFG generator of the
+        # shipped topology.  `value` above never includes this.
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import bench_decode
+        from dawn_pytorch_amd.flow_decoder import FlowDecoder
+        dec = FlowDecoder(bench_decode.lfg_state_dict(0), device, ops=ops)
+        img = torch.rand(1, 3, args.res, args.res, generator=torch.Generator().manual_seed(1)).to(device)
+        grid, conf = out[:, :2], (out[:, 2:3] + 1) * 0.5
+        dec.decode_clip(img, grid, conf)
+        tds = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            td0 = time.perf_counter()
+            vid = dec.decode_clip(img, grid, conf)["sample_out_vid"]
+            torch.cuda.synchronize()
+            tds.append(time.perf_counter() - td0)
+        assert torch.isfinite(vid).all(), "non-finite decoded frames"
+        td = sorted(tds)[1]
+        dfl = bench_decode.decode_flops_per_frame(args.res) * T
+        result["flow_decode"] = {"what": "LFG forward_with_flow for the whole clip (FlowDecoder.decode_clip), outside the timed region",
+                                 "ms_per_clip": td * 1e3, "frames_per_s": T / td, "algorithmic_tflops": dfl / td / 1e12,
+                                 "sampler_plus_decode_frames_per_s": T / (dt / args.steps + td)}
     if not args.no_cpu_baseline and n_gpus == 1:
         sd = {"denoise_fn." + k: v.detach().cpu() for k, v in unet.state_dict().items()}
         result["cpu_baseline"] = cpu_baseline(h, S, args.cpu_sample_frames, sd)
