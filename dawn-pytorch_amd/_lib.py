@@ -76,6 +76,7 @@ SIGNATURES = {
     "dawn_bn_relu_pool2": [c_f, c_f, c_f, c_f, _i, _i, _i, _i, c_f],
     "dawn_warp_blend": [c_f, _i, _i, _i, c_f, _l, c_f, _i, _i, _i, c_f, c_f, c_f, _i, c_f, c_f],
     "dawn_final_conv_blend": [c_f, _i, _i, _i, _i, c_f, c_f, c_f, c_f, _l, c_f, _i, _i, c_f, c_f, _l, c_f],
+    "dawn_frames_to_u8": [c_f, _l, _l, _d, _d, _d, _i, c_f, c_f],
 }
 
 _lib = None

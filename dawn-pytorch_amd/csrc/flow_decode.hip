@@ -252,6 +252,34 @@ __global__ __launch_bounds__(256) void final_conv_blend_kernel(const float* __re
     }
 }
 
+// ---- frame egress (UVG:383-397, 533-548 `_process_output_frame`): the decoded clip (3,T,H,W) fp32 in
+// [0,1] -> (T,H,W,3) uint8, RGB or BGR (cv2.VideoWriter / cv2.imwrite order), with numpy's exact arithmetic:
+//   frame += mean/255 (float64 add, stored back as float32) ; clip(0,1) ; (frame*255) in float32 ; astype(uint8) = trunc.
+// 4 pixels per thread: three 16-byte plane reads, three packed 4-byte stores; one D2H copy of T*H*W*3 bytes follows
+// instead of the reference's T device->host copies of fp32 frames.
+__device__ __forceinline__ unsigned u8_of(float x, double m) {
+    float v = (float)((double)x + m);
+    v = fminf(fmaxf(v, 0.0f), 1.0f);
+    return (unsigned)(v * 255.0f);
+}
+__global__ __launch_bounds__(256) void frames_to_u8_kernel(const float* __restrict__ vid, long plane, long npix4, double m0,
+                                                           double m1, double m2, int bgr, unsigned* __restrict__ out) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < npix4; i += (long)gridDim.x * 256) {
+        const f32x4 r = *reinterpret_cast<const f32x4*>(vid + 4 * i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(vid + plane + 4 * i);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(vid + 2 * plane + 4 * i);
+        unsigned c[12];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            const unsigned R = u8_of(r[p], m0), G = u8_of(g[p], m1), B = u8_of(b[p], m2);
+            c[3 * p] = bgr ? B : R; c[3 * p + 1] = G; c[3 * p + 2] = bgr ? R : B;
+        }
+#pragma unroll
+        for (int w = 0; w < 3; ++w)
+            out[3 * i + w] = c[4 * w] | (c[4 * w + 1] << 8) | (c[4 * w + 2] << 16) | (c[4 * w + 3] << 24);
+    }
+}
+
 int grid_for(long total) {
     long g = (total + 255) / 256;
     return (int)(g > 65536 ? 65536 : (g < 1 ? 1 : g));
@@ -303,6 +331,17 @@ extern "C" int dawn_final_conv_blend(const float* x, int T, int H, int W, int C,
     (void)hipFuncSetAttribute((const void*)final_conv_blend_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL(final_conv_blend_kernel, dim3((unsigned)nblk), dim3(256), lds, (hipStream_t)stream, x, T, H, W, C, w7,
                        bias3, src, grid, grid_plane, conf, h, w, out_vid, warped_vid, out_plane);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dawn_frames_to_u8(const float* vid, long plane, long npix, double mean0, double mean1, double mean2, int bgr,
+                                 unsigned char* out, void* stream) {
+    if (npix % 4 != 0 || plane % 4 != 0)
+        return dawn_set_error_msg(-77, "dawn_frames_to_u8: pixel count and plane stride must be multiples of 4");
+    if (npix <= 0) return 0;
+    hipLaunchKernelGGL(frames_to_u8_kernel, dim3(grid_for(npix / 4)), dim3(256), 0, (hipStream_t)stream, vid, plane, npix / 4,
+                       mean0, mean1, mean2, bgr, reinterpret_cast<unsigned*>(out));
     DAWN_LAUNCH_CHECK();
     return 0;
 }

@@ -448,3 +448,16 @@ class HipOps:
         check(self.L.dawn_final_conv_blend(_p(x), T, H, W, Cc, _p(w7), _p(bias3), _p(src), _p(grid), grid.stride(0),
                                            _p(conf), h, w, _p(out_vid), _p(warped_vid), out_vid.stride(0),
                                            self._stream()), "dawn_final_conv_blend")
+
+    # ------------------------------------------------------------------ frame egress
+    def frames_to_u8(self, vid: Tensor, mean=(0.0, 0.0, 0.0), bgr: bool = False) -> Tensor:
+        """(3,T,H,W) fp32 in [0,1] -> (T,H,W,3) uint8 with `_process_output_frame`'s arithmetic (UVG:533-548):
+        trunc(clip(x + mean/255, 0, 1) * 255); `bgr=True` = the cv2 channel order."""
+        _, T, H, W = vid.shape
+        assert vid.shape[0] == 3 and vid.stride(3) == 1 and vid.stride(2) == W and vid.stride(1) == H * W
+        self._require(vid)
+        out = torch.empty(T, H, W, 3, device=vid.device, dtype=torch.uint8)
+        m = [float(x) / 255.0 for x in mean]
+        check(self.L.dawn_frames_to_u8(_p(vid), vid.stride(0), T * H * W, m[0], m[1], m[2], 1 if bgr else 0, _p(out),
+                                       self._stream()), "dawn_frames_to_u8")
+        return out

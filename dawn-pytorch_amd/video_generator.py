@@ -117,9 +117,11 @@ class VideoGenerator:
                 sample_pose=poses.unsqueeze(0).to(dev), sample_eye=blink[:2].unsqueeze(0).to(dev),
                 sample_bbox=real_bb[2:].unsqueeze(0).to(dev), init_pose=init_pose.to(dev), init_eye=init_blink.to(dev),
                 cond_scale=cfg['cond_scale'])
-        vid = out["sample_out_vid"][0].permute(1, 2, 3, 0).float().cpu().numpy()            # (T,H,W,3) in [0,1]
-        vid = np.clip(vid + np.array(cfg.get('mean', (0, 0, 0))) / 255.0, 0, 1)
-        frames = (vid * 255).astype(np.uint8)
+        # frame egress (UVG:383-397 + `_process_output_frame` UVG:533-548): one conversion launch for the whole clip
+        # ((3,T,H,W) fp32 -> (T,H,W,3) uint8, numpy's exact arithmetic) and ONE device->host copy, instead of T copies
+        # of fp32 frames converted on the host.  RGB order here (PIL); `bgr=True` gives cv2's order.
+        frames = self.video_model.unet._ops().frames_to_u8(out["sample_out_vid"][0].float().contiguous(),
+                                                           mean=tuple(cfg.get('mean', (0, 0, 0))), bgr=False).cpu().numpy()
         for i, fr in enumerate(frames):
             Image.fromarray(fr).save(os.path.join(img_dir, f"{i:03d}.png"))
         self.last_output = out

@@ -204,6 +204,13 @@ int dawn_final_conv_blend(const float* x, int T, int H, int W, int C, const floa
                           const float* src, const float* grid, long grid_plane, const float* conf, int h, int w,
                           float* out_vid, float* warped_vid, long out_plane, void* stream);
 
+/* ---- frame egress (UVG:383-397, `_process_output_frame` UVG:533-548) ---------------------------
+ * vid = three fp32 planes (`plane` floats apart) of npix = T*H*W pixels each (a (3,T,H,W) clip) -> out (T,H,W,3) uint8:
+ *   u8 = trunc(clip(float32(x + mean_c/255), 0, 1) * 255)   (numpy's arithmetic, bit-exact), channel order RGB, or
+ * BGR (bgr != 0: cv2.cvtColor(RGB2BGR) for cv2.VideoWriter / imwrite).  mean0..2 = the caller's mean_c/255 as doubles. */
+int dawn_frames_to_u8(const float* vid, long plane, long npix, double mean0, double mean1, double mean2, int bgr,
+                      unsigned char* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

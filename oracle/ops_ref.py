@@ -369,3 +369,15 @@ class RefOps:
                               align_corners=False)
         warped_vid.copy_(wsrc.permute(1, 0, 2, 3))
         out_vid.copy_((wsrc * occ + y * (1 - occ)).permute(1, 0, 2, 3))
+
+    # ------------------------------------------------------------------ frame egress
+    def frames_to_u8(self, vid, mean=(0.0, 0.0, 0.0), bgr=False):
+        """numpy restatement of UVG:533-548 applied to every frame: float32 frame, in-place += float64 mean/255,
+        clip, *255 (float32), astype(uint8); cv2.cvtColor(RGB2BGR) = channel reversal."""
+        frame = vid.permute(1, 2, 3, 0).detach().cpu().numpy().astype(np.float32).copy()   # (T,H,W,3)
+        frame += np.array(mean) / 255.0
+        frame = np.clip(frame, 0, 1)
+        frame = (frame * 255).astype(np.uint8)
+        if bgr:
+            frame = frame[..., ::-1].copy()
+        return torch.from_numpy(frame)

@@ -91,3 +91,19 @@ def test_flow_diffusion_routes_the_decode_through_flow_decoder(lfg):
     assert (out["sample_out_vid"] - want["sample_out_vid"]).abs().max() <= 5e-6
     assert (out["sample_warped_vid"] - want["sample_warped_vid"]).abs().max() <= 1e-6
     assert (out["sample_out_vid"] - T(g["sample_out_vid"])).abs().max() <= 2e-5   # conf round trip (x*2-1+1)/2
+
+
+def test_frames_to_u8_restates_process_output_frame():
+    """the op reference == UVG:533-548 `_process_output_frame` written out per frame (numpy)."""
+    g = torch.Generator().manual_seed(0)
+    vid = torch.rand(3, 4, 6, 8, generator=g) * 1.4 - 0.2                     # values outside [0,1] are clipped
+    vid[:, 0, 0, :4] = torch.tensor([0.0, 1.0, 254.999 / 255, 128.0 / 255])
+    mean = (2.0, 0.0, -3.5)
+    got = RefOps().frames_to_u8(vid, mean=mean, bgr=True).numpy()
+    for t in range(4):
+        frame = vid[:, t].permute(1, 2, 0).numpy().copy()                    # frame_batch[index].permute(1,2,0)...copy()
+        frame += np.array(mean) / 255.0
+        frame = np.clip(frame, 0, 1)
+        frame = (frame * 255).astype(np.uint8)
+        assert np.array_equal(got[t], frame[..., ::-1])                      # cv2.COLOR_RGB2BGR
+    assert got.dtype == np.uint8 and got.shape == (4, 6, 8, 3)

@@ -206,3 +206,23 @@ def test_decoder_full_architecture_matches_oracle(hip, H, Tn, chunk):
     # frames are independent: decoding frame 1 alone equals frame 1 of the clip (no cross-frame state)
     one = dec.decode_clip(img.cuda(), grid[:, :, 1:2].cuda(), conf[:, :, 1:2].cuda())
     assert torch.equal(one["sample_out_vid"][:, :, 0], got["sample_out_vid"][:, :, 1])
+
+
+@pytest.mark.parametrize("bgr", [False, True])
+def test_frames_to_u8_bit_exact(hip, ref, bgr):
+    """SURVEY 8f N2 frame egress: byte output, bit-exact against numpy's arithmetic (UVG:533-548)."""
+    g = torch.Generator().manual_seed(3)
+    Ttot, H, W = 6, 40, 52
+    clip = torch.rand(3, Ttot, H, W, generator=g) * 1.3 - 0.15
+    k = torch.arange(0, 256, dtype=torch.float32)
+    clip[0, 0, 0, :256 // 8 * 0 + 52] = (k[:52] / 255.0)                       # exact byte boundaries
+    clip[1, 0, 1, :52] = (k[100:152] + 0.999) / 255.0
+    clip[2, 0, 2, :52] = torch.nextafter(k[200:252] / 255.0, torch.tensor(0.0))
+    mean = (1.5, 0.0, -2.25)
+    vid = clip[:, 1:5]                                                        # frame range of a longer clip (strided planes)
+    got = hip.frames_to_u8(clip.cuda()[:, 1:5], mean=mean, bgr=bgr).cpu()
+    want = ref.frames_to_u8(vid, mean=mean, bgr=bgr)
+    assert got.dtype == torch.uint8 and got.shape == (4, H, W, 3)
+    assert torch.equal(got, want), int((got != want).sum())
+    got0 = hip.frames_to_u8(clip.cuda(), bgr=bgr).cpu()
+    assert torch.equal(got0, ref.frames_to_u8(clip, bgr=bgr))
