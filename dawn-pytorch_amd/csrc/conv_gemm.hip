@@ -1433,58 +1433,66 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
 // the A rows of stage s+2 are in flight as register loads, those of stage s+1 are split between the MFMAs of
 // stage s and written to the idle plane buffer, the pre-split weights arrive by LDS-DMA one stage ahead -- one
 // barrier per 48 MFMAs per wave.  Accumulated transposed (lane = row) -> 16-byte row-segment stores.
-template <int NT>
-__global__ __launch_bounds__(512) void gemm1x1_bf16_kernel(const dawn_conv_desc d, const long M) {
+template <int NT, int WN>
+__global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_desc d, const long M) {
 #if __HIP_DEVICE_COMPILE__
-    constexpr int BM = 256, BN = 128, NTHR = 512, TM = 2, TN = 2;
+    // BN = 64*WN output columns, 4*WN waves (64 x 64 each).  WN = 1 serves N % 64 == 0 (to_q: 192 columns, the 64-channel
+    // res_conv) and small tile counts; the A rows may come from two channel-concatenated sources (stage s reads in0 while
+    // 32 s < C0, in1 afterwards) -- the up-path res_conv / to_q of cat[x, skip] without materialising the cat.
+    constexpr int BM = 256, BN = 64 * WN, NTHR = 256 * WN, NW = 4 * WN, TM = 2, TN = 2;
+    constexpr int NQ = 2048 / NTHR;                            // A quads per thread per stage (4 or 8)
     constexpr int HPS = BM * 16 + 128;                         // half-plane stride (bytes)
     constexpr int PSZ = 2 * 6 * HPS;                           // planes of one stage (2 sub-chunks of 16 channels)
     constexpr int BSZ = 2 * 6 * BN * 16;                       // weights of one stage
-    constexpr int NBI = BSZ / 1024;                            // 24 DMA wave-instructions per stage, 3 per wave
-    constexpr unsigned OOB = 0x80000000u;
+    constexpr int NBI = BSZ / 1024;                            // DMA wave-instructions per stage: 3 per wave
+    static_assert(NBI == 3 * NW, "weight DMA split");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* planes = smem_b;                            // [2 stages][2 sub][3 planes][2 halves][HPS]
     unsigned char* Bs = smem_b + 2 * PSZ;                      // [2 stages][2 sub][3][2][BN][16 B]
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, half = lane >> 5;
-    const int K = d.C0;
-    const int nS = K / 32;
+    const int K = d.C0 + d.C1;
+    const int nS = K / 32, nS0 = d.C0 / 32;
     const int nNt = d.N / BN;
     const int mt = blockIdx.x / nNt, nt = blockIdx.x - mt * nNt;
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
+    const int ld1 = d.in1 ? d.ld1 : d.ld0;
     const __amdgpu_buffer_rsrc_t rsa =
         __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + m0 * d.ld0), 0, BM * d.ld0 * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa1 = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)((d.in1 ? d.in1 : d.in0) + m0 * ld1), 0, BM * ld1 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, (K / 16) * 6 * d.N * 16, 0x00020000);
-    // A quads of a stage: 256 rows x 8 quads = 2048 -> 4 per thread: q = tid + 512 i -> row = q >> 3, quad = q & 7
-    unsigned voffA[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int q = tid + NTHR * i;
-        voffA[i] = (unsigned)((q >> 3) * d.ld0 * 4 + (q & 7) * 16);
-    }
+    // A quads of a stage: 256 rows x 8 quads = 2048 -> NQ per thread: q = tid + NTHR i -> row = q >> 3, quad = q & 7
+    const int row0 = tid >> 3, qoff = (tid & 7) * 16;
     unsigned voffB[3];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-        const int idx = (j * 8 + wave) * 64 + lane;            // 16-byte piece within the stage
+        const int idx = (j * NW + wave) * 64 + lane;           // 16-byte piece within the stage
         const int sub = idx / (6 * BN), rem = idx - sub * (6 * BN);
         const int ph = rem / BN, n = rem - ph * BN;
         voffB[j] = (unsigned)((((sub * 6 + ph) * d.N) + n0 + n) * 16);
     }
     typedef int i32x4 __attribute__((ext_vector_type(4)));
-    f32x4 araw[2][4];
-    uint2 ap[4][3];
+    f32x4 araw[2][NQ];
+    uint2 ap[NQ][3];
     auto loadA = [&](int s, int slot) {
+        const bool src1 = s >= nS0;                            // wave-uniform
+        const int ldb = (src1 ? ld1 : d.ld0) * 4;
+        const int soff = (src1 ? s - nS0 : s) * 128;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-            araw[slot][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsa, voffA[i], s * 128, 0));
+        for (int i = 0; i < NQ; ++i) {
+            const unsigned voff = (unsigned)((row0 + (NTHR >> 3) * i) * ldb + qoff);
+            araw[slot][i] = __builtin_bit_cast(f32x4, src1 ? __builtin_amdgcn_raw_buffer_load_b128(rsa1, voff, soff, 0)
+                                                           : __builtin_amdgcn_raw_buffer_load_b128(rsa, voff, soff, 0));
+        }
     };
     auto writeA = [&](int buf) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
+        for (int i = 0; i < NQ; ++i) {
             const int q = tid + NTHR * i;
             const int row = q >> 3, quad = q & 7;               // quad: sub-chunk = quad >> 2, k-half = (quad >> 1) & 1
             unsigned char* dst = planes + (size_t)buf * PSZ + (size_t)(quad >> 2) * 6 * HPS + (size_t)((quad >> 1) & 1) * HPS +
@@ -1499,7 +1507,7 @@ __global__ __launch_bounds__(512) void gemm1x1_bf16_kernel(const dawn_conv_desc 
 #pragma unroll
         for (int j = 0; j < 3; ++j)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                rsw, (__attribute__((address_space(3))) void*)(Bs + (size_t)buf * BSZ + (j * 8 + wave) * 1024), 16, voffB[j], soff, 0, 0);
+                rsw, (__attribute__((address_space(3))) void*)(Bs + (size_t)buf * BSZ + (j * NW + wave) * 1024), 16, voffB[j], soff, 0, 0);
     };
 
     f32x16 acc[TM][TN];
@@ -1514,7 +1522,7 @@ __global__ __launch_bounds__(512) void gemm1x1_bf16_kernel(const dawn_conv_desc 
     loadA(0, 0);
     if (nS > 1) loadA(1, 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) split3(araw[0][i], ap[i][0], ap[i][1], ap[i][2]);
+    for (int i = 0; i < NQ; ++i) split3(araw[0][i], ap[i][0], ap[i][1], ap[i][2]);
     writeA(0);
     for (int s = 0; s < nS; ++s) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1548,11 +1556,11 @@ __global__ __launch_bounds__(512) void gemm1x1_bf16_kernel(const dawn_conv_desc 
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
                         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB9[t]], fa[i][PA9[t]], acc[i][j], 0, 0, 0);
-            // split two of the next stage's quads in the shadow of these MFMAs
+            // split half of the next stage's quads in the shadow of these MFMAs
             if (s + 1 < nS) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const int qi = sub * 2 + i;
+                for (int i = 0; i < NQ / 2; ++i) {
+                    const int qi = sub * (NQ / 2) + i;
                     if ((s + 1) & 1) split3(araw[1][qi], ap[qi][0], ap[qi][1], ap[qi][2]);
                     else split3(araw[0][qi], ap[qi][0], ap[qi][1], ap[qi][2]);
                 }
@@ -1578,24 +1586,52 @@ __global__ __launch_bounds__(512) void gemm1x1_bf16_kernel(const dawn_conv_desc 
                 f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
                 if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
+                if (d.tr) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(d.tr + m * d.ld_tr + n);
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(d.tr_a + n), tb = *reinterpret_cast<const f32x4*>(d.tr_b + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += dawn_silu(t4[e] * ta[e] + tb[e]);
+                }
                 *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n) = v;
             }
     }
 #endif
 }
 
-bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
-    if (d.C1 != 0 || d.in1 || d.C0 % 32 != 0 || d.N % 128 != 0 || M % 256 != 0 || M < 51200 || d.tr || d.gn_part) return false;
-    if ((d.ld0 & 3) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) || (long)d.ld0 * 256 * 4 >= (1L << 31)) return false;
-    const size_t lds = (size_t)2 * 2 * 6 * (256 * 16 + 128) + (size_t)2 * 2 * 6 * 128 * 16;
-    const int nwg = (int)(M / 256) * (d.N / 128);
+template <int WN>
+void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
+    constexpr int BN = 64 * WN;
+    const size_t lds = (size_t)2 * 2 * 6 * (256 * 16 + 128) + (size_t)2 * 2 * 6 * BN * 16;
+    const int nwg = (int)(M / 256) * (d.N / BN);
     g_last_nwg = nwg;
     if (g_variant & 0x2000) {
-        (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<9>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((gemm1x1_bf16_kernel<9>), dim3(nwg), dim3(512), lds, s, d, M);
+        (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<9, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm1x1_bf16_kernel<9, WN>), dim3(nwg), dim3(256 * WN), lds, s, d, M);
     } else {
-        (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<6>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        hipLaunchKernelGGL((gemm1x1_bf16_kernel<6>), dim3(nwg), dim3(512), lds, s, d, M);
+        (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<6, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm1x1_bf16_kernel<6, WN>), dim3(nwg), dim3(256 * WN), lds, s, d, M);
+    }
+}
+
+bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
+    if (d.C0 % 32 != 0 || d.C1 % 32 != 0 || (d.C1 != 0) != (d.in1 != nullptr) || d.N % 64 != 0 || M % 256 != 0 ||
+        M < 12800 || d.gn_part)
+        return false;
+    if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) || (d.tr && (d.ld_tr & 3)) ||
+        (long)d.ld0 * 256 * 4 >= (1L << 31) || (long)d.ld1 * 256 * 4 >= (1L << 31))
+        return false;
+    // Tile policy from the per-shape table of the benchmark (profiles/r1_final_gemm1x1_policy.txt): 256 x 128 tiles when
+    // they fill the chip; 256 x 64 tiles for N = 192 and for the small GEMMs that would leave more than half of the CUs
+    // idle with 128-wide tiles; the thin N = 64 GEMMs and the short (M < 51200) 128..255-tile cases stay on the fp32
+    // kernel (many small workgroups hide HBM latency better than one 126 KB-LDS workgroup per CU).
+    if (d.N % 128 == 0) {
+        const long t2 = (M / 256) * (d.N / 128);
+        if (t2 >= 256 || (t2 >= 128 && M >= 51200)) launch_gemm1x1_bf16<2>(d, M, s);
+        else if (t2 < 128) launch_gemm1x1_bf16<1>(d, M, s);
+        else return false;
+    } else {
+        if (d.N == 64) return false;
+        launch_gemm1x1_bf16<1>(d, M, s);
     }
     return true;
 }

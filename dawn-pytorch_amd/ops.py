@@ -149,13 +149,16 @@ class HipOps:
     def _runs_split_kernel(w_bf3, KH, KW, stride, mode, rows, N, C0, C1, tr, gn_part) -> bool:
         """Profiling label only: does this launch take a split-operand (bf16 pipe) kernel?  Mirrors the dispatch
         conditions of dawn_conv_gemm for the shapes of the benchmark (3x3/s1 ResBlock convs; 1x1 GEMMs with
-        M >= 51200, M % 256 == 0, N % 128 == 0, K % 32 == 0, one source, no tr epilogue / GroupNorm sums)."""
+        M >= 12800, M % 256 == 0, N % 64 == 0, 32-channel multiples per source, no GroupNorm sums)."""
         if w_bf3 is None or mode != 0 or stride != 1:
             return False
         if KH == 3 and KW == 3:
             return True
-        return (KH == 1 and KW == 1 and rows >= 51200 and rows % 256 == 0 and N % 128 == 0 and C1 == 0 and C0 % 32 == 0
-                and tr is None and gn_part is None)
+        if not (KH == 1 and KW == 1 and rows >= 12800 and rows % 256 == 0 and N % 64 == 0 and N != 64 and C1 % 32 == 0
+                and C0 % 32 == 0 and gn_part is None):
+            return False
+        t2 = (rows // 256) * (N // 128)
+        return N % 128 != 0 or t2 >= 256 or t2 < 128 or rows >= 51200
 
     # ------------------------------------------------------------------ GroupNorm / LayerNorm
     def conv_gn_part(self, rows_out: int, N: int, like: Tensor) -> Tensor:

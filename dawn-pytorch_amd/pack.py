@@ -96,6 +96,9 @@ class PackedResBlock:
     br: Optional[Tensor] = None
     w1s: Optional[Tensor] = None          # pack_bf3 images of w1 / w2 (split-operand bf16 MFMA path)
     w2s: Optional[Tensor] = None
+    wrs: Optional[Tensor] = None          # ... of the 1x1 res_conv, of to_q and of the three to_out projections
+    wqs: Optional[Tensor] = None
+    wos: Optional[List[Tensor]] = None
     conditioned: bool = False
     cond_index: int = -1
     film_off: int = 0
@@ -223,6 +226,8 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
         if has(p + "res_conv.weight"):
             rb.wr = dev(pack_kn(conv_w_kn(g(p + "res_conv.weight"))))
             rb.br = dev(g(p + "res_conv.bias"))
+            if Cin % 16 == 0:
+                rb.wrs = pack_bf3(conv_w_kn(g(p + "res_conv.weight"))).to(device)
         if has(p + "time_mlp.1.weight"):
             rb.conditioned = True
             rb.cond_index = state["cond_idx"]
@@ -231,13 +236,14 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
             state["film_off"] += 2 * Co
             film_w.append(g(p + "time_mlp.1.weight"))
             film_b.append(g(p + "time_mlp.1.bias"))
-            wq, qs, wo, g3 = [], [], [], []
+            wq, qs, wo, g3, wos = [], [], [], [], []
             rb.mlp_w, rb.mlp_b, rb.kv_w, rb.k_scale, rb.null_kv = [], [], [], [], []
             for br in BRANCHES:
                 q = p + f"cross_attn_{br}."
                 wq.append(g(q + "to_q.weight").t() * g(q + "norm.g")[:, None])           # (Cin, 64)
                 qs.append(g(q + "q_scale"))
                 wo.append(dev(pack_kn(g(q + "to_out.0.weight").t())))                     # (64, Co)
+                wos.append(pack_bf3(g(q + "to_out.0.weight").t()).to(device))
                 g3.append(g(q + "to_out.1.g"))
                 rb.mlp_w.append(dev(g(p + BRANCH_MLP[br] + ".1.weight")))
                 rb.mlp_b.append(dev(g(p + BRANCH_MLP[br] + ".1.bias")))
@@ -245,6 +251,9 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
                 rb.k_scale.append(dev(g(q + "k_scale")))
                 rb.null_kv.append(dev(g(q + "null_kv")))
             rb.wq = dev(pack_kn(torch.cat(wq, dim=1)))
+            if Cin % 16 == 0:
+                rb.wqs = pack_bf3(torch.cat(wq, dim=1)).to(device)
+            rb.wos = wos
             rb.q_scale = dev(torch.stack(qs, 0))
             rb.wo = wo
             rb.g3 = dev(torch.stack(g3, 0))

@@ -95,11 +95,12 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
             return ops.xattn_layer_c64(x, x2, H * W, rb.wq, rb.wo, rb.g3, rb.q_scale, cs.kvtab[rb.cond_index],
                                        cs.nulltab[rb.cond_index])
         # LayerNorm_img is materialised (one streaming pass) so that to_q runs as a prologue-free GEMM
-        q = ops.conv_gemm(ops.ln_rows(x, x2), rb.wq, 192, **g)
+        q = ops.conv_gemm(ops.ln_rows(x, x2), rb.wq, 192, w_bf3=rb.wqs, **g)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)
         y3 = ops.empty(F * H * W, 3 * Co, like=x)
         for b in range(3):
-            ops.conv_gemm(q[:, 64 * b:64 * b + 64], rb.wo[b], Co, out=y3[:, b * Co:(b + 1) * Co], **g)
+            ops.conv_gemm(q[:, 64 * b:64 * b + 64], rb.wo[b], Co, out=y3[:, b * Co:(b + 1) * Co],
+                          w_bf3=rb.wos[b] if rb.wos is not None else None, **g)
         return ops.xattn_ln_sum(y3, rb.g3, Co)
 
     def conv1_and_stats():
@@ -123,7 +124,7 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, w_bf3=rb.w2s, **g)
     a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows, part=part2)
     if rb.wr is not None:
-        return ops.conv_gemm(x, rb.wr, Co, in1=x2, bias=rb.br, tr=(c2, a2, b2), **g)
+        return ops.conv_gemm(x, rb.wr, Co, in1=x2, bias=rb.br, tr=(c2, a2, b2), w_bf3=rb.wrs, **g)
     assert x2 is None
     return ops.gn_apply_res(c2, a2, b2, x)
 

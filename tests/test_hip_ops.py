@@ -201,6 +201,49 @@ def test_gemm1x1_split(hip, ref, M, K, N, res, bias):
     hip.L.dawn_conv_set_variant(22541)
 
 
+@pytest.mark.parametrize("M,C0,C1,N,extra", [(51200, 64, 64, 64, "tr"), (12800, 512, 512, 256, "tr"), (25600, 128, 0, 192, ""),
+                                             (12800, 512, 0, 768, "res"), (51200, 64, 0, 128, "strided"),
+                                             (12800, 64, 0, 512, "strided"), (204800, 32, 96, 64, "bias")])
+def test_gemm1x1_split_variants(hip, ref, M, C0, C1, N, extra):
+    """The same kernel family beyond the plain case: 64-column tiles (N = 64 / 192), two channel-concatenated sources
+    (res_conv / to_q of cat[x, skip]), the res_conv epilogue out += SiLU(c2*a+b), M down to 12800 rows, and strided
+    input / output views (to_out: a 64-column slice of q -> a Co-column slice of y3)."""
+    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+    K = C0 + C1
+    w = packw(K, N, seed=2)
+    kw = dict(F=M // 64, Hi=8, Wi=8)
+    x0 = rnd(M, C0, seed=1)
+    x1 = rnd(M, C1, seed=5) if C1 else None
+    if "tr" in extra:
+        kw["tr"] = (rnd(M, N, seed=6), rnd(N, seed=7), rnd(N, seed=8))
+        kw["bias"] = rnd(N, seed=4)
+    if "res" in extra:
+        kw["res"] = rnd(M, N, seed=3)
+    if "bias" in extra:
+        kw["bias"] = rnd(N, seed=4)
+    want = ref.conv_gemm(x0, w, N, in1=x1, **kw)
+    gkw = {k_: (tuple(t.cuda() for t in v) if isinstance(v, tuple) else v.cuda() if torch.is_tensor(v) else v) for k_, v in kw.items()}
+    x0g = x0.cuda()
+    out = None
+    if extra == "strided":
+        wide = torch.zeros(M, C0 + 128, device="cuda")
+        wide[:, 64:64 + C0] = x0g
+        x0g = wide[:, 64:64 + C0]
+        big = torch.full((M, 3 * N), 7.0, device="cuda")
+        out = big[:, N:2 * N]
+    got = hip.conv_gemm(x0g, w.cuda(), N, in1=None if x1 is None else x1.cuda(), w_bf3=pack_bf3(unpack_kn(w)).cuda(), out=out, **gkw)
+    torch.cuda.synchronize()
+    check(f"gemm1x1_split_variants/M{M}_C{C0}+{C1}_N{N}_{extra}", got, want)
+    if out is not None:
+        assert float(big[:, :N].min()) == 7.0 and float(big[:, 2 * N:].max()) == 7.0       # neighbours untouched
+    # and it is the split kernel's accuracy class: no worse than the fp32 MFMA path against fp64
+    hip.L.dawn_conv_set_variant(2061)
+    got32 = hip.conv_gemm(x0.cuda(), w.cuda(), N, in1=None if x1 is None else x1.cuda(), **gkw)
+    hip.L.dawn_conv_set_variant(22541)
+    e_split, e_f32 = float((got.cpu() - want).abs().max()), float((got32.cpu() - want).abs().max())
+    assert e_split <= 2.0 * e_f32 + 1e-5 * max(1.0, float(want.abs().max())), (e_split, e_f32)
+
+
 def test_conv_gemm_transposed(hip, ref):
     from dawn_pytorch_amd.pack import pack_kn, deconv_w_kn_phases
     F, H, W, Cc = 3, 8, 8, 64
