@@ -10,6 +10,14 @@
 // plus the 4 of its xor-32 partner, an output row's 64 channels are 32 in-lane values plus the partner's 32.
 // Hence q-normalisation, the two logits, the 2-way softmax and both LayerNorms are in-register arithmetic with
 // single xor-32 exchanges; no LDS traffic for activations (LDS only holds the weights, staged once per block).
+//
+// Two exact rewrites keep the per-pixel work small (the keys / values depend on (frame, branch, head) only):
+//  * softmax over [null, ctx] = sigmoid of ONE dot product: sigma_h = 1 / (1 + exp2(q_h . D_h / |q_h|)),
+//    D_h = q_scale * (k_null - k_ctx,h) * 8 log2(e)                                (MT:540-552; table per frame);
+//  * to_out of o_h = v_null + sigma_h (v_ctx,h - v_null) is affine in sigma: y = y0 + sum_h sigma_h u_h with
+//    u_h = Wo[8h..8h+7]^T (v_ctx,h - v_null), y0 = Wo^T v_null  (MT:553-558) -- a K = 9 product against a per-frame
+//    table instead of a K = 64 GEMM, and the 48 KB of to_out weights leave the LDS (2 workgroups per CU).
+// dawn_xattn_tables builds [D | u_0..u_7 | y0] per (frame, branch) once per clip (the condition is step-invariant).
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 
@@ -31,40 +39,26 @@ __device__ __forceinline__ f32x16 zz16() {
 __device__ __forceinline__ float x32(float v) { return v + __shfl_xor(v, 32, 64); }
 
 template <int CIN>
-__global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict__ in0, int C0, int ld0,
+__global__ __launch_bounds__(512, CIN == 64 ? 4 : 2) void xattn_c64_kernel(const float* __restrict__ in0, int C0, int ld0,
                                                         const float* __restrict__ in1, int ld1, long rows, int HW,
-                                                        const float* __restrict__ wq, const float* __restrict__ wo0,
-                                                        const float* __restrict__ wo1, const float* __restrict__ wo2,
-                                                        const float* __restrict__ g3, const float* __restrict__ q_scale,
-                                                        const float* __restrict__ kvtab,
-                                                        const float* __restrict__ nulltab, float eps,
+                                                        const float* __restrict__ wq, const float* __restrict__ g3,
+                                                        const float* __restrict__ xtab, float eps,
                                                         float* __restrict__ out, long ntiles) {
     constexpr int NC = CIN / 8;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wq = smem;                         // [CIN/4][192][4]
-    float* Wo = smem + (CIN / 4) * 192 * 4;   // [3][16][64][4]
-    float* Cs = Wo + 3 * 16 * 64 * 4;         // constants: g3 [3][64] | q_scale [3][8] | nulltab [3][16]  (264 floats, padded to 272)
-    float* Kv = Cs + 272;                     // per-wave copy of the current frame's table: [8 waves][3][128]
+    float* Cs = smem + (CIN / 4) * 192 * 4;   // g3 [3][64]
+    float* Dw = Cs + 192;                     // per-wave copy of the current frame's D rows: [8 waves][3][64]
     const int tid = threadIdx.x;
-    // (CIN = 128 keeps its LDS at the 147 KB of the weights: with the extra tables the block would fill the CU's LDS
-    //  and a concurrent single-block kernel of the other stream -- gn_reduce_finalize -- could not be placed)
-    constexpr bool KVLDS = CIN == 64;
     for (int i = tid; i < 192; i += 512) Cs[i] = g3[i];
-    if (tid < 24) Cs[192 + tid] = q_scale[tid];
-    if (tid < 48) Cs[216 + tid] = nulltab[tid];
     for (int i = tid; i < (CIN / 4) * 192; i += 512)
         *reinterpret_cast<f32x4*>(Wq + i * 4) = *reinterpret_cast<const f32x4*>(wq + (size_t)i * 4);
-    for (int i = tid; i < 3 * 16 * 64; i += 512) {
-        const int b = i / (16 * 64), j = i - b * 16 * 64;
-        const float* src = b == 0 ? wo0 : (b == 1 ? wo1 : wo2);
-        *reinterpret_cast<f32x4*>(Wo + i * 4) = *reinterpret_cast<const f32x4*>(src + (size_t)j * 4);
-    }
     __syncthreads();
 
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
 #ifdef DAWN_XA_TIMING
-    unsigned long long* tsb = reinterpret_cast<unsigned long long*>(smem + 28160);   // byte 112640.. (CIN = 64 build only)
+    unsigned long long* tsb = reinterpret_cast<unsigned long long*>(Dw + 8 * 192);  // after the per-wave tables
     int tix = 0, titer = 0;
 #define TSTAMP() do { if (lane == 0 && titer == 1 && tix < 24) tsb[wave * 24 + tix++] = __builtin_amdgcn_s_memtime(); } while (0)
 #else
@@ -98,81 +92,75 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
         for (int c = 0; c < NC; ++c) xn[c] = xn[c] * rs;
         TSTAMP();   // x loaded + LayerNorm
 
-        // the frame's [null | condition] k/v table -> this wave's LDS copy (no global-load latency in the head loops);
-        // a 32-pixel tile lies in one frame whenever HW % 32 == 0, otherwise fall back to per-lane global reads
-        const long f = rc / HW;
-        const bool one_frame = KVLDS && (HW & 31) == 0;
-        float* kvw = Kv + (tid >> 6) * 384;
-        if (one_frame) {
-            const long f0 = (t * 32) / HW;
-            const float* src = kvtab + f0 * 384;
-            *reinterpret_cast<f32x4*>(kvw + lane * 4) = *reinterpret_cast<const f32x4*>(src + lane * 4);
-            if (lane < 32) *reinterpret_cast<f32x4*>(kvw + 256 + lane * 4) = *reinterpret_cast<const f32x4*>(src + 256 + lane * 4);
+        // the tile's frame (HW % 32 == 0: a 32-pixel tile never straddles frames) and its table [3][D 64 | U 9 x 64]:
+        // the D rows go to this wave's LDS copy (no global-load latency in the head loops)
+        const float* xt = xtab + ((t * 32) / HW) * (3 * 640);
+        float* dw = Dw + (tid >> 6) * 192;
+        if (lane < 48) {
+            const int b = lane >> 4, j = (lane & 15) * 4;
+            *reinterpret_cast<f32x4*>(dw + b * 64 + j) = *reinterpret_cast<const f32x4*>(xt + b * 640 + j);
         }
         f32x16 hc[2];
         hc[0] = zz16();
         hc[1] = zz16();
 #pragma unroll 1
         for (int b = 0; b < 3; ++b) {
-            const float* kvt = one_frame ? kvw + b * 128 : kvtab + (f * 3 + b) * 128;
-            const f32x4 qs4 = *reinterpret_cast<const f32x4*>(Cs + 192 + b * 8 + 4 * half);
-            const f32x4 kn4 = *reinterpret_cast<const f32x4*>(Cs + 216 + b * 16 + 4 * half);
-            const f32x4 vn4 = *reinterpret_cast<const f32x4*>(Cs + 216 + b * 16 + 8 + 4 * half);
-            f32x16 qT[2];
+            // rows u_0..u_7, y0 of this (frame, branch) as MFMA A operands (k = 2s + half; row 8 = y0 pairs with a constant
+            // 1, the odd half of that step multiplies a finite value by 0): requested now, consumed after the heads
+            float ua[2][5];
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot)
+#pragma unroll
+                for (int s2 = 0; s2 < 5; ++s2)
+                    ua[ot][s2] = xt[b * 640 + 64 + (s2 < 4 ? 2 * s2 + half : 8) * CO + 32 * ot + l31];
+            float bs[4];                              // B operand of step s: sigma of head 2s + half
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 // ---- Q^T tile: features 64b + 32tt + {0..31}
                 f32x16 acc = zz16();
-                f32x4 wq4[NC];                        // all weight fragments of the tile requested before the MFMA chain
+                // weight fragments requested PF at a time ahead of their MFMAs (all 16 for CIN = 128 with its 256-register
+                // budget; 4 for CIN = 64, which runs 4 waves per SIMD on 128 registers)
+                constexpr int PF = CIN == 64 ? 4 : NC;
 #pragma unroll
-                for (int c = 0; c < NC; ++c)
-                    wq4[c] = *reinterpret_cast<const f32x4*>(Wq + ((2 * c + half) * 192 + 64 * b + 32 * tt + l31) * 4);
+                for (int c0 = 0; c0 < NC; c0 += PF) {
+                    f32x4 wq4[PF];
 #pragma unroll
-                for (int c = 0; c < NC; ++c) {
+                    for (int c = 0; c < PF; ++c)
+                        wq4[c] = *reinterpret_cast<const f32x4*>(Wq + ((2 * (c0 + c) + half) * 192 + 64 * b + 32 * tt + l31) * 4);
 #pragma unroll
-                    for (int s2 = 0; s2 < 4; ++s2)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq4[c][s2], xn[c][s2], acc, 0, 0, 0);
+                    for (int c = 0; c < PF; ++c) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq4[c][s2], xn[c0 + c][s2], acc, 0, 0, 0);
+                    }
                 }
                 // ---- 2-key cosine-sim attention per head (head = 4tt + c4; lane holds features 4half..4half+3)
 #pragma unroll
                 for (int c4 = 0; c4 < 4; ++c4) {
                     const int hd = 4 * tt + c4;
                     const float q0 = acc[4 * c4], q1 = acc[4 * c4 + 1], q2 = acc[4 * c4 + 2], q3 = acc[4 * c4 + 3];
+                    const f32x4 d4 = *reinterpret_cast<const f32x4*>(dw + b * 64 + hd * 8 + 4 * half);
                     const float n2 = x32(q0 * q0 + q1 * q1 + q2 * q2 + q3 * q3);
+                    const float dd = x32(q0 * d4.x + q1 * d4.y + q2 * d4.z + q3 * d4.w);
                     const float inv = __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f));        // 1 / max(|q|, 1e-12)  (F.normalize)
-                    const f32x4 kc4 = *reinterpret_cast<const f32x4*>(kvt + hd * 8 + 4 * half);
-                    const f32x4 vc4 = *reinterpret_cast<const f32x4*>(kvt + 64 + hd * 8 + 4 * half);
-                    const float a0 = q0 * inv * qs4.x, a1 = q1 * inv * qs4.y, a2 = q2 * inv * qs4.z, a3 = q3 * inv * qs4.w;
-                    const float sn = x32(a0 * kn4.x + a1 * kn4.y + a2 * kn4.z + a3 * kn4.w);
-                    const float sc = x32(a0 * kc4.x + a1 * kc4.y + a2 * kc4.z + a3 * kc4.w);
                     // softmax over the 2 keys [null, condition] in closed form: weight of the condition key =
-                    // sigmoid(8 (sc - sn)); one v_exp_f32 + one v_rcp_f32 (1 ulp each) instead of two expf and two divisions
-                    const float ac = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f((sn - sc) * (8.0f * 1.4426950408889634f)));
-                    acc[4 * c4] = vn4.x + ac * (vc4.x - vn4.x);
-                    acc[4 * c4 + 1] = vn4.y + ac * (vc4.y - vn4.y);
-                    acc[4 * c4 + 2] = vn4.z + ac * (vc4.z - vn4.z);
-                    acc[4 * c4 + 3] = vn4.w + ac * (vc4.w - vn4.w);
+                    // sigmoid(8 (s_ctx - s_null)) = 1 / (1 + 2^(q.D/|q|)); one v_exp_f32 + one v_rcp_f32 (1 ulp each)
+                    const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(dd * inv));
+                    if ((hd & 1) == 0) bs[hd >> 1] = sg;                  // (both halves hold every head's sigma)
+                    else bs[hd >> 1] = half ? sg : bs[hd >> 1];
                 }
-                qT[tt] = acc;
                 TSTAMP();   // Q tile tt + its 4 heads
             }
-            // ---- y^T (64 co x 32 px) = Wo_b^T . o^T, then LayerNorm over co and accumulate with gain g3[b]
+            // ---- y^T (64 co x 32 px) = [u_0 .. u_7 | y0]^T . [sigma_0 .. sigma_7 | 1]^T, then LayerNorm over co and
+            // accumulate with gain g3[b]
             f32x16 yT[2];
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot) {
                 f32x16 acc = zz16();
-                f32x4 wo4[8];
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    wo4[e] = *reinterpret_cast<const f32x4*>(Wo + ((b * 16 + 2 * e + half) * CO + 32 * ot + l31) * 4);
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt)
-#pragma unroll
-                    for (int c4 = 0; c4 < 4; ++c4) {
-#pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2)
-                            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wo4[4 * tt + c4][s2], qT[tt][4 * c4 + s2], acc, 0, 0, 0);
-                    }
+                for (int s2 = 0; s2 < 4; ++s2)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[ot][s2], bs[s2], acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ua[ot][4], half ? 0.0f : 1.0f, acc, 0, 0, 0);
                 yT[ot] = acc;
             }
             TSTAMP();   // to_out MFMAs issued
@@ -219,33 +207,78 @@ __global__ __launch_bounds__(512) void xattn_c64_kernel(const float* __restrict_
 #endif
 }
 
+// Per-clip tables of one conditioned block (see the header): xtab[f][b] = [D (8 heads x 8) | u_0 .. u_7 (Co each) | y0 (Co)].
+// kvtab[f][b] = [k_ctx (l2-normalised * k_scale) 64 | v_ctx 64], nulltab[b] = [k_null 8 | v_null 8] (dawn_xattn_prep);
+// wo_b packed [16][Co][4] (k = 8 h + i).  One block per (frame, branch); thread per table entry.
+__global__ __launch_bounds__(256) void xattn_tables_kernel(const float* __restrict__ kvtab, const float* __restrict__ nulltab,
+                                                           const float* __restrict__ q_scale, const float* __restrict__ wo0,
+                                                           const float* __restrict__ wo1, const float* __restrict__ wo2,
+                                                           int Co, float* __restrict__ xtab) {
+    const int f = blockIdx.x / 3, b = blockIdx.x - 3 * f;
+    const float* kv = kvtab + ((long)f * 3 + b) * 128;
+    const float* nt = nulltab + b * 16;
+    const float* wo = b == 0 ? wo0 : (b == 1 ? wo1 : wo2);
+    const int W = 64 + 9 * Co;
+    float* o = xtab + ((long)f * 3 + b) * W;
+    for (int e = threadIdx.x; e < W; e += 256) {
+        float v;
+        if (e < 64) {
+            const int i = e & 7;
+            v = q_scale[b * 8 + i] * (nt[i] - kv[e]) * (8.0f * 1.4426950408889634f);
+        } else {
+            const int r = (e - 64) / Co, co = (e - 64) - r * Co;
+            double a = 0.0;
+            if (r < 8) {
+                for (int i = 0; i < 8; ++i) {
+                    const int k = 8 * r + i;
+                    a += (double)wo[((k >> 2) * Co + co) * 4 + (k & 3)] * (double)(kv[64 + k] - nt[8 + i]);
+                }
+            } else {
+                for (int k = 0; k < 64; ++k) a += (double)wo[((k >> 2) * Co + co) * 4 + (k & 3)] * (double)nt[8 + (k & 7)];
+            }
+            v = (float)a;
+        }
+        o[e] = v;
+    }
+}
+
 }  // namespace
 
+extern "C" int dawn_xattn_tables(const float* kvtab, const float* nulltab, const float* q_scale, const float* wo0,
+                                 const float* wo1, const float* wo2, int F, int Co, float* xtab, void* stream) {
+    if (F <= 0) return 0;
+    hipLaunchKernelGGL(xattn_tables_kernel, dim3(3 * F), dim3(256), 0, (hipStream_t)stream, kvtab, nulltab, q_scale, wo0, wo1,
+                       wo2, Co, xtab);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
-                                    int HW, const float* wq, const float* wo0, const float* wo1, const float* wo2,
-                                    const float* g3, const float* q_scale, const float* kvtab, const float* nulltab,
-                                    float eps, float* out, void* stream) {
+                                    int HW, const float* wq, const float* g3, const float* xtab, float eps, float* out,
+                                    void* stream) {
     const int Cin = C0 + C1;
     if ((Cin != 64 && Cin != 128) || C0 % 8 != 0 || (ld0 % 4) || (in1 && (ld1 % 4)))
         return dawn_set_error_msg(-51, "dawn_xattn_layer_c64: Cin must be 64 or 128 (two sources allowed), Co = 64");
+    if (HW % 32 != 0 || rows % 32 != 0)
+        return dawn_set_error_msg(-52, "dawn_xattn_layer_c64: H*W must be a multiple of 32 (a 32-pixel tile lies in one frame)");
     if (rows <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    const long ntiles = (rows + 31) / 32;
+    const long ntiles = rows / 32;
     long grid = (ntiles + 7) / 8;
-    if (grid > 256) grid = 256;                 // one resident block per CU (LDS-bound): every block gets the same tile count
+    const long cap = Cin == 64 ? 512 : 256;     // resident blocks: 2 per CU at 56 KB of LDS (Cin = 64), 1 at 105 KB
+    if (grid > cap) grid = cap;
+    int lds = ((Cin / 4) * 192 * 4 + 192 + 8 * 192) * 4;
 #ifdef DAWN_XA_TIMING
-    const int lds = Cin == 64 ? 116736 : ((Cin / 4) * 192 * 4 + 3 * 16 * 64 * 4 + 272) * 4;
-#else
-    const int lds = ((Cin / 4) * 192 * 4 + 3 * 16 * 64 * 4 + 272 + (Cin == 64 ? 8 * 384 : 0)) * 4;
+    lds += 8 * 24 * 8;
 #endif
     if (Cin == 64) {
         (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(xattn_c64_kernel<64>, dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows, HW,
-                           wq, wo0, wo1, wo2, g3, q_scale, kvtab, nulltab, eps, out, ntiles);
+                           wq, g3, xtab, eps, out, ntiles);
     } else {
         (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         hipLaunchKernelGGL(xattn_c64_kernel<128>, dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows,
-                           HW, wq, wo0, wo1, wo2, g3, q_scale, kvtab, nulltab, eps, out, ntiles);
+                           HW, wq, g3, xtab, eps, out, ntiles);
     }
     DAWN_LAUNCH_CHECK();
     return 0;

@@ -242,18 +242,31 @@ class HipOps:
         return out
 
     @staticmethod
-    def can_fuse_xattn(Cin: int, Co: int, C0: int) -> bool:
-        return Co == 64 and Cin in (64, 128) and C0 % 8 == 0
+    def can_fuse_xattn(Cin: int, Co: int, C0: int, HW: int = 32) -> bool:
+        return Co == 64 and Cin in (64, 128) and C0 % 8 == 0 and HW % 32 == 0
+
+    def xattn_tables(self, kvtab: Tensor, nulltab: Tensor, q_scale: Tensor, wo, Co: int) -> Tensor:
+        """Once per clip and conditioned block: (F,3,64+9*Co) = per (frame, branch) [D | u_0..u_7 | y0] such that
+        softmax over [null, ctx] == sigmoid(-q.D/|q|) and to_out(o) == y0 + sum_h sigma_h u_h (include/dawn_hip.h)."""
+        F = kvtab.shape[0]
+        self._require(kvtab, nulltab, q_scale, *wo)
+        xtab = torch.empty(F, 3, 64 + 9 * Co, device=kvtab.device, dtype=torch.float32)
+        check(self.L.dawn_xattn_tables(_p(kvtab), _p(nulltab), _p(q_scale), _p(wo[0]), _p(wo[1]), _p(wo[2]), F, Co, _p(xtab),
+                                       self._stream()), "dawn_xattn_tables")
+        return xtab
 
     def xattn_layer_c64(self, x: Tensor, x2: Optional[Tensor], HW: int, wq: Tensor, wo, g3: Tensor, q_scale: Tensor,
-                        kvtab: Tensor, nulltab: Tensor, eps: float = 1e-5) -> Tensor:
-        """h_cond (rows,64) = sum over the three branches of LN(to_out(attn(LN(x)))) in one launch."""
+                        kvtab: Tensor, nulltab: Tensor, eps: float = 1e-5, xtab: Optional[Tensor] = None) -> Tensor:
+        """h_cond (rows,64) = sum over the three branches of LN(to_out(attn(LN(x)))) in one launch.  The kernel reads
+        the per-clip tables `xtab` (xattn_tables of kvtab / nulltab / q_scale / wo); built here if not supplied."""
         rows = x.shape[0]
-        self._require(x, x2, wq, g3, q_scale, kvtab, nulltab, *wo)
+        if xtab is None:
+            xtab = self.xattn_tables(kvtab, nulltab, q_scale, wo, 64)
+        self._require(x, x2, wq, g3, xtab)
+        assert xtab.is_contiguous() and xtab.shape[1:] == (3, 640) and rows == xtab.shape[0] * HW
         out = self.empty(rows, 64, like=x)
         check(self.L.dawn_xattn_layer_c64(_p(x), x.shape[1], _ld(x), _p(x2), 0 if x2 is None else x2.shape[1], _ld(x2),
-                                          rows, HW, _p(wq), _p(wo[0]), _p(wo[1]), _p(wo[2]), _p(g3), _p(q_scale),
-                                          _p(kvtab), _p(nulltab), eps, _p(out), self._stream()),
+                                          rows, HW, _p(wq), _p(g3), _p(xtab), eps, _p(out), self._stream()),
               "dawn_xattn_layer_c64")
         return out
 

@@ -31,6 +31,7 @@ class ClipState:
     fea_pre: Tensor            # (h*w, dim)
     kvtab: List[Tensor]        # per conditioned block: (F, 3, 128)
     nulltab: List[Tensor]      # per conditioned block: (3, 16)
+    xtab: List[Optional[Tensor]]   # per conditioned block with a fused (Co = 64) cross-attention: (F, 3, 640)
     rcos: Tensor
     rsin: Tensor
     band: Tensor
@@ -46,7 +47,7 @@ def build_clip_state(ops, P: PackedUNet, fea272: Tensor, cond: Tensor, win: Opti
     F = cond.shape[0]
     fea_cl = fea272.permute(1, 2, 0).reshape(h * w, Cf).contiguous()          # layout change only
     fea_pre = ops.conv_gemm(fea_cl, P.wfea, P.dim, F=1, Hi=h, Wi=w, KH=7, KW=7, pad=3, bias=P.b_init)
-    kvtabs, nulltabs = [None] * P.n_cond_blocks, [None] * P.n_cond_blocks
+    kvtabs, nulltabs, xtabs = [None] * P.n_cond_blocks, [None] * P.n_cond_blocks, [None] * P.n_cond_blocks
     n_aud, n_pose, _ = P.cond_dims
     cols = {"aud": (0, n_aud), "pose": (n_aud, n_aud + n_pose), "eye": (n_aud + n_pose, cond.shape[1])}
     from .pack import BRANCHES
@@ -59,9 +60,11 @@ def build_clip_state(ops, P: PackedUNet, fea272: Tensor, cond: Tensor, win: Opti
             kv = ops.linear(ctx, rb.kv_w[b], None)
             ops.xattn_prep(kv, rb.k_scale[b], rb.null_kv[b], kvtab, b, nulltab)
         kvtabs[rb.cond_index], nulltabs[rb.cond_index] = kvtab, nulltab
+        if ops.can_fuse_xattn(rb.Cin, rb.Co, 8, h * w):                     # level-0 blocks: tables of the fused kernel
+            xtabs[rb.cond_index] = ops.xattn_tables(kvtab, nulltab, rb.q_scale, rb.wo, rb.Co)
     rcos, rsin = P.rotary_tables(F + 2 * win)
     return ClipState(F=F, Ttotal=F if Ttotal is None else Ttotal, f0=f0, h=h, w=w, fea_pre=fea_pre, kvtab=kvtabs,
-                     nulltab=nulltabs, rcos=rcos, rsin=rsin, band=P.band(win), win=win, comm=comm)
+                     nulltab=nulltabs, xtab=xtabs, rcos=rcos, rsin=rsin, band=P.band(win), win=win, comm=comm)
 
 
 def _conditioned_blocks(P: PackedUNet):
@@ -91,9 +94,9 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     hcond, film = None, None
 
     def cross_attention():
-        if ops.can_fuse_xattn(rb.Cin, Co, x.shape[1]):
+        if ops.can_fuse_xattn(rb.Cin, Co, x.shape[1], H * W) and cs.xtab[rb.cond_index] is not None:
             return ops.xattn_layer_c64(x, x2, H * W, rb.wq, rb.wo, rb.g3, rb.q_scale, cs.kvtab[rb.cond_index],
-                                       cs.nulltab[rb.cond_index])
+                                       cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index])
         # LayerNorm_img is materialised (one streaming pass) so that to_q runs as a prologue-free GEMM
         q = ops.conv_gemm(ops.ln_rows(x, x2), rb.wq, 192, w_bf3=rb.wqs, **g)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)

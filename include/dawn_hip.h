@@ -105,13 +105,18 @@ int dawn_xattn_core(const float* q, float* o, long rows, int HW, const float* kv
 /* h_cond[row][c] = sum_b LayerNorm_img(y3[row][b][:])[c] * g[b][c]   (to_out.1, MT:513; sum MT:463) */
 int dawn_xattn_ln_sum(const float* y3, const float* g3, float* out, long rows, int Co, float eps, void* stream);
 
-/* Fused cross-attention branch for Co = 64, Cin in {64, 128} (two sources allowed):
+/* Per-clip tables of one conditioned block (the condition is DDIM-step-invariant, so this runs once per clip):
+ * xtab (F,3,64+9*Co): per (frame, branch)  D[h][i] = q_scale[i] (k_null[i] - k_ctx[h][i]) 8 log2(e)   (64 floats),
+ * u_h = Wo[8h..8h+7]^T (v_ctx,h - v_null) for h = 0..7 and y0 = Wo^T v_null (9 rows of Co).  With them the 2-key
+ * softmax is sigma_h = 1 / (1 + 2^(q_h . D_h / |q_h|)) and to_out(o) = y0 + sum_h sigma_h u_h  (exact rewrites of
+ * MT:540-558).  kvtab / nulltab from dawn_xattn_prep; wo0..2 packed (64 -> Co). */
+int dawn_xattn_tables(const float* kvtab, const float* nulltab, const float* q_scale, const float* wo0,
+                      const float* wo1, const float* wo2, int F, int Co, float* xtab, void* stream);
+/* Fused cross-attention branch for Co = 64, Cin in {64, 128} (two sources allowed), H*W % 32 == 0:
  * out[row][:] = sum_b LN(to_out_b(attn_b(LN([in0|in1][row]))))  -- everything of MT:454-468 / MT:516-559 in one launch.
- * wq packed (Cin -> 192, LayerNorm gains folded), wo0..2 packed (64 -> 64), g3 (3,64), q_scale (3,8). */
+ * wq packed (Cin -> 192, LayerNorm gains folded), g3 (3,64), xtab (F,3,640) from dawn_xattn_tables. */
 int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows, int HW,
-                         const float* wq, const float* wo0, const float* wo1, const float* wo2, const float* g3,
-                         const float* q_scale, const float* kvtab, const float* nulltab, float eps, float* out,
-                         void* stream);
+                         const float* wq, const float* g3, const float* xtab, float eps, float* out, void* stream);
 
 /* ---- A9/A10 windowed temporal self-attention per pixel (MT:665-725 with the MT:117 window mask,
  * == LA:71-99/300-342).  qkv (Fext*HW, 768) = [q|k|v][head 8][32]; queries are frames

@@ -164,10 +164,27 @@ class RefOps:
         return ((y - mean) * torch.rsqrt(var + eps) * g3[None]).sum(dim=1)
 
     @staticmethod
-    def can_fuse_xattn(Cin, Co, C0):
+    def can_fuse_xattn(Cin, Co, C0, HW=32):
         return Co == 64 and Cin in (64, 128) and C0 % 8 == 0
 
-    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5):
+    def xattn_tables(self, kvtab, nulltab, q_scale, wo, Co):
+        """[D | u_0..u_7 | y0] per (frame, branch), written from the definitions (fp64)."""
+        F = kvtab.shape[0]
+        out = torch.zeros(F, 3, 64 + 9 * Co, dtype=torch.float64)
+        for b in range(3):
+            W = _unpack(wo[b]).double()                                   # (64, Co), k = 8 h + i
+            kc, vc = kvtab[:, b, :64].double().view(F, 8, 8), kvtab[:, b, 64:].double().view(F, 8, 8)
+            kn, vn = nulltab[b, :8].double(), nulltab[b, 8:].double()
+            out[:, b, :64] = (q_scale[b].double()[None, None] * (kn[None, None] - kc) * (8.0 * math.log2(math.e))).reshape(F, 64)
+            u = torch.einsum("fhi,hic->fhc", vc - vn[None, None], W.view(8, 8, Co))
+            y0 = (vn.repeat(8)[:, None] * W).sum(0)
+            out[:, b, 64:64 + 8 * Co] = u.reshape(F, 8 * Co)
+            out[:, b, 64 + 8 * Co:] = y0[None]
+        return out.float().to(kvtab.device)
+
+    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5, xtab=None):
+        """The ORIGINAL formulation (MT:516-559 op by op); `xtab` (the kernel's per-clip tables) is not used here, so the
+        GPU test of the fused kernel also proves the table algebra."""
         rows = x.shape[0]
         stats = self.ln_rowstats(x, x2, eps)
         q = self.conv_gemm(x, wq, 192, in1=x2, row_stats=stats, F=rows, Hi=1, Wi=1)

@@ -327,9 +327,22 @@ def test_xattn_pieces(hip, ref):
         check(f"xattn_ln_sum/Co{Co}", hip.xattn_ln_sum(y3.cuda(), g3.cuda(), Co), ref.xattn_ln_sum(y3, g3, Co), 2e-5)
 
 
-@pytest.mark.parametrize("C0,C1,Fn,HW", [(64, 0, 5, 64), (64, 64, 3, 100), (128, 0, 2, 33), (64, 0, 2, 4096)])
+@pytest.mark.parametrize("Co", [64, 128, 512])
+def test_xattn_tables(hip, ref, Co):
+    Fn = 7
+    wo = [packw(64, Co, seed=10 + b) for b in range(3)]
+    qs = rnd(3, 8, seed=5) * 0.2 + 1
+    kvtab, nulltab = torch.zeros(Fn, 3, 128), torch.zeros(3, 16)
+    for b in range(3):
+        ref.xattn_prep(rnd(Fn, 128, seed=20 + b), rnd(8, seed=30 + b) * 0.2 + 1, rnd(2, 8, seed=40 + b), kvtab, b, nulltab)
+    got = hip.xattn_tables(kvtab.cuda(), nulltab.cuda(), qs.cuda(), [w.cuda() for w in wo], Co)
+    check(f"xattn_tables/Co{Co}", got, ref.xattn_tables(kvtab, nulltab, qs, wo, Co), 2e-6)
+
+
+@pytest.mark.parametrize("C0,C1,Fn,HW", [(64, 0, 5, 64), (64, 64, 3, 96), (128, 0, 2, 32), (64, 0, 2, 4096), (64, 64, 2, 1024)])
 def test_xattn_layer_c64(hip, ref, C0, C1, Fn, HW):
-    """Fused branch kernel == LN stats + q GEMM + 2-key attention + 3 out GEMMs + LN-sum."""
+    """Fused branch kernel (per-clip table algebra: sigmoid of one dot product, to_out as a K = 9 product) ==
+    LN stats + q GEMM + 2-key softmax attention + 3 out GEMMs + LN-sum in the ORIGINAL formulation."""
     rows = Fn * HW
     x = rnd(rows, C0, seed=1) * 1.5 + 0.3
     x2 = rnd(rows, C1, seed=2) if C1 else None
@@ -343,6 +356,16 @@ def test_xattn_layer_c64(hip, ref, C0, C1, Fn, HW):
     got = hip.xattn_layer_c64(x.cuda(), None if x2 is None else x2.cuda(), HW, wq.cuda(), [w.cuda() for w in wo],
                               g3.cuda(), qs.cuda(), kvtab.cuda(), nulltab.cuda())
     check(f"xattn_layer_c64/{C0}+{C1}_F{Fn}_HW{HW}", got, want, 3e-5)
+
+
+def test_xattn_layer_c64_rejects_straddling_tiles(hip):
+    """H*W not a multiple of 32 (a pixel tile would straddle two frames' tables): the op refuses, the orchestration
+    (`can_fuse_xattn`) takes the unfused chain instead."""
+    from dawn_pytorch_amd._lib import DawnHipError
+    assert not hip.can_fuse_xattn(64, 64, 64, 100)
+    with pytest.raises(DawnHipError):
+        hip.xattn_layer_c64(torch.zeros(200, 64, device="cuda"), None, 100, torch.zeros(16, 192, 4, device="cuda"), None,
+                            torch.ones(3, 64, device="cuda"), None, None, None, xtab=torch.zeros(2, 3, 640, device="cuda"))
 
 
 # ---------------------------------------------------------------------------------------------- attention cores

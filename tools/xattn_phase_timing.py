@@ -17,12 +17,13 @@ g3 = (torch.randn(3, 64) * 0.2 + 1).to(dev)
 q_scale = (torch.rand(3, 8) + 0.5).to(dev)
 kvtab = torch.randn(F, 3, 128, device=dev)
 nulltab = torch.randn(3, 16, device=dev)
+xtab = ops.xattn_tables(kvtab, nulltab, q_scale, wo, 64)
 dbg = torch.zeros(256 * 8 * 24, dtype=torch.int64, device=dev)
 ops.L.dawn_xattn_set_debug.argtypes = [ctypes.c_void_p]
 assert ops.L.dawn_xattn_set_debug(dbg.data_ptr()) == 0
 for _ in range(2):
     dbg.zero_()
-    ops.xattn_layer_c64(x, None, HW, wq, wo, g3, q_scale, kvtab, nulltab)
+    ops.xattn_layer_c64(x, None, HW, wq, wo, g3, q_scale, kvtab, nulltab, xtab=xtab)
     torch.cuda.synchronize()
 t = dbg.cpu().numpy().reshape(256, 8, 24).astype(np.float64)
 names = ["tile start", "x + LN"] + sum([[f"b{b} Q0+heads", f"b{b} Q1+heads", f"b{b} out MFMA", f"b{b} LN+acc"] for b in range(3)], []) + ["stored"]
