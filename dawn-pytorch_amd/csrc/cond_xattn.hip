@@ -144,7 +144,109 @@ __global__ __launch_bounds__(256) void xattn_ln_sum_kernel(const float* __restri
     }
 }
 
+// Unfused levels (Co = 128 / 256 / 512): everything after the Q projection in ONE pass over q, using the per-clip tables
+// of dawn_xattn_tables (xattn_layer.hip): per (row, branch) sigma_h = 1 / (1 + 2^(q_h . D_h / |q_h|)), y = y0 + sum_h sigma_h u_h,
+// LayerNorm_img over Co, gain, sum over the branches.  Replaces xattn_core + three (64 -> Co) GEMMs + xattn_ln_sum and their
+// (rows, 192) / (rows, 3 Co) intermediates.  L lanes per row (float4 columns sub + i L), R = 4 consecutive rows (one frame)
+// per lane group so that the 9 table rows are loaded once per 4 rows; lane `sub` evaluates head sub & 7 and the 8 sigmas
+// are exchanged by shuffles.
+template <int L, int MAXQ>
+__global__ __launch_bounds__(256) void xattn_sigma_out_kernel(const float* __restrict__ q, long rows, int HW,
+                                                              const float* __restrict__ xtab, const float* __restrict__ g3,
+                                                              int Co, float eps, float* __restrict__ out) {
+    constexpr int RPB = 256 / L, R = 4;
+    const int sub = threadIdx.x % L;
+    const int lane = threadIdx.x & 63;
+    const int gbase = lane - sub;                              // first lane of this row group within the wave
+    const long row0 = ((long)blockIdx.x * RPB + threadIdx.x / L) * R;
+    if (row0 >= rows) return;                                  // (whole groups only: rows % 4 == 0)
+    const int nq = Co >> 2;
+    const int W = 64 + 9 * Co;
+    const float* xt = xtab + (row0 / HW) * 3 * W;
+    const int hd = sub & 7;
+    f32x4 acc[R][MAXQ];
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) acc[r][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float rCo = 1.0f / (float)Co;
+#pragma unroll 1
+    for (int b = 0; b < 3; ++b) {
+        const float* tb = xt + b * W;
+        const f32x4 d0 = *reinterpret_cast<const f32x4*>(tb + hd * 8), d1 = *reinterpret_cast<const f32x4*>(tb + hd * 8 + 4);
+        f32x4 u[9][MAXQ], g[MAXQ];
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int qd = sub + i * L;
+            const bool ok = qd < nq;
+#pragma unroll
+            for (int k = 0; k < 9; ++k)
+                u[k][i] = ok ? *reinterpret_cast<const f32x4*>(tb + 64 + k * Co + qd * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+            g[i] = ok ? *reinterpret_cast<const f32x4*>(g3 + b * Co + qd * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float* qr = q + (row0 + r) * 192 + b * 64 + hd * 8;
+            const f32x4 q0 = *reinterpret_cast<const f32x4*>(qr), q1 = *reinterpret_cast<const f32x4*>(qr + 4);
+            const float n2 = (q0.x * q0.x + q0.y * q0.y + q0.z * q0.z + q0.w * q0.w) + (q1.x * q1.x + q1.y * q1.y + q1.z * q1.z + q1.w * q1.w);
+            const float dd = (q0.x * d0.x + q0.y * d0.y + q0.z * d0.z + q0.w * d0.w) + (q1.x * d1.x + q1.y * d1.y + q1.z * d1.z + q1.w * d1.w);
+            const float sg = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(dd * __builtin_amdgcn_rsqf(fmaxf(n2, 1e-24f))));
+            f32x4 y[MAXQ];
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) y[i] = u[8][i];
+#pragma unroll
+            for (int k = 0; k < 8; ++k) {
+                const float sk = __shfl(sg, gbase + k, 64);    // sigma of head k (lane k of the group evaluated it)
+#pragma unroll
+                for (int i = 0; i < MAXQ; ++i) y[i] += u[k][i] * sk;
+            }
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) s1 += (y[i].x + y[i].y) + (y[i].z + y[i].w);   // (columns beyond Co are zero)
+            const float mu = wave_sum(s1, L) * rCo;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) {
+                if (sub + i * L < nq) {
+                    const f32x4 dl = y[i] - mu;
+                    s2 += (dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w);
+                }
+            }
+            const float rs = __builtin_amdgcn_rsqf(wave_sum(s2, L) * rCo + eps);
+#pragma unroll
+            for (int i = 0; i < MAXQ; ++i) acc[r][i] += (y[i] - mu) * rs * g[i];
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < R; ++r)
+#pragma unroll
+        for (int i = 0; i < MAXQ; ++i) {
+            const int qd = sub + i * L;
+            if (qd < nq) *reinterpret_cast<f32x4*>(out + (row0 + r) * Co + qd * 4) = acc[r][i];
+        }
+}
+
 }  // namespace
+
+extern "C" int dawn_xattn_sigma_out(const float* q, long rows, int HW, const float* xtab, const float* g3, int Co, float eps,
+                                    float* out, void* stream) {
+    if (Co % 32 != 0 || Co < 32 || Co > 512 || HW % 4 != 0 || rows % 4 != 0)
+        return dawn_set_error_msg(-53, "dawn_xattn_sigma_out: need Co % 32 == 0, 32 <= Co <= 512, H*W % 4 == 0");
+    if (rows <= 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const int nq = Co / 4;
+#define LAUNCH_XS(L, MQ)                                                                                                   \
+    hipLaunchKernelGGL((xattn_sigma_out_kernel<L, MQ>), dim3(dawn_cdiv(rows, (256 / L) * 4)), dim3(256), 0, s, q, rows, HW, xtab, \
+                       g3, Co, eps, out)
+    if (nq > 64) LAUNCH_XS(64, 2);
+    else if (nq > 32) LAUNCH_XS(64, 1);
+    else if (nq > 16) LAUNCH_XS(32, 1);
+    else if (nq > 8) LAUNCH_XS(16, 1);
+    else LAUNCH_XS(8, 1);
+#undef LAUNCH_XS
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
 
 extern "C" int dawn_xattn_prep(const float* kv, int F, const float* k_scale, const float* null_kv, float* kvtab,
                                int branch, float* nulltab, void* stream) {

@@ -255,6 +255,22 @@ class HipOps:
                                        self._stream()), "dawn_xattn_tables")
         return xtab
 
+    @staticmethod
+    def can_fuse_xattn_out(Co: int, HW: int) -> bool:
+        return Co % 32 == 0 and 32 <= Co <= 512 and HW % 4 == 0
+
+    def xattn_sigma_out(self, q: Tensor, HW: int, xtab: Tensor, g3: Tensor, Co: int, eps: float = 1e-5) -> Tensor:
+        """q (rows,192) = raw to_q output -> h_cond (rows,Co): the 2-key attention, the three to_out projections, their
+        LayerNorms and the branch sum in one pass (per-clip tables `xtab` from xattn_tables)."""
+        rows = q.shape[0]
+        assert q.is_contiguous() and q.shape[1] == 192 and xtab.is_contiguous() and xtab.shape[1:] == (3, 64 + 9 * Co)
+        assert rows == xtab.shape[0] * HW
+        self._require(q, xtab, g3)
+        out = self.empty(rows, Co, like=q)
+        check(self.L.dawn_xattn_sigma_out(_p(q), rows, HW, _p(xtab), _p(g3), Co, eps, _p(out), self._stream()),
+              "dawn_xattn_sigma_out")
+        return out
+
     def xattn_layer_c64(self, x: Tensor, x2: Optional[Tensor], HW: int, wq: Tensor, wo, g3: Tensor, q_scale: Tensor,
                         kvtab: Tensor, nulltab: Tensor, eps: float = 1e-5, xtab: Optional[Tensor] = None) -> Tensor:
         """h_cond (rows,64) = sum over the three branches of LN(to_out(attn(LN(x)))) in one launch.  The kernel reads

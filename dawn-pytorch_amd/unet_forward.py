@@ -60,7 +60,8 @@ def build_clip_state(ops, P: PackedUNet, fea272: Tensor, cond: Tensor, win: Opti
             kv = ops.linear(ctx, rb.kv_w[b], None)
             ops.xattn_prep(kv, rb.k_scale[b], rb.null_kv[b], kvtab, b, nulltab)
         kvtabs[rb.cond_index], nulltabs[rb.cond_index] = kvtab, nulltab
-        if ops.can_fuse_xattn(rb.Cin, rb.Co, 8, h * w):                     # level-0 blocks: tables of the fused kernel
+        # per-clip tables of the sigma-affine form (fused level-0 kernel; one-pass kernel after to_q elsewhere)
+        if ops.can_fuse_xattn(rb.Cin, rb.Co, 8, 32) or ops.can_fuse_xattn_out(rb.Co, 4):
             xtabs[rb.cond_index] = ops.xattn_tables(kvtab, nulltab, rb.q_scale, rb.wo, rb.Co)
     rcos, rsin = P.rotary_tables(F + 2 * win)
     return ClipState(F=F, Ttotal=F if Ttotal is None else Ttotal, f0=f0, h=h, w=w, fea_pre=fea_pre, kvtab=kvtabs,
@@ -99,6 +100,8 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
                                        cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index])
         # LayerNorm_img is materialised (one streaming pass) so that to_q runs as a prologue-free GEMM
         q = ops.conv_gemm(ops.ln_rows(x, x2), rb.wq, 192, w_bf3=rb.wqs, **g)
+        if ops.can_fuse_xattn_out(Co, H * W) and cs.xtab[rb.cond_index] is not None:
+            return ops.xattn_sigma_out(q, H * W, cs.xtab[rb.cond_index], rb.g3, Co)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)
         y3 = ops.empty(F * H * W, 3 * Co, like=x)
         for b in range(3):

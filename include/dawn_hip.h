@@ -112,6 +112,11 @@ int dawn_xattn_ln_sum(const float* y3, const float* g3, float* out, long rows, i
  * MT:540-558).  kvtab / nulltab from dawn_xattn_prep; wo0..2 packed (64 -> Co). */
 int dawn_xattn_tables(const float* kvtab, const float* nulltab, const float* q_scale, const float* wo0,
                       const float* wo1, const float* wo2, int F, int Co, float* xtab, void* stream);
+/* Levels without the fused kernel (Co = 128 / 256 / 512; any Co % 32 == 0 up to 512, H*W % 4 == 0): everything after the
+ * Q projection in one pass -- q (rows,192) raw to_q output, xtab (F,3,64+9*Co) from dawn_xattn_tables, g3 (3,Co):
+ * out[row][:] = sum_b LN(y0_b + sum_h sigma_bh u_bh) * g3[b]   ==   dawn_xattn_core + 3 x to_out + dawn_xattn_ln_sum. */
+int dawn_xattn_sigma_out(const float* q, long rows, int HW, const float* xtab, const float* g3, int Co, float eps,
+                         float* out, void* stream);
 /* Fused cross-attention branch for Co = 64, Cin in {64, 128} (two sources allowed), H*W % 32 == 0:
  * out[row][:] = sum_b LN(to_out_b(attn_b(LN([in0|in1][row]))))  -- everything of MT:454-468 / MT:516-559 in one launch.
  * wq packed (Cin -> 192, LayerNorm gains folded), g3 (3,64), xtab (F,3,640) from dawn_xattn_tables. */

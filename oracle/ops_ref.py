@@ -167,6 +167,27 @@ class RefOps:
     def can_fuse_xattn(Cin, Co, C0, HW=32):
         return Co == 64 and Cin in (64, 128) and C0 % 8 == 0
 
+    @staticmethod
+    def can_fuse_xattn_out(Co, HW):
+        return Co % 32 == 0 and 32 <= Co <= 512 and HW % 4 == 0
+
+    def xattn_sigma_out(self, q, HW, xtab, g3, Co, eps=1e-5):
+        """Reference of the one-pass kernel, evaluated from the per-clip tables (the tables themselves are checked
+        against the definitions by test_xattn_tables, the whole chain against the original formulation by
+        test_xattn_sigma_out_equals_unfused_chain)."""
+        rows = q.shape[0]
+        F = rows // HW
+        qh = q.view(F, HW, 3, 8, 8)
+        D = xtab[:, :, :64].view(F, 1, 3, 8, 8)
+        n = qh.norm(dim=-1).clamp_min(1e-12)
+        sig = 1.0 / (1.0 + torch.exp2((qh * D).sum(-1) / n))                                   # (F,HW,3,8)
+        U = xtab[:, :, 64:64 + 8 * Co].view(F, 3, 8, Co)
+        y0 = xtab[:, :, 64 + 8 * Co:]                                                          # (F,3,Co)
+        y = y0[:, None] + torch.einsum("fpbh,fbhc->fpbc", sig, U)
+        mean = y.mean(-1, keepdim=True)
+        var = y.var(-1, unbiased=False, keepdim=True)
+        return ((y - mean) * torch.rsqrt(var + eps) * g3[None, None]).sum(2).reshape(rows, Co)
+
     def xattn_tables(self, kvtab, nulltab, q_scale, wo, Co):
         """[D | u_0..u_7 | y0] per (frame, branch), written from the definitions (fp64)."""
         F = kvtab.shape[0]

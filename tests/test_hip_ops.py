@@ -358,6 +358,26 @@ def test_xattn_layer_c64(hip, ref, C0, C1, Fn, HW):
     check(f"xattn_layer_c64/{C0}+{C1}_F{Fn}_HW{HW}", got, want, 3e-5)
 
 
+@pytest.mark.parametrize("Co,Fn,HW", [(128, 3, 1024), (256, 5, 64), (512, 7, 16), (32, 2, 4), (96, 3, 36), (64, 2, 64)])
+def test_xattn_sigma_out_equals_unfused_chain(hip, ref, Co, Fn, HW):
+    """One-pass kernel (tables + sigmoid + K = 9 affine form + LN + sum) == xattn_core + 3 to_out GEMMs + xattn_ln_sum in
+    the original formulation, and == its own table-based reference."""
+    rows = Fn * HW
+    q = rnd(rows, 192, seed=1) * 1.3
+    wo = [packw(64, Co, seed=10 + b) for b in range(3)]
+    g3, qs = rnd(3, Co, seed=4) * 0.2 + 1, rnd(3, 8, seed=5) * 0.2 + 1
+    kvtab, nulltab = torch.zeros(Fn, 3, 128), torch.zeros(3, 16)
+    for b in range(3):
+        ref.xattn_prep(rnd(Fn, 128, seed=20 + b), rnd(8, seed=30 + b) * 0.2 + 1, rnd(2, 8, seed=40 + b), kvtab, b, nulltab)
+    o = ref.xattn_core(q.clone(), HW, kvtab, nulltab, qs)
+    y3 = torch.cat([ref.conv_gemm(o[:, 64 * b:64 * b + 64], wo[b], Co, F=rows, Hi=1, Wi=1) for b in range(3)], 1)
+    want = ref.xattn_ln_sum(y3, g3, Co)
+    xtab = hip.xattn_tables(kvtab.cuda(), nulltab.cuda(), qs.cuda(), [w.cuda() for w in wo], Co)
+    got = hip.xattn_sigma_out(q.cuda(), HW, xtab, g3.cuda(), Co)
+    check(f"xattn_sigma_out/Co{Co}_F{Fn}_HW{HW}", got, want, 3e-5)
+    check(f"xattn_sigma_out/Co{Co}_vs_table_ref", got, ref.xattn_sigma_out(q, HW, ref.xattn_tables(kvtab, nulltab, qs, wo, Co), g3, Co), 3e-5)
+
+
 def test_xattn_layer_c64_rejects_straddling_tiles(hip):
     """H*W not a multiple of 32 (a pixel tile would straddle two frames' tables): the op refuses, the orchestration
     (`can_fuse_xattn`) takes the unfused chain instead."""
