@@ -217,10 +217,10 @@ def main():
                    "parallelism": {"single": "1 GPU", "tshard": f"T-shard x{n_gpus}: one {Ttotal}-frame clip, RCCL neighbour halo exchange + GroupNorm/quantile all-reduces",
                                    "replica": f"{n_gpus} independent clips"}[mode]},
     }
-    # ---- roofline of the dominant kernel family (dawn_conv_gemm: every conv and every projection).  The 3x3 ResBlock
-    # convs run on the bf16 matrix pipe with exactly split fp32 operands (6 bf16 MFMA flops per algorithmic flop);
-    # everything else on the fp32 MFMA.  The class with the larger share of the timed region is "the dominant
-    # kernel" (`roofline`), the other one is reported beside it (`roofline_other`).
+    # ---- roofline per kernel class of dawn_conv_gemm (every conv and every projection).  The 3x3 ResBlock convs and most
+    # 1x1 projections run on the bf16 matrix pipe with exactly split fp32 operands (6 bf16 MFMA flops per algorithmic
+    # flop), the rest on the fp32 MFMA.  The class with the largest share of the timed region is "the dominant kernel"
+    # (`roofline`); the others are listed beside it (`roofline_other`).
     if prof:
         torch.cuda.synchronize()
         tp = os.path.join(ROOT, "profiles", "r1_pmc_traffic.json")
@@ -231,42 +231,51 @@ def main():
                   if sampled else f"HIP events around every conv_gemm launch of every {max(1, args.event_every)}th DDIM step of the "
                   "timed region (all 50 steps are timed; the events are sampled to keep their marker packets out of the way)")
 
-        def roof(entries, split):
+        KINDS = {
+            "conv3x3": ("hbm_bytes_per_launch_conv3x3_bf16",
+                        "conv3x3_bf16_v2_kernel (3x3 ResBlock convs: fp32 operands split exactly into 3 bf16 pieces, 6 cross "
+                        "terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate)"),
+            "gemm1x1": ("hbm_bytes_per_launch_gemm1x1_bf16",
+                        "gemm1x1_bf16_kernel (1x1 projections: to_qkv / to_out / to_q / res_conv, same split-operand scheme)"),
+            "fp32": ("hbm_bytes_per_launch_fp32",
+                     "conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA implicit GEMM: thin N=64 1x1, 4x4/s2, transposed 4x4)"),
+        }
+
+        def roof(entries, kind):
             t_ms = sum(p[1].elapsed_time(p[2]) for p in entries)
             flops = sum(p[0] for p in entries)
             alg = flops / (t_ms * 1e-3) / 1e12
             # PMC counters cannot be read live: measured on this exact workload by tools/pmc_bench.sh
-            traffic = None
-            if pmc is not None:
-                traffic = pmc.get("hbm_bytes_per_launch_split_bf16" if split else "hbm_bytes_per_launch_fp32",
-                                  pmc.get("hbm_bytes_per_launch"))
+            traffic = pmc.get(KINDS[kind][0], pmc.get("hbm_bytes_per_launch")) if pmc is not None else None
             r = {"bound": "mfma", "unit": "TFLOP/s", "traffic": traffic,
                  "algorithmic_bytes_per_launch_avg": sum(p[4] for p in entries) / len(entries),
                  "launches": len(entries), "avg_launch_us": t_ms * 1e3 / len(entries), "timing": timing,
                  "algorithmic_flops_per_launch_avg": flops / len(entries), "algorithmic_tflops": alg,
-                 "share_of_conv_time": None}
-            if split:
-                r.update({"kernel": "conv3x3_bf16_v2_kernel + gemm1x1_bf16_kernel (3x3 ResBlock convs and the large 1x1 "
-                                    "projections: fp32 operands split exactly into 3 bf16 pieces, 6 cross terms on "
-                                    "v_mfma_f32_32x32x16_bf16, fp32 accumulate)",
-                          "achieved": 6.0 * alg, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": 6.0 * alg / PEAK_BF16_MFMA_TFLOPS,
+                 "share_of_conv_time": None, "kernel": KINDS[kind][1]}
+            if kind != "fp32":
+                r.update({"achieved": 6.0 * alg, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": 6.0 * alg / PEAK_BF16_MFMA_TFLOPS,
                           "executed_flops_per_algorithmic_flop": 6,
                           "note": "achieved = executed bf16 MFMA rate; algorithmic_tflops = 2*M*N*K / time"})
             else:
-                r.update({"kernel": "conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA implicit GEMM: small 1x1, 4x4/s2, "
-                                    "transposed 4x4, 7x7)",
-                          "achieved": alg, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": alg / PEAK_FP32_MFMA_TFLOPS})
+                r.update({"achieved": alg, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": alg / PEAK_FP32_MFMA_TFLOPS})
             return r, t_ms
 
-        groups = {True: [p for p in prof if "split-bf16" in p[3]], False: [p for p in prof if "split-bf16" not in p[3]]}
+        def kind_of(label):
+            if "split-bf16" not in label:
+                return "fp32"
+            return "conv3x3" if " k=3x3 " in label else "gemm1x1"
+
+        groups = {}
+        for pr in prof:
+            groups.setdefault(kind_of(pr[3]), []).append(pr)
         roofs = {k: roof(v, k) for k, v in groups.items() if v}
         t_all = sum(t for _, t in roofs.values())
         for r, t in roofs.values():
             r["share_of_conv_time"] = t / t_all
         order = sorted(roofs, key=lambda k: -roofs[k][1])
-        result["roofline"] = roofs[order[0]][0]
+        result["roofline"] = roofs[order[0]][0]                     # the dominant kernel
         if len(order) > 1:
-            result["roofline_other"] = roofs[order[1]][0]
+            result["roofline_other"] = [roofs[k][0] for k in order[1:]]
     alg = algorithmic_flops_per_forward(Ttotal if mode == "tshard" else T, h) * S * args.steps * \
         (n_gpus if mode == "replica" else 1)
     result["whole_path"] = {"algorithmic_tflop": alg / 1e12, "achieved_tflops": alg / dt / 1e12,

@@ -22,8 +22,12 @@ with open(dst, "w") as f:
     for k, r in e2e.items():
         f.write(f"| {k} | {r['max_abs_err']:.3e} | {r['max_abs_ref']:.3g} |\n")
     if extra:
-        f.write("\n## Split-operand (bf16-pipe) convolution vs an fp64 reference, relative max error\n\n")
-        for r in extra[-1:]:
+        f.write("\n## Accuracy against fp64 references (split-operand convolution: relative max error; flow decode: max abs error of the HIP path and of the fp32 CPU oracle)\n")
+        last = {}
+        for r in extra:
+            last[r["op"]] = r                      # latest record per check
+        for r in last.values():
+            f.write(f"\n`{r['op']}`\n\n")
             f.write("| " + " | ".join(k for k in r if k != "op") + " |\n|" + "---|" * (len(r) - 1) + "\n")
             f.write("| " + " | ".join(f"{v:.3e}" for k, v in r.items() if k != "op") + " |\n")
     f.write("\n## Per kernel / op case\n\n| op / case | max abs err | scale (max|ref|) | tolerance |\n|---|---|---|---|\n")
