@@ -1,0 +1,63 @@
+"""bench.py contract (CPU-checkable parts): the algorithmic-work model of SURVEY.md §8d D3, the decode FLOP model, and
+the shape of the JSON line (checked on the committed evidence file produced by `python bench.py` on the GPU box)."""
+import json
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import bench                      # noqa: E402
+import bench_decode               # noqa: E402
+
+
+def test_algorithmic_flops_match_survey_d3():
+    # C3 = (24.9 G * 200 + 15.4 M * (200*81 - 1640)) * 50 = 260.2 TFLOP; C2 = 130.9 TFLOP
+    assert bench.algorithmic_flops_per_forward(200, 64) * 50 == pytest.approx(260.2e12, rel=5e-3)
+    assert bench.algorithmic_flops_per_forward(400, 32) * 50 == pytest.approx(130.9e12, rel=5e-3)
+    # short clips attend to every frame: b * T^2
+    assert bench.algorithmic_flops_per_forward(16, 32) == pytest.approx(6.25e9 * 16 + 3.85e6 * 256, rel=1e-2)
+
+
+def test_decode_flop_model_counts_the_per_frame_convolutions():
+    res, be = 256, 64
+    hb, cb = res // 4, 4 * be
+    f = 12 * 2 * hb * hb * 9 * cb * cb                     # 6 ResBlock2d x 2 convs, 256 -> 256 at 64^2
+    f += 2 * (2 * hb) ** 2 * 9 * cb * (cb // 2)            # up block 0: 256 -> 128 at 128^2
+    f += 2 * res * res * 9 * (cb // 2) * be                # up block 1: 128 -> 64 at 256^2
+    f += 2 * res * res * 49 * be * 3                       # final 7x7, 64 -> 3
+    assert bench_decode.decode_flops_per_frame(res) == pytest.approx(f, rel=1e-12)
+    assert bench_decode.decode_flops_per_frame(res) * 200 == pytest.approx(15.7e12, rel=1e-2)
+
+
+def test_committed_bench_line_has_the_contract_fields():
+    d = json.load(open(os.path.join(ROOT, "profiles", "r1_final_bench_default.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["unit"] == "frames/s" and d["dtype"] == "f32" and "synthetic" in d["data"]
+    assert "workload" in d["config"] and "model" not in d["config"]
+    frames = d["config"]["frames_per_gpu"]
+    assert d["value"] == pytest.approx(frames / (d["ms_per_step"] * 1e-3), rel=1e-6)      # whole-job frames / timed seconds
+    r = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel"):
+        assert k in r, k
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert r["frac"] == pytest.approx(r["achieved"] / r["peak"], rel=1e-9) and 0 < r["frac"] < 1
+    assert r["traffic"] is None or r["traffic"] > 0
+    c = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in c, k
+    assert c["kind"] in ("port", "reference") and c["unit"] == d["unit"] and c["cores"] >= 1
+    # the flow-decode report is beside the metric, never inside it
+    assert "flow_decode" in d and d["flow_decode"]["sampler_plus_decode_frames_per_s"] < d["value"]
+
+
+def test_bench_defaults_are_the_headline_config():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for frag in ('"--gpus", type=int, default=1', '"--frames", type=int, default=200', '"--res", type=int, default=256',
+                 '"--ddim-steps", type=int, default=50'):
+        assert frag in src, frag
