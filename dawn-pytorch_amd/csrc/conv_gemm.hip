@@ -1751,7 +1751,13 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         const bool nine = (g_variant & 0x2000) != 0;
         bool ok = false;
         if (g_variant & 0x4000) {           // v2 structure (row-of-taps weight stages, register-prefetched patch)
-            ok = d.N <= 64 ? try_launch_bf16_v2<1>(d, M, s, nine) : try_launch_bf16_v2<2>(d, M, s, nine);
+            // 256 x 128 tiles run one 8-wave workgroup per CU: when they occupy at most half of the 256 CUs (M = 12,800 rows,
+            // N = 256: 100 tiles), 256 x 64 tiles put one 4-wave workgroup on twice as many CUs and the launch takes
+            // 0.67x the time (measured 520 -> 349 us at K = 9216, 142 -> 97 us at K = 2304; with 129..256 tiles the same
+            // CUs stay busy either way and nothing is gained)
+            const bool narrow = d.N <= 64 || (d.N % 64 == 0 && M % 256 == 0 && (M / 256) * ((d.N + 127) / 128) <= 128);
+            ok = narrow ? try_launch_bf16_v2<1>(d, M, s, nine) : try_launch_bf16_v2<2>(d, M, s, nine);
+            if (!ok && narrow && d.N > 64) ok = try_launch_bf16_v2<2>(d, M, s, nine);
         }
         if (!ok) ok = d.N <= 64 ? try_launch_halo_bf16<64, 1>(d, M, s, nine) : try_launch_halo_bf16<128, 2>(d, M, s, nine);
         if (ok) {
