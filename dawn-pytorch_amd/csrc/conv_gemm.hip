@@ -1479,6 +1479,22 @@ __global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     f32x4 araw[2][NQ];
     uint2 ap[NQ][3];
+    // optional LayerNorm prologue (PreNorm / LayerNorm_img with the gain folded into the weights): A = (x - mean[row]) *
+    // rstd[row], applied to the row quads right before the operand split -- the same arithmetic as dawn_ln_rows, so the
+    // result is bit-identical to the GEMM on materialised normalised rows, without writing and re-reading them
+    const bool norm = d.row_mean != nullptr;
+    float rmu[NQ], rrs[NQ];
+#pragma unroll
+    for (int i = 0; i < NQ; ++i) {
+        const long row = m0 + row0 + (NTHR >> 3) * i;
+        rmu[i] = norm ? d.row_mean[row] : 0.f;
+        rrs[i] = norm ? d.row_rstd[row] : 1.f;
+    }
+    auto splitq = [&](int slot, int qi) {
+        f32x4 v = slot ? araw[1][qi] : araw[0][qi];
+        if (norm) v = (v - rmu[qi]) * rrs[qi];
+        split3(v, ap[qi][0], ap[qi][1], ap[qi][2]);
+    };
     auto loadA = [&](int s, int slot) {
         const bool src1 = s >= nS0;                            // wave-uniform
         const int ldb = (src1 ? ld1 : d.ld0) * 4;
@@ -1522,7 +1538,7 @@ __global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_
     loadA(0, 0);
     if (nS > 1) loadA(1, 1);
 #pragma unroll
-    for (int i = 0; i < NQ; ++i) split3(araw[0][i], ap[i][0], ap[i][1], ap[i][2]);
+    for (int i = 0; i < NQ; ++i) splitq(0, i);
     writeA(0);
     for (int s = 0; s < nS; ++s) {
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1561,8 +1577,8 @@ __global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_
 #pragma unroll
                 for (int i = 0; i < NQ / 2; ++i) {
                     const int qi = sub * (NQ / 2) + i;
-                    if ((s + 1) & 1) split3(araw[1][qi], ap[qi][0], ap[qi][1], ap[qi][2]);
-                    else split3(araw[0][qi], ap[qi][0], ap[qi][1], ap[qi][2]);
+                    if ((s + 1) & 1) splitq(1, qi);
+                    else splitq(0, qi);
                 }
             }
         }
@@ -1742,7 +1758,7 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     if (M <= 0 || d.N <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
     if ((g_variant & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ch_a &&
-        !d.pro_act && !d.pro_add && !d.row_mean && try_launch_gemm1x1_bf16(d, M, s)) {
+        !d.pro_act && !d.pro_add && (d.row_mean == nullptr) == (d.row_rstd == nullptr) && try_launch_gemm1x1_bf16(d, M, s)) {
         DAWN_LAUNCH_CHECK();
         return 0;
     }

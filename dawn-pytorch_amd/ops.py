@@ -160,6 +160,12 @@ class HipOps:
         t2 = (rows // 256) * (N // 128)
         return N % 128 != 0 or t2 >= 256 or t2 < 128 or rows >= 51200
 
+    @classmethod
+    def split_gemm_ok(cls, rows: int, N: int, C0: int, C1: int = 0) -> bool:
+        """Will a 1x1 projection of this shape run on the split-operand GEMM (which can apply the LayerNorm row
+        statistics in its loader)?  Otherwise the caller materialises the normalised rows for the direct-to-LDS fp32 GEMM."""
+        return cls._runs_split_kernel(True, 1, 1, 1, 0, rows, N, C0, C1, None, None)
+
     # ------------------------------------------------------------------ GroupNorm / LayerNorm
     def conv_gn_part(self, rows_out: int, N: int, like: Tensor) -> Tensor:
         """Buffer for the GroupNorm partial sums a conv_gemm launch of this output shape emits (gn_part=...)."""

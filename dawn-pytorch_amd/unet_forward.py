@@ -87,6 +87,16 @@ def time_film(ops, P: PackedUNet, t: float, like: Tensor) -> Tensor:
     return ops.linear(e, P.film_w, P.film_b, act_in=1).reshape(-1)
 
 
+def _ln_gemm(ops, x: Tensor, x2: Optional[Tensor], w: Tensor, N: int, w_bf3: Optional[Tensor], **g) -> Tensor:
+    """LayerNorm over the channels of [x | x2] (gain folded into w) followed by a projection.  On the split-operand GEMM
+    the normalisation rides in the loader (per-row mean / rstd from a read-only statistics pass): the normalised rows are
+    never written.  Otherwise they are materialised once so that the fp32 GEMM stays prologue-free (direct-to-LDS)."""
+    C1 = 0 if x2 is None else x2.shape[1]
+    if w_bf3 is not None and ops.split_gemm_ok(x.shape[0], N, x.shape[1], C1):
+        return ops.conv_gemm(x, w, N, in1=x2, row_stats=ops.ln_rowstats(x, x2), w_bf3=w_bf3, **g)
+    return ops.conv_gemm(ops.ln_rows(x, x2), w, N, w_bf3=w_bf3, **g)
+
+
 def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, H: int, W: int, film_all: Tensor,
               cs: ClipState) -> Tensor:
     Co = rb.Co
@@ -99,7 +109,7 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
             return ops.xattn_layer_c64(x, x2, H * W, rb.wq, rb.wo, rb.g3, rb.q_scale, cs.kvtab[rb.cond_index],
                                        cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index])
         # LayerNorm_img is materialised (one streaming pass) so that to_q runs as a prologue-free GEMM
-        q = ops.conv_gemm(ops.ln_rows(x, x2), rb.wq, 192, w_bf3=rb.wqs, **g)
+        q = _ln_gemm(ops, x, x2, rb.wq, 192, rb.wqs, **g)
         if ops.can_fuse_xattn_out(Co, H * W) and cs.xtab[rb.cond_index] is not None:
             return ops.xattn_sigma_out(q, H * W, cs.xtab[rb.cond_index], rb.g3, Co)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)
@@ -145,7 +155,7 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
     if ops.can_fuse_temporal(a.C, Fext, F, cs.win):
         return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
                                       wqkv_bf3=a.wqkv_s)
-    qkv = ops.conv_gemm(ops.ln_rows(xe), a.wqkv, 768, F=Fext, Hi=H, Wi=W, w_bf3=a.wqkv_s)
+    qkv = _ln_gemm(ops, xe, None, a.wqkv, 768, a.wqkv_s, F=Fext, Hi=H, Wi=W)
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
@@ -153,13 +163,13 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
 def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
     if a.C == 64:
         return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout, wqkv_bf3=a.wqkv_s)
-    qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W, w_bf3=a.wqkv_s)
+    qkv = _ln_gemm(ops, x, None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W)
     o = ops.sla(qkv, F, H * W)
     return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 
 def _mid_spatial(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
-    qkv = ops.conv_gemm(ops.ln_rows(x), a.wqkv, 768, F=F, Hi=H, Wi=W, w_bf3=a.wqkv_s)
+    qkv = _ln_gemm(ops, x, None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W)
     o = ops.frame_attn(qkv, F, H * W)
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 

@@ -168,6 +168,10 @@ class RefOps:
         return Co == 64 and Cin in (64, 128) and C0 % 8 == 0
 
     @staticmethod
+    def split_gemm_ok(rows, N, C0, C1=0):
+        return True          # exercise the row-statistics form of the LayerNorm + projection on CPU
+
+    @staticmethod
     def can_fuse_xattn_out(Co, HW):
         return Co % 32 == 0 and 32 <= Co <= 512 and HW % 4 == 0
 

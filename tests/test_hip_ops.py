@@ -203,7 +203,9 @@ def test_gemm1x1_split(hip, ref, M, K, N, res, bias):
 
 @pytest.mark.parametrize("M,C0,C1,N,extra", [(51200, 64, 64, 64, "tr"), (12800, 512, 512, 256, "tr"), (25600, 128, 0, 192, ""),
                                              (12800, 512, 0, 768, "res"), (51200, 64, 0, 128, "strided"),
-                                             (12800, 64, 0, 512, "strided"), (204800, 32, 96, 64, "bias")])
+                                             (12800, 64, 0, 512, "strided"), (204800, 32, 96, 64, "bias"),
+                                             (51200, 128, 0, 768, "rowstats"), (25600, 128, 128, 192, "rowstats"),
+                                             (12800, 512, 0, 768, "rowstats")])
 def test_gemm1x1_split_variants(hip, ref, M, C0, C1, N, extra):
     """The same kernel family beyond the plain case: 64-column tiles (N = 64 / 192), two channel-concatenated sources
     (res_conv / to_q of cat[x, skip]), the res_conv epilogue out += SiLU(c2*a+b), M down to 12800 rows, and strided
@@ -221,7 +223,13 @@ def test_gemm1x1_split_variants(hip, ref, M, C0, C1, N, extra):
         kw["res"] = rnd(M, N, seed=3)
     if "bias" in extra:
         kw["bias"] = rnd(N, seed=4)
+    if "rowstats" in extra:            # LayerNorm prologue: (x - mean[row]) * rstd[row] applied in the loader
+        x0 = x0 * 1.7 + 0.4
+        kw["row_stats"] = ref.ln_rowstats(x0, x1)
     want = ref.conv_gemm(x0, w, N, in1=x1, **kw)
+    if "rowstats" in extra:            # == the GEMM on materialised normalised rows, bit for bit on the GPU path
+        xn = hip.ln_rows(x0.cuda(), None if x1 is None else x1.cuda())
+        via_rows = hip.conv_gemm(xn, w.cuda(), N, w_bf3=pack_bf3(unpack_kn(w)).cuda(), F=M // 64, Hi=8, Wi=8)
     gkw = {k_: (tuple(t.cuda() for t in v) if isinstance(v, tuple) else v.cuda() if torch.is_tensor(v) else v) for k_, v in kw.items()}
     x0g = x0.cuda()
     out = None
@@ -234,6 +242,11 @@ def test_gemm1x1_split_variants(hip, ref, M, C0, C1, N, extra):
     got = hip.conv_gemm(x0g, w.cuda(), N, in1=None if x1 is None else x1.cuda(), w_bf3=pack_bf3(unpack_kn(w)).cuda(), out=out, **gkw)
     torch.cuda.synchronize()
     check(f"gemm1x1_split_variants/M{M}_C{C0}+{C1}_N{N}_{extra}", got, want)
+    if "rowstats" in extra:            # with the statistics of the HIP LayerNorm kernel itself (the product's pairing)
+        st = hip.ln_rowstats(x0.cuda(), None if x1 is None else x1.cuda())
+        got_hs = hip.conv_gemm(x0.cuda(), w.cuda(), N, in1=None if x1 is None else x1.cuda(), row_stats=st,
+                               w_bf3=pack_bf3(unpack_kn(w)).cuda(), F=M // 64, Hi=8, Wi=8)
+        assert torch.equal(got_hs, via_rows)
     if out is not None:
         assert float(big[:, :N].min()) == 7.0 and float(big[:, 2 * N:].max()) == 7.0       # neighbours untouched
     # and it is the split kernel's accuracy class: no worse than the fp32 MFMA path against fp64
