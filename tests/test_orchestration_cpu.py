@@ -43,6 +43,37 @@ def test_unet_orchestration_matches_golden(tiny):
     torch.testing.assert_close(y, T(g["y"])[0], atol=3e-5, rtol=1e-5)
 
 
+class _NoFusionOps(RefOps):
+    """The op set with every optional fused / table-based route switched off: the orchestration then takes the op-by-op
+    chains (materialised LayerNorm rows, xattn_core + three to_out GEMMs + xattn_ln_sum)."""
+
+    @staticmethod
+    def split_gemm_ok(rows, N, C0, C1=0):
+        return False
+
+    @staticmethod
+    def can_fuse_xattn_out(Co, HW):
+        return False
+
+    @staticmethod
+    def can_fuse_xattn(Cin, Co, C0, HW=32):
+        return False
+
+
+def test_unet_orchestration_fused_and_unfused_routes_agree(tiny):
+    """Both routes of every branch in unet_forward reproduce the reference golden: the shipped one (LayerNorm statistics
+    applied in the GEMM loader, cross-attention through the per-clip sigma/affine tables) and the op-by-op one."""
+    g, sd = tiny
+    P = pack_unet(sd, win=3, device="cpu")
+    x = T(g["x"])[0]
+    outs = []
+    for ops in (RefOps(), _NoFusionOps()):
+        cs = build_clip_state(ops, P, x[3:, 0].contiguous(), T(g["cond"])[0])
+        outs.append(unet_forward(ops, P, cs, x[:3].contiguous(), int(g["time"][0])))
+        torch.testing.assert_close(outs[-1], T(g["y"])[0], atol=3e-5, rtol=1e-5)
+    torch.testing.assert_close(outs[0], outs[1], atol=2e-5, rtol=1e-5)
+
+
 def test_module_api_with_ref_ops(tiny):
     g, sd = tiny
     unet = D.DynamicNfUnet3D(default_num_frames=12, **TINY_KW)
