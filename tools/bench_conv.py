@@ -27,12 +27,11 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default=",".join(CASES))
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--variants", default="7")
-ap.add_argument("--stagger", default="0")
 a = ap.parse_args()
 ops = HipOps()
 dev = "cuda"
 import itertools
-for variant, name, stg in itertools.product([int(v) for v in a.variants.split(",")], a.cases.split(","), [int(v, 0) for v in a.stagger.split(",")]):
+for variant, name in itertools.product([int(v) for v in a.variants.split(",")], a.cases.split(",")):
     ops.L.dawn_conv_set_variant(variant)
     F, H, W, C0, C1, N, k, st, pad, rs = CASES[name]
     rows = F * H * W
@@ -65,5 +64,5 @@ for variant, name, stg in itertools.product([int(v) for v in a.variants.split(",
     diff = float((out - refs[ref_key]).abs().max()) if ref_key in refs else 0.0
     refs.setdefault(ref_key, out.clone())
     print(f"maxdiff_vs_first_variant={diff:.2e} ", end="")
-    print(f"v{variant} stg={stg:#x} {name:12s} M={rows} N={N} K={K}: {us:9.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  "
+    print(f"v{variant} {name:12s} M={rows} N={N} K={K}: {us:9.1f} us  {fl / us / 1e6:7.1f} TFLOP/s  "
           f"({(rows * (C0 + C1) + rows * N) * 4 / us / 1e6:6.2f} TB/s min-traffic)")
