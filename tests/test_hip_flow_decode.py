@@ -149,36 +149,16 @@ def test_decoder_matches_reference_golden(hip):
     check("flow_decoder/golden_out", o["sample_out_vid"], T(g["sample_out_vid"]), 2e-5)
 
 
-def random_lfg_state_dict(seed=0, be=64, max_features=512, n_down=2, n_bott=6):
-    """Shipped LFG generator topology (config/hdtf256.yaml generator_params) with seeded random weights and
-    BatchNorm statistics; key names as in the reference checkpoint's `generator` entry."""
-    g = torch.Generator().manual_seed(seed)
-    sd = {}
-
-    def conv(p, co, ci, k):
-        sd[p + ".weight"] = torch.randn(co, ci, k, k, generator=g) * (ci * k * k) ** -0.5
-        sd[p + ".bias"] = torch.randn(co, generator=g) * 0.1
-
-    def bn(p, c):
-        sd[p + ".weight"] = 1 + 0.2 * torch.randn(c, generator=g)
-        sd[p + ".bias"] = 0.2 * torch.randn(c, generator=g)
-        sd[p + ".running_mean"] = 0.2 * torch.randn(c, generator=g)
-        sd[p + ".running_var"] = torch.rand(c, generator=g) + 0.5
-
-    conv("first.conv", be, 3, 7); bn("first.norm", be)
-    for i in range(n_down):
-        ci, co = min(max_features, be * 2 ** i), min(max_features, be * 2 ** (i + 1))
-        conv(f"down_blocks.{i}.conv", co, ci, 3); bn(f"down_blocks.{i}.norm", co)
-    for i in range(n_down):
-        ci, co = min(max_features, be * 2 ** (n_down - i)), min(max_features, be * 2 ** (n_down - i - 1))
-        conv(f"up_blocks.{i}.conv", co, ci, 3); bn(f"up_blocks.{i}.norm", co)
-    cb = min(max_features, be * 2 ** n_down)
-    for i in range(n_bott):
-        for j in (1, 2):
-            conv(f"bottleneck.r{i}.conv{j}", cb, cb, 3); bn(f"bottleneck.r{i}.norm{j}", cb)
-    sd["final.weight"] = torch.randn(3, be, 7, 7, generator=g) * (be * 49) ** -0.5
-    sd["final.bias"] = torch.randn(3, generator=g) * 0.1
-    return sd
+def random_lfg_state_dict(seed=0):
+    """Shipped LFG generator topology (config/hdtf256.yaml generator_params: 64/128/256 channels, 2 down/up blocks,
+    6 bottleneck blocks) with seeded random weights and BatchNorm statistics; key names as in the reference checkpoint's
+    `generator` entry.  Shared with the decode benchmark."""
+    import os
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_decode
+    return bench_decode.lfg_state_dict(seed)
 
 
 @pytest.mark.parametrize("H,Tn,chunk", [(128, 3, 2), (256, 2, 2)])
