@@ -37,6 +37,7 @@ class ConvDesc(C.Structure):
         ("gn_part", c_f),
         ("w_bf3", c_f),
         ("gn_rows", C.POINTER(C.c_int)),
+        ("policy", _i),
     ]
 
 

@@ -29,8 +29,17 @@ namespace {
 // MFMA version of that kernel when the caller supplies w_bf3 (6 cross terms; 0x2000: all 9), 0x4000 its second
 // generation (conv3x3_bf16_v2_kernel: +5..20 %, profiles/r1_n_conv_bf16.txt), 0x10/0x20 fp32-kernel perf ablations,
 // (8 << 16) the s_memtime build of the split kernel.
-static int g_variant = 0x580D;
-static thread_local int g_last_nwg = 0;   // gridDim.x of the last launch (= rows of gn_part it writes)
+// The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
+// perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
+// split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
+constexpr int DAWN_CONV_POLICY_DEFAULT = 0x580D;
+#ifdef DAWN_ABLATION
+constexpr int DAWN_CONV_POLICY_MASK = 0x000FFFFF;
+#else
+constexpr int DAWN_CONV_POLICY_MASK = 0x0000FFCF;
+#endif
+static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
+static thread_local int g_last_nwg = 0;   // gridDim.x of the calling thread's last launch (= rows of gn_part it writes)
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
 
 struct RowInfo {
@@ -786,7 +795,7 @@ bool try_launch_halo(const dawn_conv_desc& d, long M, hipStream_t s) {
     const size_t lds = ((size_t)2 * P16 * 16 + (size_t)2 * 4 * BN * 4) * sizeof(float);
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * dawn_cdiv(d.N, BN);
-    const int remap = ((g_variant & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
+    const int remap = ((policy_of(d) & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
@@ -1401,11 +1410,11 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     const int P = nf * (TR + 2) * (WT + 2);
     const int P16 = (P + 15) / 16 * 16;
     if (P16 > 448) return false;
-    const bool timing = ((g_variant >> 16) & 15) == 8;
+    const bool timing = ((policy_of(d) >> 16) & 15) == 8;
     const size_t lds = (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 18 * BN * 16 + (timing ? 512 : 0);
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * (d.N / BN);
-    const int remap = ((g_variant & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
+    const int remap = ((policy_of(d) & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
 #define LAUNCH_V2(NTV, ABLV)                                                                                          \
     do {                                                                                                              \
         (void)hipFuncSetAttribute((const void*)conv3x3_bf16_v2_kernel<WN, NTV, ABLV>,                                 \
@@ -1413,14 +1422,15 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
         hipLaunchKernelGGL((conv3x3_bf16_v2_kernel<WN, NTV, ABLV>), dim3(nwg), dim3(256 * WN), lds, s, d, remap, TR, nf, \
                            P16, WT);                                                                                  \
     } while (0)
-    const int abl = (g_variant >> 16) & 15;
     g_last_nwg = nwg;
     if (nine) LAUNCH_V2(9, 0);
+#ifdef DAWN_ABLATION
     else if (timing) LAUNCH_V2(6, 8);
-    else if (abl == 1) LAUNCH_V2(6, 1);
-    else if (abl == 2) LAUNCH_V2(6, 2);
-    else if (abl == 4) LAUNCH_V2(6, 4);
-    else if (abl == 7) LAUNCH_V2(6, 7);
+    else if (((policy_of(d) >> 16) & 15) == 1) LAUNCH_V2(6, 1);
+    else if (((policy_of(d) >> 16) & 15) == 2) LAUNCH_V2(6, 2);
+    else if (((policy_of(d) >> 16) & 15) == 4) LAUNCH_V2(6, 4);
+    else if (((policy_of(d) >> 16) & 15) == 7) LAUNCH_V2(6, 7);
+#endif
     else LAUNCH_V2(6, 0);
 #undef LAUNCH_V2
     return true;
@@ -1620,7 +1630,7 @@ void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * 6 * (256 * 16 + 128) + (size_t)2 * 2 * 6 * BN * 16;
     const int nwg = (int)(M / 256) * (d.N / BN);
     g_last_nwg = nwg;
-    if (g_variant & 0x2000) {
+    if (policy_of(d) & 0x2000) {
         (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<9, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((gemm1x1_bf16_kernel<9, WN>), dim3(nwg), dim3(256 * WN), lds, s, d, M);
     } else {
@@ -1666,7 +1676,7 @@ bool try_launch_halo_bf16(const dawn_conv_desc& d, long M, hipStream_t s, bool n
     const size_t lds = (size_t)P16 * 64 + (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 3 * BN * 32;
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * dawn_cdiv(d.N, BN);
-    const int remap = ((g_variant & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
+    const int remap = ((policy_of(d) & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
     g_last_nwg = nwg;
     if (nine) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_bf16_kernel<BN, WN, 9>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1685,30 +1695,32 @@ void launch_pro(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
     const int z = d.mode == 1 ? 4 : 1;
     const int nwg = nMt * nNt;
-    const int remap = ((g_variant & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
+    const int remap = ((policy_of(d) & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
     g_last_nwg = nwg;
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, PRO>), dim3(nwg, 1, z), dim3(256), 0, s, d, remap);
 }
 
 template <int BM, int BN, int BK, int WM, int WN>
 void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
-    if (g_variant & 0x30) {   // perf ablations only (wrong results): 0x10 no re-staging, 0x20 also no barrier
+#ifdef DAWN_ABLATION
+    if (policy_of(d) & 0x30) {   // perf ablations only (wrong results): 0x10 no re-staging, 0x20 also no barrier
         const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
         const int nwg = nMt * nNt;
         g_last_nwg = nwg;
-        if (g_variant & 0x20)
+        if (policy_of(d) & 0x20)
             hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, 0, 2>), dim3(nwg, 1, 1), dim3(256), 0, s, d, 0);
         else
             hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, 0, 1>), dim3(nwg, 1, 1), dim3(256), 0, s, d, 0);
         return;
     }
-    if ((g_variant & 8) && BM == 128 && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
+#endif
+    if ((policy_of(d) & 8) && BM == 128 && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
         const int nwg = nMt * nNt;
-        const int remap = ((g_variant & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
+        const int remap = ((policy_of(d) & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
         const dim3 grid(nwg, 1, d.mode == 1 ? 4 : 1);
         const bool deep = d.KH * d.KW * (d.C0 + d.C1) >= 2304 && d.N >= 256;
-        if (BN == 64 && M >= 65536 && ((g_variant & 0x200) || (d.KH * d.KW > 1 && d.C0 + d.C1 <= 64 && !(g_variant & 0x400)))) {
+        if (BN == 64 && M >= 65536 && ((policy_of(d) & 0x200) || (d.KH * d.KW > 1 && d.C0 + d.C1 <= 64 && !(policy_of(d) & 0x400)))) {
             // 256 x 64 tile (weights amortised over 2x the rows): +7 % on the K=576 3x3 convs, not on 1x1 / K>=1152
             const int nwg2 = dawn_cdiv(M, 256);
             g_last_nwg = nwg2;
@@ -1717,9 +1729,9 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
             return;
         }
         g_last_nwg = nwg;
-        if (((g_variant & 0x80) || deep) && d.C0 % 32 == 0 && d.C1 % 32 == 0)
+        if (((policy_of(d) & 0x80) || deep) && d.C0 % 32 == 0 && d.C1 % 32 == 0)
             hipLaunchKernelGGL((conv_gemm_glds_kernel<BN, 2, 32>), grid, dim3(256), 0, s, d, remap);
-        else if (g_variant & 0x100)
+        else if (policy_of(d) & 0x100)
             hipLaunchKernelGGL((conv_gemm_glds_kernel<BN, 3, 16>), grid, dim3(256), 0, s, d, remap);
         else
             hipLaunchKernelGGL((conv_gemm_glds_kernel<BN, 2, 16>), grid, dim3(256), 0, s, d, remap);
@@ -1732,10 +1744,11 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 
 }  // namespace
 
-extern "C" void dawn_conv_set_variant(int v) { g_variant = v; }
+#ifdef DAWN_ABLATION
 extern "C" int dawn_conv_set_debug(void* p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &p, sizeof(p));
 }
+#endif
 
 extern "C" int dawn_conv_gemm_nblocks(long M, int N) {
     if (N <= 64) return dawn_cdiv(M, 128);   // upper bound (the 256-row tile variants launch fewer blocks; the
@@ -1757,16 +1770,16 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     const long M = (d.mode == 0) ? (long)d.F * d.Ho * d.Wo : (long)d.F * d.Hi * d.Wi;
     if (M <= 0 || d.N <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if ((g_variant & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ch_a &&
+    if ((policy_of(d) & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ch_a &&
         !d.pro_act && !d.pro_add && (d.row_mean == nullptr) == (d.row_rstd == nullptr) && try_launch_gemm1x1_bf16(d, M, s)) {
         DAWN_LAUNCH_CHECK();
         return 0;
     }
-    if ((g_variant & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 &&
+    if ((policy_of(d) & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 &&
         d.Ho == d.Hi && d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
-        const bool nine = (g_variant & 0x2000) != 0;
+        const bool nine = (policy_of(d) & 0x2000) != 0;
         bool ok = false;
-        if (g_variant & 0x4000) {           // v2 structure (row-of-taps weight stages, register-prefetched patch)
+        if (policy_of(d) & 0x4000) {           // v2 structure (row-of-taps weight stages, register-prefetched patch)
             // 256 x 128 tiles run one 8-wave workgroup per CU: when they occupy at most half of the 256 CUs (M = 12,800 rows,
             // N = 256: 100 tiles), 256 x 64 tiles put one 4-wave workgroup on twice as many CUs and the launch takes
             // 0.67x the time (measured 520 -> 349 us at K = 9216, 142 -> 97 us at K = 2304; with 129..256 tiles the same
@@ -1782,7 +1795,7 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
             return 0;
         }
     }
-    if ((g_variant & 0x800) && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.Hi &&
+    if ((policy_of(d) & 0x800) && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.Hi &&
         d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool ok = d.N <= 64 ? try_launch_halo<64, 1>(d, M, s) : try_launch_halo<128, 2>(d, M, s);
         if (ok) {
@@ -1791,9 +1804,9 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
             return 0;
         }
     }
-    const bool k32 = (g_variant & 1) && (d.C0 % 32 == 0) && (d.C1 % 32 == 0) && (d.KH * d.KW * Cin >= 4096);
+    const bool k32 = (policy_of(d) & 1) && (d.C0 % 32 == 0) && (d.C1 % 32 == 0) && (d.KH * d.KW * Cin >= 4096);
     if (d.N <= 64) {
-        if ((g_variant & 2) && M >= 256 * 256) launch<256, 64, 16, 4, 1>(d, M, s);
+        if ((policy_of(d) & 2) && M >= 256 * 256) launch<256, 64, 16, 4, 1>(d, M, s);
         else launch<128, 64, 16, 2, 2>(d, M, s);
     } else {
         if (k32) launch<128, 128, 32, 2, 2>(d, M, s);

@@ -42,6 +42,7 @@ class HipOps:
         self.overlap = True          # two-stream overlap of independent branches (fork_join)
         self._side_stream = None
         self.graph_error = None      # set when a HIP-graph capture failed and the sampler fell back to eager
+        self.conv_policy = 0         # dawn_conv_desc.policy of every conv_gemm launch (0 = shipped kernel policy)
 
     def with_comm(self, comm):
         o = HipOps(comm)
@@ -49,6 +50,7 @@ class HipOps:
         o.prof_on = self.prof_on
         o.prof_every = getattr(self, "prof_every", 1)
         o.overlap = self.overlap
+        o.conv_policy = self.conv_policy
         return o
 
     # ------------------------------------------------------------------ helpers
@@ -122,6 +124,7 @@ class HipOps:
         d.out, d.ld_out = _p(out), _ld(out)
         d.gn_part = _p(gn_part)
         d.w_bf3 = _p(w_bf3)
+        d.policy = self.conv_policy
         nrows = C.c_int(0)
         if gn_part is not None:
             d.gn_rows = C.pointer(nrows)
@@ -387,13 +390,26 @@ class HipOps:
         check(self.L.dawn_ddim_x0(_p(x), _p(eps), recip, recipm1, n, _p(x0), _p(hist), self._stream()), "dawn_ddim_x0")
         return x0, hist
 
+    @staticmethod
+    def quantile_rank(n_total: int, q: float) -> Tuple[int, float]:
+        """(lower order statistic, interpolation weight) of the q-quantile of n_total values (MT:1186-1190).
+        Up to 2^24 elements this is `torch.quantile`'s own arithmetic: the rank q*(n-1) is formed in the input dtype,
+        fp32.  Above 2^24 torch refuses (no reference behaviour exists: the reference cannot sample such clips) and fp32
+        cannot even represent n-1, so the rank is exact: floor / fraction of q*(n-1) in fp64 (the exact
+        linearly interpolated order statistic)."""
+        import numpy as np
+        if n_total <= (1 << 24):
+            pos = np.float32(q) * np.float32(n_total - 1)
+            lo = int(np.floor(pos))
+            return lo, float(np.float32(pos) - np.float32(lo))
+        pos = np.float64(q) * np.float64(n_total - 1)
+        lo = int(np.floor(pos))
+        return lo, float(pos - np.float64(lo))
+
     def quantile_threshold(self, x0: Tensor, hist1: Tensor, n_total: int, q: float = 0.9) -> Tensor:
         """s = max(1, torch.quantile(|x0|, q)) over the WHOLE clip (histograms all-reduced when T-sharded).
         Returns a 2-float device tensor [s, raw quantile]."""
-        import numpy as np
-        pos = np.float32(q) * np.float32(n_total - 1)          # torch.quantile ranks in the input dtype
-        lo = int(np.floor(pos))
-        weight = float(np.float32(pos) - np.float32(lo))
+        lo, weight = self.quantile_rank(n_total, q)
         s = self._stream()
         n = x0.numel()
         state = torch.zeros(4, device=x0.device, dtype=torch.int32)

@@ -84,6 +84,9 @@ def ddim_sample_clip(ops, P: PackedUNet, cs: ClipState, x_init: Tensor, steps: S
         except Exception as e:                                   # noqa: BLE001  (capture is an optimisation only)
             ops.graph_error = f"{type(e).__name__}: {str(e)[:200]}"
             graphed = None
+            import warnings
+            warnings.warn(f"HIP-graph capture of the denoiser evaluation failed ({ops.graph_error}); running eagerly",
+                          RuntimeWarning, stacklevel=2)
     prof_every = getattr(ops, "prof_every", 1)
     for i, st in enumerate(steps):
         ops.prof_on = (i % prof_every == 0)     # per-kernel HIP events (bench.py roofline) on every n-th step only
@@ -101,5 +104,6 @@ def ddim_sample_clip(ops, P: PackedUNet, cs: ClipState, x_init: Tensor, steps: S
         noise = noise_fn(i) if st["t_next"] > 0 else None
         x = ops.ddim_update(x0, eps, s, noise, st["sqrt_alpha_next"], st["c"], st["sigma"])
         if trace is not None:
-            trace.append(dict(eps=eps, s=s, x=x))
+            # a graphed evaluation returns its static output buffer: clone, or every entry would alias the last step
+            trace.append(dict(eps=eps.clone() if graphed is not None else eps, s=s, x=x))
     return x

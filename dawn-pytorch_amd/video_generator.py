@@ -23,7 +23,16 @@ from .flow_diffusion import FlowDiffusion
 
 
 class VideoGenerator:
-    def __init__(self, args, *, generator=None, frontend=None, config: Optional[dict] = None, device=None):
+    def __init__(self, args, *, generator=None, frontend=None, config: Optional[dict] = None, device=None,
+                 allow_random_weights: bool = False, deterministic: bool = True):
+        """`allow_random_weights`: explicit opt-in (benches, tests) to run with the deterministic random-init denoiser
+        when the configured checkpoint is absent; without it a missing checkpoint raises, as the reference's
+        `torch.load` does (UVG:527).  `deterministic`: seed the sampler's counter-based noise with the config's
+        `random_seed` (the reference never seeds torch); False draws from torch's global generator.
+        NOTE (reference quirk, kept): `FlowDiffusion.face_loc_emb` is never saved / loaded by the reference (it is a
+        sibling of `.diffusion`, FD:169), so it stays at its constructor initialisation here too."""
+        self.allow_random_weights = bool(allow_random_weights) or bool(getattr(args, "allow_random_weights", False))
+        self.deterministic = deterministic
         self.audio_path = args.audio_path
         self.image_path = args.image_path
         self.output_path = args.output_path
@@ -56,9 +65,14 @@ class VideoGenerator:
         ckpt_path = model_config.get('diffusion_pretrained_pth')
         if ckpt_path and osp.exists(ckpt_path):
             checkpoint = torch.load(ckpt_path, map_location=self.device)
-            model.diffusion.load_state_dict(checkpoint['diffusion'])          # UVG:527-528, 912 keys
+            model.diffusion.load_state_dict(checkpoint['diffusion'])          # UVG:527-528, 912 keys, strict
+        elif not self.allow_random_weights:
+            raise FileNotFoundError(
+                f"diffusion checkpoint {ckpt_path!r} (model_config.diffusion_pretrained_pth) not found; sampling with "
+                "random-init weights would silently write a garbage video.  Pass allow_random_weights=True "
+                "(--allow_random_weights) to do that on purpose (benches / plumbing tests).")
         seed = self.video_config.get('random_seed')
-        if seed is not None and getattr(self, "deterministic", True):
+        if seed is not None and self.deterministic:
             model.diffusion.noise_seed = int(seed)   # the reference never seeds torch; we can
         model.eval()
         return model
@@ -158,6 +172,8 @@ def parse_args(argv=None):
     p.add_argument('--config', type=str, default=None, help='DAWN_{res}.yaml (defaults to ./config/DAWN_<res>.yaml)')
     p.add_argument('--sampling_step', type=int, default=None, help='override DDIM steps (YAML ships 20)')
     p.add_argument('--max_n_frames', type=int, default=None, help='override the clip-length cap (YAML ships 200)')
+    p.add_argument('--allow_random_weights', action='store_true',
+                   help='run with the deterministic random-init denoiser when the checkpoint is absent (plumbing only)')
     return p.parse_args(argv)
 
 

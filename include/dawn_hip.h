@@ -56,19 +56,17 @@ typedef struct dawn_conv_desc {
                                                       the split-operand bf16-MFMA kernel; NULL = fp32 MFMA */
     int* gn_rows;                                  /* optional HOST pointer: receives the number of gn_part rows this launch
                                                       writes (= its thread-block count; <= dawn_conv_gemm_nblocks) */
+    int policy;                                    /* kernel-selection policy bits (see below); 0 = shipped default */
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;
  * the launch reports the exact count through dawn_conv_desc.gn_rows */
 int dawn_conv_gemm_nblocks(long M, int N);
-/* tuning knob for A/B measurements and tests (default 0x580D = shipped policy): bit0 BK=32 tiles, bit1 256x64 tile for
- * N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel, 0x1000 split-operand
- * (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000 second-generation split
- * 3x3 kernel; 0x10/0x20 fp32-kernel perf ablations; (8 << 16) selects the s_memtime-instrumented build of the split
- * 3x3 kernel (tools/conv_phase_timing.py). */
-void dawn_conv_set_variant(int v);
-/* instrumented build only: device buffer (4096 x 64 uint64) receiving the per-phase s_memtime stamps */
-int dawn_conv_set_debug(void* device_buffer);
+/* dawn_conv_desc.policy bits (0 = shipped policy 0x580D; per call, no process-global state): bit0 BK=32 tiles,
+ * bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel,
+ * 0x1000 split-operand (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000
+ * second-generation split 3x3 kernel.  Every combination computes the same function (tests run the kernel families
+ * against each other); perf-ablation / s_memtime builds exist only under -DDAWN_ABLATION (tools/build_timing_lib.sh). */
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --
  * partial: per-block fp64 (sum, sumsq) per group -> part[nblk][16]; reduce: fixed-order sum ->

@@ -318,9 +318,14 @@ class RefOps:
         v = x0.abs().flatten()
         if self.comm is not None:
             v = self.comm.all_gather_cat(v)
-        pos = np.float32(q) * np.float32(n_total - 1)
-        lo = int(np.floor(pos))
-        wgt = float(np.float32(pos) - np.float32(lo))
+        if n_total <= (1 << 24):                       # torch.quantile's own rank arithmetic (input dtype = fp32)
+            pos = np.float32(q) * np.float32(n_total - 1)
+            lo = int(np.floor(pos))
+            wgt = float(np.float32(pos) - np.float32(lo))
+        else:                                          # torch refuses above 2^24: exact rank in fp64
+            pos = np.float64(q) * np.float64(n_total - 1)
+            lo = int(pos // 1)
+            wgt = float(pos - lo)
         sv = torch.sort(v).values
         a, b = sv[lo], sv[min(lo + 1, sv.numel() - 1)]
         qv = torch.lerp(a, b, torch.tensor(wgt, dtype=torch.float32, device=v.device))

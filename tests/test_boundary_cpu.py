@@ -66,9 +66,11 @@ def test_pre_post_match_reference_golden(fd):
     assert out["sample_out_vid"].shape == (2, 3, 5, 64, 64)
 
 
-def test_video_generator_plumbing(tmp_path):
+@pytest.mark.parametrize("Tn,res,steps", [(4, 64, 2), (16, 128, 10)], ids=["small", "BASELINE-configs0"])
+def test_video_generator_plumbing(tmp_path, Tn, res, steps):
+    """CLI contract end to end on CPU (RefOps injected = the torch op set; the product ops have no CPU path).  The second
+    case is BASELINE configs[0] exactly: 128x128, 16 frames, 10 DDIM steps, random-init full DAWN_128 UNet."""
     from PIL import Image
-    Tn, res = 4, 64
     cache, outd = tmp_path / "cache", tmp_path / "out"
     cache.mkdir()
     rng = np.random.default_rng(0)
@@ -78,11 +80,14 @@ def test_video_generator_plumbing(tmp_path):
     img = tmp_path / "face.png"
     Image.fromarray((rng.random((80, 80, 3)) * 255).astype(np.uint8)).save(img)
     cfg = {"input_size": res, "max_n_frames": Tn, "random_seed": 1234, "mean": [0.0, 0.0, 0.0], "win_width": 40,
-           "sampling_step": 2, "ddim_sampling_eta": 1.0, "cond_scale": 1.0,
+           "sampling_step": steps, "ddim_sampling_eta": 1.0, "cond_scale": 1.0,
            "model_config": {"is_train": True, "pose_dim": 6}}
     args = argparse.Namespace(audio_path="", image_path=str(img), output_path=str(outd), cache_path=str(cache),
                               resolution=res)
-    vg = VideoGenerator(args, generator=FakeLFG(), config=cfg, device="cpu")
+    with pytest.raises(FileNotFoundError):           # a missing checkpoint is an error unless explicitly allowed
+        VideoGenerator(args, generator=FakeLFG(), config=cfg, device="cpu")
+    vg = VideoGenerator(args, generator=FakeLFG(), config=cfg, device="cpu", allow_random_weights=True)
+    assert sum(p.numel() for p in set(vg.video_model.unet.parameters())) == 49857555
     vg.video_model.unet.ops = RefOps()
     frames = vg.run()
     assert frames.shape == (Tn, res, res, 3) and frames.dtype == np.uint8

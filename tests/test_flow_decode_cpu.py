@@ -107,3 +107,14 @@ def test_frames_to_u8_restates_process_output_frame():
         frame = (frame * 255).astype(np.uint8)
         assert np.array_equal(got[t], frame[..., ::-1])                      # cv2.COLOR_RGB2BGR
     assert got.dtype == np.uint8 and got.shape == (4, 6, 8, 3)
+
+
+def test_frames_to_u8_reference_golden():
+    """N2 pinned: the op reference against bytes produced by the reference's own `_process_output_frame`
+    (tools/gen_goldens_egress.py -> tests/golden/frames_u8.npz; UVG:533-548), bit-exact."""
+    from conftest import load_golden
+    g = load_golden("frames_u8.npz")
+    x = T(g["x"])                                            # (B,3,H,W): the reference treats dim 0 as the batch index
+    for mi in range(3):
+        got = RefOps().frames_to_u8(x.permute(1, 0, 2, 3), mean=tuple(g[f"mean{mi}"]), bgr=True).numpy()
+        assert np.array_equal(got, g[f"bgr{mi}"]), mi

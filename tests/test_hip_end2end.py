@@ -36,7 +36,7 @@ def tiny_unet(sd):
 
 def test_loaded_native_library():
     from dawn_pytorch_amd import _lib
-    assert _lib.lib().dawn_abi_version() == 1
+    assert _lib.lib().dawn_abi_version() == 2
 
 
 def test_tiny_unet_golden(tiny):
@@ -178,10 +178,10 @@ def test_benchmark_size_kernel_families_agree(Tn, res):
     x = torch.randn(3, Tn, h, h, generator=torch.Generator().manual_seed(9)).to(dev)
     try:
         y_split = unet_forward(ops, P, cs, x, 500)
-        ops.L.dawn_conv_set_variant(0x80D)
+        ops.conv_policy = 0x80D
         y_fp32 = unet_forward(ops, P, cs, x, 500)
     finally:
-        ops.L.dawn_conv_set_variant(0x580D)
+        ops.conv_policy = 0x580D
     torch.cuda.synchronize()
     assert torch.isfinite(y_split).all() and torch.isfinite(y_fp32).all()
     scale = float(y_fp32.abs().max())

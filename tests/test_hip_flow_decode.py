@@ -206,3 +206,17 @@ def test_frames_to_u8_bit_exact(hip, ref, bgr):
     assert torch.equal(got, want), int((got != want).sum())
     got0 = hip.frames_to_u8(clip.cuda(), bgr=bgr).cpu()
     assert torch.equal(got0, ref.frames_to_u8(clip, bgr=bgr))
+
+
+def test_frames_to_u8_reference_golden(hip):
+    """N2 pinned on the GPU: dawn_frames_to_u8 against bytes produced by the reference's own `_process_output_frame`
+    (UVG:533-548; tools/gen_goldens_egress.py), bit-exact, BGR (cv2 order) and RGB."""
+    from conftest import load_golden
+    g = load_golden("frames_u8.npz")
+    x = torch.from_numpy(g["x"]).permute(1, 0, 2, 3).contiguous().cuda()          # (3,T,H,W), T = the golden's batch index
+    for mi in range(3):
+        mean = tuple(float(v) for v in g[f"mean{mi}"])
+        want = torch.from_numpy(g[f"bgr{mi}"])
+        got = hip.frames_to_u8(x, mean=mean, bgr=True).cpu()
+        assert torch.equal(got, want), (mi, int((got != want).sum()))
+        assert torch.equal(hip.frames_to_u8(x, mean=mean, bgr=False).cpu(), want.flip(-1))

@@ -111,15 +111,15 @@ def test_conv_gemm(hip, ref, case):
         kw["tr"] = (rnd(F * Ho * Wo, N, seed=9), rnd(N, seed=10) * 0.3 + 1.0, rnd(N, seed=11) * 0.3)
     want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
     for variant in (0, 7, 141, 269, 525, 1037, 13, 2061):   # every fp32-MFMA tile configuration
-        hip.L.dawn_conv_set_variant(variant)
+        hip.conv_policy = variant
         _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
     if k == 3 and C0 % 16 == 0 and C1 % 16 == 0:
         from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
         kw["w_bf3"] = pack_bf3(unpack_kn(w)).cuda()
         for variant in (14349, 30733, 6157, 22541):           # split-operand bf16 MFMA: 9 / 6 terms, v1 / v2 kernels
-            hip.L.dawn_conv_set_variant(variant)
+            hip.conv_policy = variant
             _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
-    hip.L.dawn_conv_set_variant(22541)                        # shipped policy (left active)
+    hip.conv_policy = 22541                        # shipped policy (left active)
 
 
 def _conv_case(hip, name, in0, in1, w, N, kw, want):
@@ -140,7 +140,7 @@ def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
     from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
     ws = pack_bf3(unpack_kn(w)).cuda() if C0 % 16 == 0 else None
     for variant in (5, 525, 13, 2061, 6157, 22541):
-        hip.L.dawn_conv_set_variant(variant)
+        hip.conv_policy = variant
         xg = x.cuda()
         part = hip.conv_gn_part(rows, N, xg)
         c = hip.conv_gemm(xg, w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=b.cuda(), gn_part=part, w_bf3=ws)
@@ -167,14 +167,14 @@ def test_conv_bf16_split_is_fp32_accurate(hip, ref):
     errs = {}
     for variant, ws in ((2061, None), (6157, pack_bf3(unpack_kn(w)).cuda()), (14349, pack_bf3(unpack_kn(w)).cuda()),
                         (22541, pack_bf3(unpack_kn(w)).cuda())):
-        hip.L.dawn_conv_set_variant(variant)
+        hip.conv_policy = variant
         got = hip.conv_gemm(x.cuda(), w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, w_bf3=ws)
         torch.cuda.synchronize()
         errs[variant] = float((got.cpu().double() - want).abs().max() / want.abs().max())
     with open(LOG, "a") as f:
         f.write(json.dumps({"op": "conv_bf16_split/rel_err_vs_fp64", "fp32_mfma": errs[2061], "bf16x6": errs[6157],
                             "bf16x9": errs[14349], "bf16x6_v2": errs[22541]}) + "\n")
-    hip.L.dawn_conv_set_variant(22541)
+    hip.conv_policy = 22541
     assert errs[6157] <= 2.0 * errs[2061] + 1e-7, errs
     assert errs[22541] <= 2.0 * errs[2061] + 1e-7, errs
     assert errs[14349] <= 2.0 * errs[2061] + 1e-7, errs
@@ -194,11 +194,11 @@ def test_gemm1x1_split(hip, ref, M, K, N, res, bias):
     want = ref.conv_gemm(x, w, N, **kw)
     gkw = {k_: (v.cuda() if torch.is_tensor(v) else v) for k_, v in kw.items()}
     for variant in (22541, 30733):
-        hip.L.dawn_conv_set_variant(variant)
+        hip.conv_policy = variant
         got = hip.conv_gemm(x.cuda(), w.cuda(), N, w_bf3=pack_bf3(unpack_kn(w)).cuda(), **gkw)
         torch.cuda.synchronize()
         check(f"gemm1x1_split/M{M}_K{K}_N{N}/v{variant}", got, want)
-    hip.L.dawn_conv_set_variant(22541)
+    hip.conv_policy = 22541
 
 
 @pytest.mark.parametrize("M,C0,C1,N,extra", [(51200, 64, 64, 64, "tr"), (12800, 512, 512, 256, "tr"), (25600, 128, 0, 192, ""),
@@ -250,9 +250,9 @@ def test_gemm1x1_split_variants(hip, ref, M, C0, C1, N, extra):
     if out is not None:
         assert float(big[:, :N].min()) == 7.0 and float(big[:, 2 * N:].max()) == 7.0       # neighbours untouched
     # and it is the split kernel's accuracy class: no worse than the fp32 MFMA path against fp64
-    hip.L.dawn_conv_set_variant(2061)
+    hip.conv_policy = 2061
     got32 = hip.conv_gemm(x0.cuda(), w.cuda(), N, in1=None if x1 is None else x1.cuda(), **gkw)
-    hip.L.dawn_conv_set_variant(22541)
+    hip.conv_policy = 22541
     e_split, e_f32 = float((got.cpu() - want).abs().max()), float((got32.cpu() - want).abs().max())
     assert e_split <= 2.0 * e_f32 + 1e-5 * max(1.0, float(want.abs().max())), (e_split, e_f32)
 
@@ -403,7 +403,11 @@ def test_xattn_layer_c64_rejects_straddling_tiles(hip):
 
 # ---------------------------------------------------------------------------------------------- attention cores
 @pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(12, 5, 0, 12, 3), (100, 3, 0, 100, 40), (70, 2, 20, 33, 40),
-                                                 (45, 4, 3, 40, 7), (33, 2, 0, 33, 40)])
+                                                 (45, 4, 3, 40, 7), (33, 2, 0, 33, 40),
+                                                 # the shapes the benchmark / long clips / T-shards run (several 128-query
+                                                 # blocks, a full +-40 window on both sides, q0 != 0, >= 64 pixel columns)
+                                                 (200, 64, 0, 200, 40), (280, 64, 40, 200, 40), (400, 64, 0, 400, 40),
+                                                 (240, 70, 40, 200, 40), (327, 64, 40, 247, 40)])
 def test_temporal_attn(hip, ref, Fext, HW, q0, Fq, win):
     qkv = rnd(Fext * HW, 768, seed=1)
     ang = torch.arange(Fext).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
@@ -516,6 +520,26 @@ def test_quantile_matches_torch(hip, n, scale):
     s = hip.quantile_threshold(x0, hist, n, 0.9).cpu()
     assert float(s[1]) == pytest.approx(float(want), rel=0, abs=1e-6 * max(1, float(want))), (float(s[1]), float(want))
     assert float(s[0]) == max(1.0, float(s[1]))
+
+
+@pytest.mark.parametrize("n", [19660800, (1 << 24) + 2])
+def test_quantile_exact_rank_above_2p24(hip, n):
+    """n = 3*1600*64*64 (BASELINE configs[3], the T-sharded 1600-frame clip) is above torch.quantile's 2^24 cap: there the
+    rank q*(n-1) must be exact (fp32 cannot represent n-1), checked against a sort-based fp64 evaluation."""
+    g = torch.Generator(device="cuda").manual_seed(n % 1000)
+    v = torch.randn(n, device="cuda", generator=g) * 1.7
+    sv = torch.sort(v.abs()).values
+    pos = 0.9 * (n - 1)                                  # python float = fp64
+    lo = int(pos // 1)
+    a, b = float(sv[lo]), float(sv[min(lo + 1, n - 1)])
+    want = a + (b - a) * (pos - lo)
+    assert hip.quantile_rank(n, 0.9)[0] == lo
+    import numpy as np
+    assert int(np.floor(np.float32(0.9) * np.float32(n - 1))) != lo, "fp32 rank would have been right: weak test size"
+    _, hist = hip.ddim_x0(v, torch.zeros_like(v), 1.0, 0.0)
+    s = hip.quantile_threshold(v, hist, n, 0.9).cpu()
+    assert abs(float(s[1]) - want) <= 2e-7 * max(1.0, want), (float(s[1]), want)
+    assert a <= float(s[1]) <= b
 
 
 def test_quantile_golden(hip):

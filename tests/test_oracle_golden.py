@@ -114,3 +114,21 @@ def test_fd_prepost():
     assert torch.equal(c, T(d["cond_none"]))
     assert torch.equal(T(d["pred"])[:, :2], T(d["grid_given"]))
     assert torch.equal((T(d["pred"])[:, 2:3] + 1) * 0.5, T(d["conf_given"]))
+
+
+def test_full_architecture_T96_vs_reference():
+    """The oracle at the full shipped architecture with a cutting window (T=96 > 2w+1, h=32) against the reference's own
+    output (tools/gen_goldens_fullsize.py); C2 / C3 are checked by tools/check_oracle_fullsize.py in the build container
+    (minutes of CPU; results in profiles/r2_parity_errors.md)."""
+    import dawn_pytorch_amd as D
+    from fullsize_cases import CASES, KW, build_inputs, checksum
+    g = load_golden("full_T96.npz")
+    Tn, h, tval = CASES["T96"]
+    unet = D.DynamicNfUnet3D(default_num_frames=Tn, **KW, init_seed=0)
+    sd = {"denoise_fn." + k: v for k, v in unet.state_dict().items()}
+    np.testing.assert_allclose(checksum(unet.state_dict().values()), g["weights_checksum"], rtol=1e-12)
+    fea272, cond, x3 = build_inputs(Tn, h)
+    np.testing.assert_allclose(checksum([fea272, cond, x3]), g["inputs_checksum"], rtol=1e-12)
+    xin = torch.cat((x3, fea272.unsqueeze(2).expand(-1, -1, Tn, -1, -1)), 1)
+    y = O.unet_forward(sd, xin, torch.tensor([tval]), cond, win=40)
+    close(y[0][:, T(g["frames"]).long()], g["y"], 2e-5)

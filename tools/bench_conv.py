@@ -32,7 +32,7 @@ ops = HipOps()
 dev = "cuda"
 import itertools
 for variant, name in itertools.product([int(v) for v in a.variants.split(",")], a.cases.split(",")):
-    ops.L.dawn_conv_set_variant(variant)
+    ops.conv_policy = variant
     F, H, W, C0, C1, N, k, st, pad, rs = CASES[name]
     rows = F * H * W
     torch.manual_seed(0)

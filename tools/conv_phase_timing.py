@@ -31,7 +31,7 @@ ops.L.dawn_conv_set_debug.argtypes = [ctypes.c_void_p]
 assert ops.L.dawn_conv_set_debug(dbg.data_ptr()) == 0
 part = ops.conv_gn_part(rows, N, x0)
 for it in range(3):
-    ops.L.dawn_conv_set_variant(a.variant)
+    ops.conv_policy = a.variant
     dbg.zero_()
     out = ops.conv_gemm(x0, w, N, in1=x1, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, w_bf3=ws, gn_part=part)
     torch.cuda.synchronize()

@@ -1,0 +1,1 @@
+"""Import stub (absent offline); nothing on the pinned path calls into it."""
