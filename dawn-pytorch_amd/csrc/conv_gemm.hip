@@ -1639,26 +1639,30 @@ void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
     }
 }
 
+// Which split-operand 1x1 GEMM tile (0 = none: fp32 kernel, 1 = 256 x 64, 2 = 256 x 128) serves an (M x N) projection of
+// C0 (+ C1) channels.  Tile policy from the per-shape table of the benchmark (profiles/r1_final_gemm1x1_policy.txt):
+// 256 x 128 tiles when they fill the chip; 256 x 64 tiles for N = 192 and for the small GEMMs that would leave more than
+// half of the CUs idle with 128-wide tiles; the thin N = 64 GEMMs and the short (M < 51200) 128..255-tile cases stay on
+// the fp32 kernel (many small workgroups hide HBM latency better than one 126 KB-LDS workgroup per CU).
+int gemm1x1_split_plan(long M, int N, int C0, int C1) {
+    if (C0 % 32 != 0 || C1 % 32 != 0 || N % 64 != 0 || M % 256 != 0 || M < 12800) return 0;
+    if (N % 128 == 0) {
+        const long t2 = (M / 256) * (N / 128);
+        if (t2 >= 256 || (t2 >= 128 && M >= 51200)) return 2;
+        return t2 < 128 ? 1 : 0;
+    }
+    return N == 64 ? 0 : 1;
+}
+
 bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
-    if (d.C0 % 32 != 0 || d.C1 % 32 != 0 || (d.C1 != 0) != (d.in1 != nullptr) || d.N % 64 != 0 || M % 256 != 0 ||
-        M < 12800 || d.gn_part)
-        return false;
+    if ((d.C1 != 0) != (d.in1 != nullptr) || d.gn_part) return false;
     if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) || (d.tr && (d.ld_tr & 3)) ||
         (long)d.ld0 * 256 * 4 >= (1L << 31) || (long)d.ld1 * 256 * 4 >= (1L << 31))
         return false;
-    // Tile policy from the per-shape table of the benchmark (profiles/r1_final_gemm1x1_policy.txt): 256 x 128 tiles when
-    // they fill the chip; 256 x 64 tiles for N = 192 and for the small GEMMs that would leave more than half of the CUs
-    // idle with 128-wide tiles; the thin N = 64 GEMMs and the short (M < 51200) 128..255-tile cases stay on the fp32
-    // kernel (many small workgroups hide HBM latency better than one 126 KB-LDS workgroup per CU).
-    if (d.N % 128 == 0) {
-        const long t2 = (M / 256) * (d.N / 128);
-        if (t2 >= 256 || (t2 >= 128 && M >= 51200)) launch_gemm1x1_bf16<2>(d, M, s);
-        else if (t2 < 128) launch_gemm1x1_bf16<1>(d, M, s);
-        else return false;
-    } else {
-        if (d.N == 64) return false;
-        launch_gemm1x1_bf16<1>(d, M, s);
-    }
+    const int plan = gemm1x1_split_plan(M, d.N, d.C0, d.C1);
+    if (plan == 2) launch_gemm1x1_bf16<2>(d, M, s);
+    else if (plan == 1) launch_gemm1x1_bf16<1>(d, M, s);
+    else return false;
     return true;
 }
 
@@ -1749,6 +1753,11 @@ extern "C" int dawn_conv_set_debug(void* p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &p, sizeof(p));
 }
 #endif
+
+/* 1 when a prologue-free 1x1 projection (M rows, N columns, C0 + C1 input channels, w_bf3 supplied, shipped policy) runs on
+ * the split-operand GEMM, whose loader can apply LayerNorm row statistics; the host then skips materialising the
+ * normalised rows (see unet_forward._ln_gemm / dawn_ctx.hip). */
+extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1) { return gemm1x1_split_plan(M, N, C0, C1) != 0; }
 
 extern "C" int dawn_conv_gemm_nblocks(long M, int N) {
     if (N <= 64) return dawn_cdiv(M, 128);   // upper bound (the 256-row tile variants launch fewer blocks; the

@@ -486,33 +486,496 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
 #endif
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// WMODE 3: EVERY large contraction of the layer on the bf16 matrix pipe with exactly split operands (fp32 results):
+// besides the Q/K/V projections (WMODE 2) also S^T = K . Q^T and O^T = V^T . P^T.  The fp32 versions of those two cost
+// 2 x 4096 MFMA cycles per (32-query tile, head) on v_mfma_f32_32x32x2_f32; with K / Q / V / P each written as three
+// bf16 pieces and the 6 cross terms down to 2^-16 (conv_gemm.hip) they cost 2 x 1536.
+//   * K is split ONCE per head by the wave that projects it (after the rotary) into three bf16 planes in LDS
+//     ([plane][d-chunk 2][k-half 2][row] x 16 B: the A fragment of a key tile is one ds_read_b128 per plane and chunk);
+//   * V is projected NON-transposed (operands swapped: D = X . Wv, lane = feature d, registers = keys), so that a lane
+//     holds exactly the 8 keys {16g + 4*half + (i&3) + 8(i>>2)} of one A fragment of O^T = V^T . P^T and writes them as one
+//     16-byte piece per plane ([plane][16-key block][k-half][d] x 16 B);
+//   * the k index of a 16-wide MFMA is a free permutation: Q^T and P^T feed their B fragments STRAIGHT from the
+//     accumulator registers 8g..8g+7 of the previous MFMA (no shuffles), K and V are laid out to match;
+//   * the key tiles of a query tile start at j0 = i0 - win; for the 16-key V blocks to be tile-aligned the query tiles
+//     start `delta` = (q0 - win) mod 16 rows before q0 (dummy queries in front are computed and not stored).
+// LDS: X planes 384 B + K planes 192 B per frame row (rows = Fext, no padding: reads clamp) + V^T 192 B per key of
+// 32*nrt + the bias table: 163,328 B at Fext = 200 (the benchmark clip); longer buffers (T-shard interior shards) use
+// WMODE 2 / 1.
+__device__ __forceinline__ void split3_oct(const float (&v)[8], bf16x8t& p1, bf16x8t& p2, bf16x8t& p3) {
+    float r[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { p1[i] = (__bf16)v[i]; r[i] = v[i] - (float)p1[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { p2[i] = (__bf16)r[i]; r[i] = r[i] - (float)p2[i]; }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) p3[i] = (__bf16)r[i];
+}
+
+// K^T (transposed: lane = row, registers = features) and V (lane = feature, registers = rows) of one 32-row tile for one
+// head, sharing the X plane fragments; weights through the buffer descriptor as in proj_T_split.
+__device__ __forceinline__ void proj_KV_split(const __amdgpu_buffer_rsrc_t rw, unsigned wvoff, int colk, int colv,
+                                              const unsigned char* xp, int FA, f32x16& kT, f32x16& v) {
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int WS = 2 * 768 * 16;
+    kT = zero16();
+    v = zero16();
+    bf16x8t wk[2][3], wv[2][3];
+#pragma unroll
+    for (int pl = 0; pl < 3; ++pl) {
+        wk[0][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colk * 16 + pl * WS, 0));
+        wv[0][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colv * 16 + pl * WS, 0));
+    }
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        if (kc < 3) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl) {
+                wk[(kc + 1) & 1][pl] = __builtin_bit_cast(
+                    bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colk * 16 + ((kc + 1) * 3 + pl) * WS, 0));
+                wv[(kc + 1) & 1][pl] = __builtin_bit_cast(
+                    bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colv * 16 + ((kc + 1) * 3 + pl) * WS, 0));
+            }
+        }
+        bf16x8t xs[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            xs[pl] = *reinterpret_cast<const bf16x8t*>(xp + (size_t)((pl * 4 + kc) * 2) * FA * 16);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            kT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[kc & 1][PW[u]], xs[PX[u]], kT, 0, 0, 0);   // D^T = W^T . X^T
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[PX[u]], wv[kc & 1][PW[u]], v, 0, 0, 0);     // D   = X . W
+        }
+    }
+}
+
+template <int NKT, int SCHED, bool HL, bool OB>
+__global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
+    const float* __restrict__ x, int Fext, int HW, int q0, int Fq, int win, const unsigned short* __restrict__ wqkv_s,
+    const float* __restrict__ wout, const unsigned short* __restrict__ wout_sp, const float* __restrict__ rcos,
+    const float* __restrict__ rsin, const float* __restrict__ band, float eps, float* __restrict__ out, int nrt, int delta) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int FA = Fext;                                         // rows of the X / K planes (reads clamp to FA - 1)
+    const int NBV = 2 * nrt;                                     // 16-key blocks of V^T
+    unsigned char* Xp = reinterpret_cast<unsigned char*>(smem);  // [3][4][2][FA] x 16 B
+    unsigned char* Kp = Xp + (size_t)24 * FA * 16;               // [3][2][2][FA] x 16 B
+    unsigned char* Vt = Kp + (size_t)12 * FA * 16;               // [3][NBV][2][32] x 16 B
+    constexpr int BLD = 32 * NKT + 32;
+    float* band_s = reinterpret_cast<float*>(Vt + (size_t)3 * NBV * 64 * 16);   // [8][BLD]
+
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const long p = blockIdx.x;
+#ifdef DAWN_TL_TIMING
+    unsigned long long* tsb = reinterpret_cast<unsigned long long*>(smem + 40000);
+    int tix = 0;
+#endif
+    TSTAMP();
+
+    // ---- phase 0: bias table; LayerNorm rows, split once into three bf16 planes (16 lanes per row, float4 each)
+    for (int i = tid; i < HEADS * BLD; i += 512) {
+        const int hh = i / BLD, idx = i - hh * BLD - 32;
+        band_s[i] = (idx >= 0 && idx <= 2 * win) ? band[idx * HEADS + hh] : NEG;
+    }
+    {
+        // a thread owns float4 #sub of the rows (tid >> 4) + 32 i: ALL its row loads are issued before the first reduction
+        // (one exposed HBM round trip per block instead of one per row)
+        const int sub = tid & 15;
+        constexpr int MAXR = 7;                                   // 32 * 7 = 224 >= FA (FA <= ~206 by the LDS budget)
+        f32x4 xv[MAXR];
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int j = (tid >> 4) + 32 * i;
+            xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (j < FA) xv[i] = *reinterpret_cast<const f32x4*>(x + ((long)j * HW + p) * C + sub * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int j = (tid >> 4) + 32 * i;
+            const f32x4 v = xv[i];
+            float s = v.x + v.y + v.z + v.w;
+            s = wave_sum(s, 16);
+            const float mu = s * (1.0f / C);
+            const f32x4 dl = v - mu;
+            float ss = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w;
+            ss = wave_sum(ss, 16);
+            const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
+            const f32x4 o = dl * rs;
+            uint2 p1, p2, p3;
+            split3_quad_t(o, p1, p2, p3);
+            const int kc = sub >> 2, qd = sub & 3;
+            if (j < FA) {
+                unsigned char* dst = Xp + ((size_t)(kc * 2 + (qd >> 1)) * FA + j) * 16 + (qd & 1) * 8;
+                *reinterpret_cast<uint2*>(dst) = p1;
+                *reinterpret_cast<uint2*>(dst + (size_t)8 * FA * 16) = p2;
+                *reinterpret_cast<uint2*>(dst + (size_t)16 * FA * 16) = p3;
+            }
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wqkv_s, 0, 4 * 3 * 2 * 768 * 16, 0x00020000);
+    const unsigned wvoff = (unsigned)((half * 768 + l31) * 16);
+    const int nqt = (Fq + delta + 31) >> 5;
+    const bool has_q = wave < nqt;
+    const int i0 = q0 - delta + 32 * wave;                       // first (possibly dummy) query row of this wave's tile
+    const int iq = i0 + l31;
+    const int iqc = iq < 0 ? 0 : (iq < Fext ? iq : Fext - 1);
+    const int qend = q0 + Fq;
+    const float scale = 0.17677669529663687f;
+    constexpr float LOG2E = 1.4426950408889634f;
+    constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};      // smallest cross terms first
+    f32x16 outT[2];
+    outT[0] = zero16();
+    outT[1] = zero16();
+
+    TSTAMP();   // phase 0 done (+ setup)
+    for (int h = 0; h < HEADS; ++h) {
+        if (h < 2) TSTAMP();   // head start
+        // ---- K^T / V projection of every frame row; rotary on K; both split into bf16 planes in LDS
+        for (int rt = wave; rt < nrt; rt += 8) {
+            const int j = 32 * rt + l31;
+            const int jc = j < FA ? j : FA - 1;
+            float2 kcs[4], ksn[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                kcs[c] = *reinterpret_cast<const float2*>(rcos + jc * 16 + 4 * c + 2 * half);
+                ksn[c] = *reinterpret_cast<const float2*>(rsin + jc * 16 + 4 * c + 2 * half);
+            }
+            f32x16 kT, vv;
+            proj_KV_split(rsw, wvoff, HEADS * DH + h * DH, 2 * HEADS * DH + h * DH, Xp + ((size_t)half * FA + jc) * 16, FA, kT, vv);
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                float kr[8];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int c = 2 * kc + cc;
+                    const float2 cs = kcs[c], sn = ksn[c];
+                    kr[4 * cc] = kT[4 * c] * cs.x - kT[4 * c + 1] * sn.x;
+                    kr[4 * cc + 1] = kT[4 * c + 1] * cs.x + kT[4 * c] * sn.x;
+                    kr[4 * cc + 2] = kT[4 * c + 2] * cs.y - kT[4 * c + 3] * sn.y;
+                    kr[4 * cc + 3] = kT[4 * c + 3] * cs.y + kT[4 * c + 2] * sn.y;
+                }
+                bf16x8t k1, k2, k3;
+                split3_oct(kr, k1, k2, k3);
+                if (j < FA) {
+                    unsigned char* dst = Kp + ((size_t)(kc * 2 + half) * FA + j) * 16;
+                    *reinterpret_cast<bf16x8t*>(dst) = k1;
+                    *reinterpret_cast<bf16x8t*>(dst + (size_t)4 * FA * 16) = k2;
+                    *reinterpret_cast<bf16x8t*>(dst + (size_t)8 * FA * 16) = k3;
+                }
+            }
+            // V: lane = feature d = l31, registers 8g..8g+7 = keys 32 rt + 16 g + 4 half + (i & 3) + 8 (i >> 2)
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float vr[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int key = 32 * rt + 16 * g + 4 * half + (i & 3) + 8 * (i >> 2);
+                    vr[i] = key < Fext ? vv[8 * g + i] : 0.f;          // padded keys: finite zeros (their P is exactly 0)
+                }
+                bf16x8t v1, v2, v3;
+                split3_oct(vr, v1, v2, v3);
+                unsigned char* dst = Vt + ((size_t)((2 * rt + g) * 2 + half) * 32 + l31) * 16;
+                *reinterpret_cast<bf16x8t*>(dst) = v1;
+                *reinterpret_cast<bf16x8t*>(dst + (size_t)NBV * 64 * 16) = v2;
+                *reinterpret_cast<bf16x8t*>(dst + (size_t)2 * NBV * 64 * 16) = v3;
+            }
+        }
+        if (h < 2) TSTAMP();   // K/V projected (before barrier)
+        __syncthreads();
+        if (h < 2) TSTAMP();   // barrier passed
+
+        if (has_q) {
+            // ---- Q^T (registers = B fragments): scale + rotary (lane-local), split into three bf16 pieces per d-chunk
+            bf16x8t qp[3][2];
+            {
+                float2 qcs[4], qsn[4];                     // requested before the projection MFMAs (L1/L2 round trip hidden)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    qcs[c] = *reinterpret_cast<const float2*>(rcos + iqc * 16 + 4 * c + 2 * half);
+                    qsn[c] = *reinterpret_cast<const float2*>(rsin + iqc * 16 + 4 * c + 2 * half);
+                }
+                f32x16 qT, unused;
+                proj_T_split<false>(rsw, wvoff, h * DH, h * DH, Xp + ((size_t)half * FA + iqc) * 16, FA, qT, unused);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    float qr[8];
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const int c = 2 * kc + cc;
+                        const float2 cs = qcs[c];
+                        const float2 sn = qsn[c];
+                        const float a0 = qT[4 * c] * scale, a1 = qT[4 * c + 1] * scale;
+                        const float a2 = qT[4 * c + 2] * scale, a3 = qT[4 * c + 3] * scale;
+                        qr[4 * cc] = a0 * cs.x - a1 * sn.x;
+                        qr[4 * cc + 1] = a1 * cs.x + a0 * sn.x;
+                        qr[4 * cc + 2] = a2 * cs.y - a3 * sn.y;
+                        qr[4 * cc + 3] = a3 * cs.y + a2 * sn.y;
+                    }
+                    split3_oct(qr, qp[0][kc], qp[1][kc], qp[2][kc]);
+                }
+            }
+            if (h < 2) TSTAMP();   // Q projected + rotated
+            const int j0 = i0 - win;                                           // multiple of 16 (delta)
+            int j0m = j0;
+            asm volatile("" : "+v"(j0m));
+            const float* bb = band_s + h * BLD + 32 - l31 + 4 * half;
+            constexpr int HA = (NKT + 1) / 2;
+            f32x16 st[NKT];
+            auto s_tile = [&](int t) {                                         // S^T tile = K . Q^T, 12 bf16 MFMAs
+                st[t] = zero16();
+                int j = j0 + 32 * t + l31;
+                j = j < 0 ? 0 : (j >= FA ? FA - 1 : j);
+                const unsigned char* kr = Kp + ((size_t)half * FA + j) * 16;
+                bf16x8t kf[3][2];
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc)
+                        kf[pl][kc] = *reinterpret_cast<const bf16x8t*>(kr + (size_t)((pl * 2 + kc) * 2) * FA * 16);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+                        st[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[PA6[u]][kc], qp[PB6[u]][kc], st[t], 0, 0, 0);
+            };
+            const int lo = j0 < 0 ? -j0 : 0;
+            const int hi = Fext - j0 < 32 * NKT ? Fext - j0 : 32 * NKT;
+            int vbase = 4 * half - lo;
+            asm volatile("" : "+v"(vbase));
+            const unsigned span = (unsigned)(hi - lo);
+            // HL: 32 + 2 win <= 32 NKT - 16, i.e. the upper 16 keys of the last tile (registers 8..15) are outside the window
+            // of EVERY query of the tile: their bias / exp / split / P.V work is skipped (1/8 of the softmax + P.V at win 40)
+            auto nreg = [](int t) { return (HL && t == NKT - 1) ? 8 : 16; };
+            auto bias_max = [&](int t, float& m) {
+                float bz[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r < nreg(t)) bz[r] = bb[32 * t + (r & 3) + 8 * (r >> 2)];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r >= nreg(t)) continue;
+                    const int c = 32 * t + (r & 3) + 8 * (r >> 2);
+                    const bool ok = (unsigned)(vbase + c) < span;
+                    const float sv = ok ? st[t][r] + bz[r] : NEG;
+                    st[t][r] = sv;
+                    m = fmaxf(m, sv);
+                }
+            };
+            auto pv_tile = [&](int t, f32x16& o) {                             // o^T += V^T . P^T, 12 (6) bf16 MFMAs
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    if (8 * g >= nreg(t)) continue;
+                    int b = (j0m >> 4) + 2 * t + g;
+                    b = b < 0 ? 0 : (b >= NBV ? NBV - 1 : b);                  // clamped blocks hold masked keys only (P = 0)
+                    const unsigned char* vr = Vt + ((size_t)(b * 2 + half) * 32 + l31) * 16;
+                    bf16x8t vf[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl) vf[pl] = *reinterpret_cast<const bf16x8t*>(vr + (size_t)pl * NBV * 64 * 16);
+                    float pr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) pr[i] = st[t][8 * g + i];
+                    bf16x8t pp[3];
+                    split3_oct(pr, pp[0], pp[1], pp[2]);
+#pragma unroll
+                    for (int u = 0; u < 6; ++u) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA6[u]], pp[PB6[u]], o, 0, 0, 0);
+                }
+            };
+#pragma unroll
+            for (int t = 0; t < HA; ++t) s_tile(t);
+            if (h < 2) TSTAMP();   // S(A) issued
+            // ---- S of half B  ||  bias + max + exp of half A
+#pragma unroll
+            for (int t = HA; t < NKT; ++t) s_tile(t);
+            float mA = NEG;
+#pragma unroll
+            for (int t = 0; t < HA; ++t) bias_max(t, mA);
+            mA = fmaxf(mA, __shfl_xor(mA, 32, 64));
+            float lA = 0.f;
+#pragma unroll
+            for (int t = 0; t < HA; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r >= nreg(t)) continue;
+                    const float pv = __builtin_amdgcn_exp2f((st[t][r] - mA) * LOG2E);
+                    st[t][r] = pv;
+                    lA += pv;
+                }
+            if (SCHED) {
+#pragma unroll
+                for (int i = 0; i < 12 * (NKT - HA); ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);       // one MFMA of S(B) ...
+                    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);       // ... VALU of half A's softmax in its shadow
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            if (h < 2) TSTAMP();   // S(B) issued + softmax(A)
+            // ---- P.V of half A  ||  bias + max + exp of half B (relative to the joint max)
+            f32x16 oA = zero16();
+#pragma unroll
+            for (int t = 0; t < HA; ++t) pv_tile(t, oA);
+            float m = mA;
+#pragma unroll
+            for (int t = HA; t < NKT; ++t) bias_max(t, m);
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float alpha = __builtin_amdgcn_exp2f((mA - m) * LOG2E);
+            float l = lA * alpha;
+#pragma unroll
+            for (int t = HA; t < NKT; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    if (r >= nreg(t)) continue;
+                    const float pv = __builtin_amdgcn_exp2f((st[t][r] - m) * LOG2E);
+                    st[t][r] = pv;
+                    l += pv;
+                }
+            if (SCHED) {
+#pragma unroll
+                for (int i = 0; i < 12 * HA; ++i) {
+                    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x002, 8, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                }
+            }
+            l += __shfl_xor(l, 32, 64);
+            if (h < 2) TSTAMP();   // PV(A) issued + softmax(B)
+            f32x16 oT = zero16();
+#pragma unroll
+            for (int t = HA; t < NKT; ++t) pv_tile(t, oT);
+            {
+                const float inv = 1.0f / l;
+                const float ia = alpha * inv;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oT[r] = oA[r] * ia + oT[r] * inv;
+            }
+            if (h < 2) TSTAMP();   // PV issued
+            if (OB) {
+                // ---- out^T += Wout_h^T . O^T on the bf16 pipe: O^T split from the accumulators (registers 8kc..8kc+7 = the
+                // B fragment of d-chunk kc), to_out as the k-permuted 3-way split image wout_sp (pack.pack_bf3_temporal_out:
+                // slot (kc, k-half, i) of head h holds row h*32 + 16 kc + 8 (i >> 2) + 4 k-half + (i & 3))
+                bf16x8t op[3][2];
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    float orr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) orr[i] = oT[8 * kc + i];
+                    split3_oct(orr, op[0][kc], op[1][kc], op[2][kc]);
+                }
+                const unsigned char* wb = reinterpret_cast<const unsigned char*>(wout_sp) + ((size_t)half * C + l31) * 16;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    bf16x8t wf[3][2];
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            wf[pl][kc] = *reinterpret_cast<const bf16x8t*>(
+                                wb + ((size_t)(((2 * h + kc) * 3 + pl) * 2) * C + 32 * nt) * 16);
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                        for (int u = 0; u < 6; ++u)
+                            outT[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[PA6[u]][kc], op[PB6[u]][kc], outT[nt], 0, 0, 0);
+                }
+            } else {
+                // ---- out^T += Wout_h^T . O^T   (fp32 MFMA; A = to_out rows h*32 + d, columns n)
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 w4 = *reinterpret_cast<const f32x4*>(
+                            wout + ((size_t)(h * (DH / 4) + 2 * c + half) * C + 32 * nt + l31) * 4);
+#pragma unroll
+                        for (int s = 0; s < 4; ++s)
+                            outT[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(w4[s], oT[4 * c + s], outT[nt], 0, 0, 0);
+                    }
+            }
+        }
+        if (h < 2) TSTAMP();   // out-proj issued (before end-of-head barrier)
+        __syncthreads();       // K / V planes are rewritten by the next head
+    }
+
+    if (has_q && iq >= q0 && iq < qend) {
+        const float* xr = x + ((long)iq * HW + p) * C;
+        float* orow = out + ((long)(iq - q0) * HW + p) * C;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = 32 * nt + 8 * g + 4 * half;
+                const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + n);
+                f32x4 o = {outT[nt][4 * g], outT[nt][4 * g + 1], outT[nt][4 * g + 2], outT[nt][4 * g + 3]};
+                *reinterpret_cast<f32x4*>(orow + n) = o + xv;
+            }
+    }
+    TSTAMP();   // end
+#ifdef DAWN_TL_TIMING
+    if (lane == 0 && blockIdx.x < 512)
+        for (int i = 0; i < 24; ++i) dawn_tl_dbg[((size_t)blockIdx.x * 8 + wave) * 24 + i] = i < tix ? tsb[wave * 24 + i] : 0ull;
+#endif
+#endif
+}
+
 }  // namespace
 
-extern "C" int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
-                                       const void* wqkv_bf3, const float* wout, const float* rot_cos,
-                                       const float* rot_sin, const float* band, float eps, float* out, void* stream) {
+extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
+                                          const void* wqkv_bf3, const float* wout, const void* wout_bf3p,
+                                          const float* rot_cos, const float* rot_sin, const float* band, float eps,
+                                          float* out, int flags, void* stream) {
     if (Fq <= 0) return 0;
     if (q0 < 0 || q0 + Fq > Fext || win < 0) return dawn_set_error_msg(-32, "dawn_temporal_layer_c64: bad frame range");
     if (Fq > 256 || Fext > 288) return dawn_set_error_msg(-33, "dawn_temporal_layer_c64: Fq <= 256 and Fext <= 288 only");
     const int nkt = (32 + 2 * win + 31) / 32;
     const int nrt = (Fext + 31) / 32;
+    if (nkt > 4) return dawn_set_error_msg(-35, "dawn_temporal_layer_c64: win > 48 not supported (use the unfused path)");
+    const int force = flags & 7;                       // 0 = automatic, m + 1 = WMODE m (A/B measurements, tests)
     const size_t band_floats = (size_t)HEADS * (32 * nkt + 32);
     const size_t base = ((size_t)32 * nrt * (XLD + KLD + DH) + band_floats) * sizeof(float);
     // WMODE 2 (split-operand projections): X as bf16 planes (96 floats per row instead of XLD), no weight region
     const size_t base2 = ((size_t)32 * nrt * (96 + KLD + DH) + band_floats) * sizeof(float);
-    const bool split = wqkv_bf3 != nullptr && base2 <= 163840;
-    const bool wlds = !split && base + 32768 <= 163840;
+    // WMODE 3 (also S and P.V on the bf16 pipe): X + K planes for Fext rows, V^T for 32 nrt keys
+    const int delta = (((q0 - win) % 16) + 16) % 16;
+    const size_t base3 = (size_t)Fext * 576 + (size_t)nrt * 6144 + band_floats * sizeof(float);
+    bool mode3 = wqkv_bf3 != nullptr && base3 <= 163840 && Fq + delta <= 256 && (force == 0 || force == 4);
+    if (force == 4 && !mode3) return dawn_set_error_msg(-36, "dawn_temporal_layer_c64: WMODE 3 does not fit this shape");
+    const bool split = !mode3 && wqkv_bf3 != nullptr && base2 <= 163840 && (force == 0 || force == 3);
+    const bool wlds = !mode3 && !split && base + 32768 <= 163840 && force != 1;
 #ifdef DAWN_TL_TIMING
     const size_t lds = 163840;                 // instrumented build: stamps live at byte 160000
+    if (mode3 && base3 > 160000) mode3 = false;
 #else
-    const size_t lds = split ? base2 : base + (wlds ? 32768 : 0);
+    const size_t lds = mode3 ? base3 : (split ? base2 : base + (wlds ? 32768 : 0));
 #endif
     const unsigned short* ws = (const unsigned short*)wqkv_bf3;
     if (lds > 163840) return dawn_set_error_msg(-34, "dawn_temporal_layer_c64: LDS budget exceeded");
     hipStream_t s = (hipStream_t)stream;
+    const unsigned short* wsp = (const unsigned short*)wout_bf3p;
+    const bool hl = 32 + 2 * win <= 32 * nkt - 16;       // the upper 16 keys of the last key tile are never in a window
+    const bool ob = wout_bf3p != nullptr && !(flags & 32);
+#define LAUNCH_TL3B(N, SC, HLV, OBV)                                                                           \
+    do {                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV>,                \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        hipLaunchKernelGGL((temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV>), dim3(HW), dim3(512), lds, s, x,  \
+                           Fext, HW, q0, Fq, win, ws, wout, wsp, rot_cos, rot_sin, band, eps, out, nrt, delta); \
+    } while (0)
+#define LAUNCH_TL3(N, SC)                                                                                      \
+    do {                                                                                                       \
+        if (hl && ob) LAUNCH_TL3B(N, SC, true, true);                                                          \
+        else if (hl) LAUNCH_TL3B(N, SC, true, false);                                                          \
+        else if (ob) LAUNCH_TL3B(N, SC, false, true);                                                          \
+        else LAUNCH_TL3B(N, SC, false, false);                                                                 \
+    } while (0)
 #define LAUNCH_TL(N)                                                                                           \
     do {                                                                                                       \
-        if (split) {                                                                                           \
+        if (mode3) {                                                                                           \
+            if (flags & 16) LAUNCH_TL3(N, 1); else LAUNCH_TL3(N, 0);                                           \
+        } else if (split) {                                                                                    \
             (void)hipFuncSetAttribute((const void*)temporal_layer_c64_kernel<N, 2>,                            \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                   \
             hipLaunchKernelGGL((temporal_layer_c64_kernel<N, 2>), dim3(HW), dim3(512), lds, s, x, Fext, HW,    \
@@ -533,10 +996,18 @@ extern "C" int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0,
         case 1: LAUNCH_TL(1); break;
         case 2: LAUNCH_TL(2); break;
         case 3: LAUNCH_TL(3); break;
-        case 4: LAUNCH_TL(4); break;
-        default: return dawn_set_error_msg(-35, "dawn_temporal_layer_c64: win > 48 not supported (use the unfused path)");
+        default: LAUNCH_TL(4); break;
     }
 #undef LAUNCH_TL
+#undef LAUNCH_TL3
+#undef LAUNCH_TL3B
     DAWN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
+                                       const void* wqkv_bf3, const float* wout, const float* rot_cos,
+                                       const float* rot_sin, const float* band, float eps, float* out, void* stream) {
+    return dawn_temporal_layer_c64_ex(x, Fext, HW, q0, Fq, win, wqkv, wqkv_bf3, wout, nullptr, rot_cos, rot_sin, band, eps,
+                                      out, 0, stream);
 }

@@ -43,6 +43,7 @@ class HipOps:
         self._side_stream = None
         self.graph_error = None      # set when a HIP-graph capture failed and the sampler fell back to eager
         self.conv_policy = 0         # dawn_conv_desc.policy of every conv_gemm launch (0 = shipped kernel policy)
+        self.temporal_flags = 0      # kernel-family selector of the fused temporal layer (0 = automatic; A/B and tests)
 
     def with_comm(self, comm):
         o = HipOps(comm)
@@ -51,6 +52,7 @@ class HipOps:
         o.prof_every = getattr(self, "prof_every", 1)
         o.overlap = self.overlap
         o.conv_policy = self.conv_policy
+        o.temporal_flags = self.temporal_flags
         return o
 
     # ------------------------------------------------------------------ helpers
@@ -311,13 +313,15 @@ class HipOps:
 
     def temporal_layer_c64(self, x: Tensor, Fext: int, HW: int, q0: int, Fq: int, win: int, wqkv: Tensor,
                            wout: Tensor, rcos: Tensor, rsin: Tensor, band: Tensor, eps: float = 1e-5,
-                           wqkv_bf3: Optional[Tensor] = None) -> Tensor:
+                           wqkv_bf3: Optional[Tensor] = None, wout_bf3p: Optional[Tensor] = None) -> Tensor:
         """out = x[q0:q0+Fq] + to_out(attn(LayerNorm(x))) for 64-channel levels, one kernel."""
         assert x.is_contiguous() and x.shape == (Fext * HW, 64)
         self._require(x, wqkv, wout, rcos, rsin, band)
         out = self.empty(Fq * HW, 64, like=x)
-        check(self.L.dawn_temporal_layer_c64(_p(x), Fext, HW, q0, Fq, win, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(rcos),
-                                             _p(rsin), _p(band), eps, _p(out), self._stream()), "dawn_temporal_layer_c64")
+        check(self.L.dawn_temporal_layer_c64_ex(_p(x), Fext, HW, q0, Fq, win, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(wout_bf3p),
+                                                _p(rcos), _p(rsin), _p(band), eps, _p(out), self.temporal_flags,
+                                                self._stream()),
+              "dawn_temporal_layer_c64")
         return out
 
     def sla(self, qkv: Tensor, F: int, HW: int) -> Tensor:

@@ -39,6 +39,22 @@ def pack_bf3(w_kn: Tensor) -> Tensor:
     return planes.reshape(3, K // 16, 2, 8, N).permute(1, 0, 2, 4, 3).contiguous()
 
 
+def pack_bf3_temporal_out(w_kn: Tensor) -> Tensor:
+    """to_out of the temporal attention, (256, C) with k = head*32 + d, as the 3-way bf16 split image the all-bf16-pipe
+    fused layer (temporal_layer.hip, WMODE 3) consumes: within every head the rows are permuted to the accumulator order
+    of O^T, so that its registers feed the MFMA's B operand unshuffled -- slot (d-chunk kc, k-half hf, i) holds row
+    head*32 + 16 kc + 8 (i >> 2) + 4 hf + (i & 3)."""
+    K, N = w_kn.shape
+    assert K % 32 == 0
+    idx = []
+    for head in range(K // 32):
+        for kc in range(2):
+            for hf in range(2):
+                for i in range(8):
+                    idx.append(head * 32 + 16 * kc + 8 * (i >> 2) + 4 * hf + (i & 3))
+    return pack_bf3(w_kn[torch.tensor(idx)])
+
+
 def unpack_kn(wp: Tensor) -> Tensor:
     K4, N, _ = wp.shape
     return wp.permute(0, 2, 1).reshape(K4 * 4, N)
@@ -122,6 +138,7 @@ class PackedAttn:
     bout: Optional[Tensor] = None
     wqkv_s: Optional[Tensor] = None       # pack_bf3 images of wqkv / wout (split-operand kernels)
     wout_s: Optional[Tensor] = None
+    wout_sp: Optional[Tensor] = None      # pack_bf3_temporal_out image (64-channel temporal layers, all-bf16-pipe kernel)
 
 
 @dataclass
@@ -209,6 +226,8 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
         # exact 3-way bf16 split images for the split-operand kernels (fused 64-channel layers, large 1x1 GEMMs)
         a.wqkv_s = pack_bf3(wqkv.t() * gamma[:, None]).to(device)
         a.wout_s = pack_bf3(wout.t()).to(device)
+        if not spatial_linear and a.C == 64:
+            a.wout_sp = pack_bf3_temporal_out(wout.t()).to(device)
         return a
 
     def resblock(p: str) -> PackedResBlock:

@@ -137,6 +137,17 @@ int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, int Fq, int w
 int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
                             const void* wqkv_bf3, const float* wout, const float* rot_cos, const float* rot_sin,
                             const float* band, float eps, float* out, void* stream);
+/* same, with a kernel-family selector for A/B measurements and tests: flags & 7 = 0 automatic (what the entry point above
+ * does), m + 1 forces WMODE m: 0 fp32 MFMA with weights from L2, 1 fp32 MFMA with per-head weight slices in LDS, 2 Q/K/V
+ * projections on the bf16 pipe (exact 3-way operand split), 3 additionally S = K.Q^T and O = V^T.P^T on the bf16 pipe
+ * (K / V split once per head into bf16 planes in LDS, Q / P split from the accumulators; fits up to Fext ~ 200 rows:
+ * the benchmark clip); flags & 16 adds explicit MFMA/VALU interleave hints to WMODE 3 (measured: no gain); flags & 32 keeps
+ * the out-projection of WMODE 3 on the fp32 MFMA even when wout_bf3p is given.  wout_bf3p (optional, WMODE 3): the exact
+ * 3-way bf16 split of to_out with the rows of every head permuted to the accumulator order of O^T, [256/16][3][2][64][8]
+ * (pack.pack_bf3_temporal_out).  All families compute the same function to fp32 round-off. */
+int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
+                               const void* wqkv_bf3, const float* wout, const void* wout_bf3p, const float* rot_cos,
+                               const float* rot_sin, const float* band, float eps, float* out, int flags, void* stream);
 
 /* ---- A8 SpatialLinearAttention core (MT:611-627) ---------------------------------------------- */
 int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);     /* ctx (F,8,32,32) */

@@ -247,7 +247,7 @@ class RefOps:
     def can_fuse_temporal(C, Fext, Fq, win):
         return C == 64 and Fext <= 288 and Fq <= 256 and win <= 48
 
-    def temporal_layer_c64(self, x, Fext, HW, q0, Fq, win, wqkv, wout, rcos, rsin, band, eps=1e-5, wqkv_bf3=None):
+    def temporal_layer_c64(self, x, Fext, HW, q0, Fq, win, wqkv, wout, rcos, rsin, band, eps=1e-5, wqkv_bf3=None, wout_bf3p=None):
         """Composition of the unfused reference ops (what the fused kernel must equal)."""
         stats = self.ln_rowstats(x, None, eps)
         qkv = self.conv_gemm(x, wqkv, 768, row_stats=stats, F=Fext, Hi=1, Wi=HW)

@@ -419,7 +419,10 @@ def test_temporal_attn(hip, ref, Fext, HW, q0, Fq, win):
 
 
 @pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(12, 5, 0, 12, 3), (200, 3, 0, 200, 40), (280, 2, 40, 200, 40),
-                                                 (45, 4, 3, 40, 7), (33, 2, 0, 33, 40), (240, 2, 40, 200, 40)])
+                                                 (45, 4, 3, 40, 7), (33, 2, 0, 33, 40), (240, 2, 40, 200, 40),
+                                                 (200, 64, 0, 200, 40), (200, 3, 47, 120, 40), (190, 2, 5, 185, 33),
+                                                 (96, 4, 0, 96, 40), (130, 2, 13, 100, 40), (150, 2, 0, 150, 48),
+                                                 (100, 2, 9, 80, 45), (64, 3, 0, 64, 16), (120, 2, 31, 70, 24)])
 def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
     """Fused layer kernel == composition of LN stats + qkv GEMM + windowed attention + out GEMM + residual."""
     x = rnd(Fext * HW, 64, seed=1) * 1.3 + 0.2
@@ -431,9 +434,26 @@ def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
     got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band))
     check(f"temporal_layer_c64/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 3e-5)
     from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
-    got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band),
-                                 wqkv_bf3=pack_bf3(unpack_kn(wqkv)).cuda())
+    from dawn_pytorch_amd.pack import pack_bf3_temporal_out
+    wsplit = pack_bf3(unpack_kn(wqkv)).cuda()
+    wosp = pack_bf3_temporal_out(unpack_kn(wout)).cuda()
+    got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band), wqkv_bf3=wsplit)
     check(f"temporal_layer_c64_split/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 3e-5)
+    # every kernel family explicitly (flags: m + 1 forces WMODE m; 16 = WMODE 3 without the interleave hints)
+    try:
+        for flags, name in ((1, "wmode0"), (2, "wmode1"), (3, "wmode2"), (4, "wmode3"), (4 | 16, "wmode3_sched"),
+                            (4 | 32, "wmode3_out_fp32")):
+            if flags & 7 == 4 and (Fext * 576 + ((Fext + 31) // 32) * 6144 + 8 * (32 * ((32 + 2 * win + 31) // 32) + 32) * 4 > 163840
+                                   or Fq + (q0 - win) % 16 > 256):
+                continue                                         # WMODE 3 does not fit this shape (LDS)
+            if flags == 2 and Fext > 192:
+                continue                                         # weight slices in LDS need the room
+            hip.temporal_flags = flags
+            got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band), wqkv_bf3=wsplit,
+                                         wout_bf3p=wosp)
+            check(f"temporal_layer_c64_{name}/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 3e-5)
+    finally:
+        hip.temporal_flags = 0
 
 
 @pytest.mark.parametrize("F,HW", [(3, 64), (2, 256), (5, 16), (2, 100)])

@@ -6,7 +6,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dawn_pytorch_amd.ops import HipOps
-from dawn_pytorch_amd.pack import pack_kn, pack_bf3, rel_pos_bucket
+from dawn_pytorch_amd.pack import pack_kn, pack_bf3, pack_bf3_temporal_out, rel_pos_bucket
 
 ops = HipOps()
 dev = "cuda"
@@ -15,7 +15,9 @@ torch.manual_seed(0)
 x = torch.randn(F * HW, 64, device=dev)
 wqkv_kn = torch.randn(64, 768) * 0.125
 wqkv, wqkv_s = pack_kn(wqkv_kn).to(dev), pack_bf3(wqkv_kn).to(dev)
-wout = pack_kn(torch.randn(256, 64) / 16).to(dev)
+wout_kn = torch.randn(256, 64) / 16
+wout = pack_kn(wout_kn).to(dev)
+wout_sp = pack_bf3_temporal_out(wout_kn).to(dev)
 bias = torch.randn(64, device=dev)
 pos = torch.arange(F + 2 * win, dtype=torch.float32)
 freqs = 10000.0 ** (-torch.arange(0, 32, 2, dtype=torch.float32) / 32)
@@ -37,6 +39,12 @@ def timeit(fn, n=5):
 for name, s in (("fp32", None), ("split", wqkv_s)):
     t = timeit(lambda: ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band, wqkv_bf3=s))
     print(f"temporal_layer_c64 {name:6s}: {t:8.1f} us")
+for flags, name in ((3, "WMODE 2 (projections on the bf16 pipe)"), (4, "WMODE 3 (+ S, P.V, out-proj on the bf16 pipe)"),
+                    (4 | 32, "WMODE 3 with the out-projection on fp32 MFMA"), (4 | 16, "WMODE 3 with interleave hints")):
+    ops.temporal_flags = flags
+    t = timeit(lambda: ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band, wqkv_bf3=wqkv_s, wout_bf3p=wout_sp))
+    print(f"temporal_layer_c64 {name}: {t:8.1f} us")
+ops.temporal_flags = 0
 # T-shard geometry: 200 own frames + 40 halo frames on each side (interior shard), 240 for an edge shard
 xe = torch.randn(280 * HW, 64, device=dev)
 rc2, rs2 = torch.cos(torch.arange(280 + 2 * win, dtype=torch.float32)[:, None] * freqs[None, :]).to(dev), torch.sin(torch.arange(280 + 2 * win, dtype=torch.float32)[:, None] * freqs[None, :]).to(dev)

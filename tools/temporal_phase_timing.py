@@ -6,15 +6,17 @@ import numpy as np, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from dawn_pytorch_amd.ops import HipOps
-from dawn_pytorch_amd.pack import pack_kn, pack_bf3
+from dawn_pytorch_amd.pack import pack_kn, pack_bf3, pack_bf3_temporal_out
 ops = HipOps()
 dev = "cuda"
-F, HW, win = 200, 4096, 40
+F, HW, win = (int(sys.argv[1]) if len(sys.argv) > 1 else 200), 4096, 40
 torch.manual_seed(0)
 x = torch.randn(F * HW, 64, device=dev)
 wqkv_kn = torch.randn(64, 768) * 0.125
 wqkv, wqkv_s = pack_kn(wqkv_kn).to(dev), pack_bf3(wqkv_kn).to(dev)
-wout = pack_kn(torch.randn(256, 64) / 16).to(dev)
+wout_kn = torch.randn(256, 64) / 16
+wout = pack_kn(wout_kn).to(dev)
+wout_sp = pack_bf3_temporal_out(wout_kn).to(dev)
 pos = torch.arange(F + 2 * win, dtype=torch.float32)
 freqs = 10000.0 ** (-torch.arange(0, 32, 2, dtype=torch.float32) / 32)
 ang = pos[:, None] * freqs[None, :]
@@ -25,10 +27,12 @@ ops.L.dawn_temporal_set_debug.argtypes = [ctypes.c_void_p]
 assert ops.L.dawn_temporal_set_debug(dbg.data_ptr()) == 0
 names = ["start", "phase0+setup", "h0 start", "h0 KV proj", "h0 barrier", "h0 Q proj", "h0 S(A)", "h0 S(B)+smA", "h0 PV(A)+smB", "h0 PV(B)", "h0 out",
          "h1 start", "h1 KV proj", "h1 barrier", "h1 Q proj", "h1 S(A)", "h1 S(B)+smA", "h1 PV(A)+smB", "h1 PV(B)", "h1 out", "end (6 more heads + store)"]
-for label, s in (("fp32 (WMODE 1)", None), ("split (WMODE 2)", wqkv_s)):
+for label, s, flags in (("fp32 (WMODE 1)", None, 0), ("split projections (WMODE 2)", wqkv_s, 3),
+                        ("all-bf16-pipe (WMODE 3)", wqkv_s, 4), ("WMODE 3, out-projection on fp32 MFMA", wqkv_s, 4 | 32)):
+    ops.temporal_flags = flags
     for _ in range(2):
         dbg.zero_()
-        ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band, wqkv_bf3=s)
+        ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band, wqkv_bf3=s, wout_bf3p=wout_sp)
         torch.cuda.synchronize()
     t = dbg.cpu().numpy().reshape(512, 8, 24).astype(np.float64)
     print(f"--- {label}: mean cycles between stamps, per wave (columns = waves 0..7; wave 7 has no query tile)")
