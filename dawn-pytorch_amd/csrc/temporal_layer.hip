@@ -504,14 +504,37 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
 // LDS: X planes 384 B + K planes 192 B per frame row (rows = Fext, no padding: reads clamp) + V^T 192 B per key of
 // 32*nrt + the bias table: 163,328 B at Fext = 200 (the benchmark clip); longer buffers (T-shard interior shards) use
 // WMODE 2 / 1.
+// Exact 3-way split of 8 fp32 values into bf16 pieces by TRUNCATION: p1 = top 16 bits of x, r = x - p1 (exact), p2 = top 16
+// bits of r, r2 = r - p2 (exact, <= 8 significant bits left) = p3.  p1 + p2 + p3 == x bit for bit, every piece is a valid
+// bf16, and the instruction mix is the cheap one on gfx950 (tools/ubench/valu_rate.hip: v_and / v_sub issue at ~2.4 cycles
+// with two waves per SIMD, v_cvt_pk_bf16_f32 / v_lshlrev / v_perm at ~4.3): per pair 4 v_and + 4 v_sub + 3 v_perm.
 __device__ __forceinline__ void split3_oct(const float (&v)[8], bf16x8t& p1, bf16x8t& p2, bf16x8t& p3) {
-    float r[8];
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q1, q2, q3;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { p1[i] = (__bf16)v[i]; r[i] = v[i] - (float)p1[i]; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) { p2[i] = (__bf16)r[i]; r[i] = r[i] - (float)p2[i]; }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) p3[i] = (__bf16)r[i];
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        const unsigned a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
+        const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
+        const unsigned a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
+        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+        q1[i] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);          // [hi16(a) | hi16(b) << 16]
+        q2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+        q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    }
+    p1 = __builtin_bit_cast(bf16x8t, q1);
+    p2 = __builtin_bit_cast(bf16x8t, q2);
+    p3 = __builtin_bit_cast(bf16x8t, q3);
+}
+
+// Sum over the 16 lanes of a DPP row, result in every lane, as four v_add_f32_dpp (quad xor 1, quad xor 2, half-row mirror,
+// row mirror): same pairing tree as the xor butterfly (bit-identical), without its ds_bpermute round trips.
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    return v;
 }
 
 // K^T (transposed: lane = row, registers = features) and V (lane = feature, registers = rows) of one 32-row tile for one
@@ -522,43 +545,102 @@ __device__ __forceinline__ void proj_KV_split(const __amdgpu_buffer_rsrc_t rw, u
     constexpr int WS = 2 * 768 * 16;
     kT = zero16();
     v = zero16();
-    bf16x8t wk[2][3], wv[2][3];
+    // all 24 weight fragments of the head's K / V slices are requested before the first MFMA (96 VGPRs): one exposed L2
+    // round trip per row tile instead of one per 16-channel chunk (a chunk's 12 MFMAs are shorter than the L2 latency)
+    bf16x8t wk[4][3], wv[4][3];
 #pragma unroll
-    for (int pl = 0; pl < 3; ++pl) {
-        wk[0][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colk * 16 + pl * WS, 0));
-        wv[0][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colv * 16 + pl * WS, 0));
-    }
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            wk[kc][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colk * 16 + (kc * 3 + pl) * WS, 0));
+            wv[kc][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colv * 16 + (kc * 3 + pl) * WS, 0));
+        }
+    __builtin_amdgcn_sched_barrier(0);          // keep the requests in front (the scheduler sinks them to save registers)
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc) {
-        if (kc < 3) {
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl) {
-                wk[(kc + 1) & 1][pl] = __builtin_bit_cast(
-                    bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colk * 16 + ((kc + 1) * 3 + pl) * WS, 0));
-                wv[(kc + 1) & 1][pl] = __builtin_bit_cast(
-                    bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colv * 16 + ((kc + 1) * 3 + pl) * WS, 0));
-            }
-        }
         bf16x8t xs[3];
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
             xs[pl] = *reinterpret_cast<const bf16x8t*>(xp + (size_t)((pl * 4 + kc) * 2) * FA * 16);
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
-            kT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[kc & 1][PW[u]], xs[PX[u]], kT, 0, 0, 0);   // D^T = W^T . X^T
-            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[PX[u]], wv[kc & 1][PW[u]], v, 0, 0, 0);     // D   = X . W
+            kT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wk[kc][PW[u]], xs[PX[u]], kT, 0, 0, 0);   // D^T = W^T . X^T
+            v = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[PX[u]], wv[kc][PW[u]], v, 0, 0, 0);     // D   = X . W
         }
     }
 }
 
-template <int NKT, int SCHED, bool HL, bool OB>
+// the same, as two passes: K^T first (returned early so that the caller's rotary + split of K runs in the shadow of the V
+// pass) -- the V pass is `proj_V_pass`; weight fragments of both are requested up front by the caller
+struct KVWeights { bf16x8t wk[4][3], wv[4][3]; };
+__device__ __forceinline__ void kv_weights_request(const __amdgpu_buffer_rsrc_t rw, unsigned wvoff, int colk, int colv, KVWeights& w) {
+    constexpr int WS = 2 * 768 * 16;
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            w.wk[kc][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colk * 16 + (kc * 3 + pl) * WS, 0));
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            w.wv[kc][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colv * 16 + (kc * 3 + pl) * WS, 0));
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <bool VPASS>
+__device__ __forceinline__ f32x16 proj_pass(const KVWeights& w, const unsigned char* xp, int FA) {
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+    f32x16 d = zero16();
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        bf16x8t xs[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            xs[pl] = *reinterpret_cast<const bf16x8t*>(xp + (size_t)((pl * 4 + kc) * 2) * FA * 16);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            if (VPASS) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[PX[u]], w.wv[kc][PW[u]], d, 0, 0, 0);    // D   = X . W
+            else d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.wk[kc][PW[u]], xs[PX[u]], d, 0, 0, 0);          // D^T = W^T . X^T
+        }
+    }
+    return d;
+}
+
+// Q^T of one 32-row tile for one head, all 12 weight fragments requested up front (see proj_KV_split)
+__device__ __forceinline__ f32x16 proj_Q_split(const __amdgpu_buffer_rsrc_t rw, unsigned wvoff, int col,
+                                               const unsigned char* xp, int FA) {
+    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};
+    constexpr int WS = 2 * 768 * 16;
+    f32x16 d = zero16();
+    bf16x8t w[4][3];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            w[kc][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, col * 16 + (kc * 3 + pl) * WS, 0));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        bf16x8t xs[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            xs[pl] = *reinterpret_cast<const bf16x8t*>(xp + (size_t)((pl * 4 + kc) * 2) * FA * 16);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w[kc][PW[u]], xs[PX[u]], d, 0, 0, 0);
+    }
+    return d;
+}
+
+template <int NKT, int SCHED, bool HL, bool OB, int FAC>
 __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     const float* __restrict__ x, int Fext, int HW, int q0, int Fq, int win, const unsigned short* __restrict__ wqkv_s,
     const float* __restrict__ wout, const unsigned short* __restrict__ wout_sp, const float* __restrict__ rcos,
     const float* __restrict__ rsin, const float* __restrict__ band, float eps, float* __restrict__ out, int nrt, int delta) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    const int FA = Fext;                                         // rows of the X / K planes (reads clamp to FA - 1)
+    // row capacity (= stride) of the X / K planes; reads clamp to Fext - 1.  FAC != 0: compile-time capacity, so that every
+    // plane / chunk offset folds into the ds instructions' immediate fields instead of costing a v_add each
+    const int FA = FAC ? FAC : Fext;
     const int NBV = 2 * nrt;                                     // 16-key blocks of V^T
     unsigned char* Xp = reinterpret_cast<unsigned char*>(smem);  // [3][4][2][FA] x 16 B
     unsigned char* Kp = Xp + (size_t)24 * FA * 16;               // [3][2][2][FA] x 16 B
@@ -591,24 +673,24 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
         for (int i = 0; i < MAXR; ++i) {
             const int j = (tid >> 4) + 32 * i;
             xv[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (j < FA) xv[i] = *reinterpret_cast<const f32x4*>(x + ((long)j * HW + p) * C + sub * 4);
+            if (j < Fext) xv[i] = *reinterpret_cast<const f32x4*>(x + ((long)j * HW + p) * C + sub * 4);
         }
 #pragma unroll
         for (int i = 0; i < MAXR; ++i) {
             const int j = (tid >> 4) + 32 * i;
             const f32x4 v = xv[i];
             float s = v.x + v.y + v.z + v.w;
-            s = wave_sum(s, 16);
+            s = row16_sum(s);
             const float mu = s * (1.0f / C);
             const f32x4 dl = v - mu;
             float ss = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w;
-            ss = wave_sum(ss, 16);
+            ss = row16_sum(ss);
             const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
             const f32x4 o = dl * rs;
             uint2 p1, p2, p3;
             split3_quad_t(o, p1, p2, p3);
             const int kc = sub >> 2, qd = sub & 3;
-            if (j < FA) {
+            if (j < Fext) {
                 unsigned char* dst = Xp + ((size_t)(kc * 2 + (qd >> 1)) * FA + j) * 16 + (qd & 1) * 8;
                 *reinterpret_cast<uint2*>(dst) = p1;
                 *reinterpret_cast<uint2*>(dst + (size_t)8 * FA * 16) = p2;
@@ -624,7 +706,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     const bool has_q = wave < nqt;
     const int i0 = q0 - delta + 32 * wave;                       // first (possibly dummy) query row of this wave's tile
     const int iq = i0 + l31;
-    const int iqc = iq < 0 ? 0 : (iq < Fext ? iq : Fext - 1);
+    const int iqc = max(0, min(iq, Fext - 1));
     const int qend = q0 + Fq;
     const float scale = 0.17677669529663687f;
     constexpr float LOG2E = 1.4426950408889634f;
@@ -639,15 +721,18 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
         // ---- K^T / V projection of every frame row; rotary on K; both split into bf16 planes in LDS
         for (int rt = wave; rt < nrt; rt += 8) {
             const int j = 32 * rt + l31;
-            const int jc = j < FA ? j : FA - 1;
+            const int jc = min(j, Fext - 1);
             float2 kcs[4], ksn[4];
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 kcs[c] = *reinterpret_cast<const float2*>(rcos + jc * 16 + 4 * c + 2 * half);
                 ksn[c] = *reinterpret_cast<const float2*>(rsin + jc * 16 + 4 * c + 2 * half);
             }
-            f32x16 kT, vv;
-            proj_KV_split(rsw, wvoff, HEADS * DH + h * DH, 2 * HEADS * DH + h * DH, Xp + ((size_t)half * FA + jc) * 16, FA, kT, vv);
+            KVWeights kvw;
+            kv_weights_request(rsw, wvoff, HEADS * DH + h * DH, 2 * HEADS * DH + h * DH, kvw);
+            const unsigned char* xrow = Xp + ((size_t)half * FA + jc) * 16;
+            const f32x16 kT = proj_pass<false>(kvw, xrow, FA);
+            const f32x16 vv = proj_pass<true>(kvw, xrow, FA);       // its MFMAs cover the rotary + split of K below
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
                 float kr[8];
@@ -662,7 +747,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                 }
                 bf16x8t k1, k2, k3;
                 split3_oct(kr, k1, k2, k3);
-                if (j < FA) {
+                if (j < Fext) {
                     unsigned char* dst = Kp + ((size_t)(kc * 2 + half) * FA + j) * 16;
                     *reinterpret_cast<bf16x8t*>(dst) = k1;
                     *reinterpret_cast<bf16x8t*>(dst + (size_t)4 * FA * 16) = k2;
@@ -674,9 +759,13 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
             for (int g = 0; g < 2; ++g) {
                 float vr[8];
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const int key = 32 * rt + 16 * g + 4 * half + (i & 3) + 8 * (i >> 2);
-                    vr[i] = key < Fext ? vv[8 * g + i] : 0.f;          // padded keys: finite zeros (their P is exactly 0)
+                for (int i = 0; i < 8; ++i) vr[i] = vv[8 * g + i];
+                if (32 * rt + 32 > Fext) {                              // wave-uniform: only the last row tile has padded keys
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int key = 32 * rt + 16 * g + 4 * half + (i & 3) + 8 * (i >> 2);
+                        vr[i] = key < Fext ? vr[i] : 0.f;               // finite zeros (their P is exactly 0)
+                    }
                 }
                 bf16x8t v1, v2, v3;
                 split3_oct(vr, v1, v2, v3);
@@ -700,8 +789,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                     qcs[c] = *reinterpret_cast<const float2*>(rcos + iqc * 16 + 4 * c + 2 * half);
                     qsn[c] = *reinterpret_cast<const float2*>(rsin + iqc * 16 + 4 * c + 2 * half);
                 }
-                f32x16 qT, unused;
-                proj_T_split<false>(rsw, wvoff, h * DH, h * DH, Xp + ((size_t)half * FA + iqc) * 16, FA, qT, unused);
+                const f32x16 qT = proj_Q_split(rsw, wvoff, h * DH, Xp + ((size_t)half * FA + iqc) * 16, FA);
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
                     float qr[8];
@@ -729,8 +817,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
             f32x16 st[NKT];
             auto s_tile = [&](int t) {                                         // S^T tile = K . Q^T, 12 bf16 MFMAs
                 st[t] = zero16();
-                int j = j0 + 32 * t + l31;
-                j = j < 0 ? 0 : (j >= FA ? FA - 1 : j);
+                const int j = max(0, min(j0 + 32 * t + l31, Fext - 1));
                 const unsigned char* kr = Kp + ((size_t)half * FA + j) * 16;
                 bf16x8t kf[3][2];
 #pragma unroll
@@ -757,22 +844,33 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     if (r < nreg(t)) bz[r] = bb[32 * t + (r & 3) + 8 * (r >> 2)];
+                // all slots of the tile are frames of the clip (wave-uniform; true for every tile away from the clip ends):
+                // the window mask is already in the table, no per-element select (v_cndmask issues at ~20 cycles here)
+                if (32 * t >= lo && 32 * t + 2 * nreg(t) <= hi) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    if (r >= nreg(t)) continue;
-                    const int c = 32 * t + (r & 3) + 8 * (r >> 2);
-                    const bool ok = (unsigned)(vbase + c) < span;
-                    const float sv = ok ? st[t][r] + bz[r] : NEG;
-                    st[t][r] = sv;
-                    m = fmaxf(m, sv);
+                    for (int r = 0; r < 16; ++r) {
+                        if (r >= nreg(t)) continue;
+                        const float sv = st[t][r] + bz[r];
+                        st[t][r] = sv;
+                        m = fmaxf(m, sv);
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (r >= nreg(t)) continue;
+                        const int c = 32 * t + (r & 3) + 8 * (r >> 2);
+                        const bool ok = (unsigned)(vbase + c) < span;
+                        const float sv = ok ? st[t][r] + bz[r] : NEG;
+                        st[t][r] = sv;
+                        m = fmaxf(m, sv);
+                    }
                 }
             };
             auto pv_tile = [&](int t, f32x16& o) {                             // o^T += V^T . P^T, 12 (6) bf16 MFMAs
 #pragma unroll
                 for (int g = 0; g < 2; ++g) {
                     if (8 * g >= nreg(t)) continue;
-                    int b = (j0m >> 4) + 2 * t + g;
-                    b = b < 0 ? 0 : (b >= NBV ? NBV - 1 : b);                  // clamped blocks hold masked keys only (P = 0)
+                    const int b = max(0, min((j0m >> 4) + 2 * t + g, NBV - 1));    // clamped blocks hold masked keys only (P = 0)
                     const unsigned char* vr = Vt + ((size_t)(b * 2 + half) * 32 + l31) * 16;
                     bf16x8t vf[3];
 #pragma unroll
@@ -844,6 +942,20 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
             }
             l += __shfl_xor(l, 32, 64);
             if (h < 2) TSTAMP();   // PV(A) issued + softmax(B)
+            // to_out fragments of this head (bf16 pipe): requested here, consumed after P.V of half B
+            bf16x8t wf[2][3][2];
+            if (OB) {
+                const unsigned char* wb = reinterpret_cast<const unsigned char*>(wout_sp) + ((size_t)half * C + l31) * 16;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int kc = 0; kc < 2; ++kc)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            wf[nt][pl][kc] = *reinterpret_cast<const bf16x8t*>(
+                                wb + ((size_t)(((2 * h + kc) * 3 + pl) * 2) * C + 32 * nt) * 16);
+                __builtin_amdgcn_sched_barrier(0);
+            }
             f32x16 oT = zero16();
 #pragma unroll
             for (int t = HA; t < NKT; ++t) pv_tile(t, oT);
@@ -866,22 +978,13 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                     for (int i = 0; i < 8; ++i) orr[i] = oT[8 * kc + i];
                     split3_oct(orr, op[0][kc], op[1][kc], op[2][kc]);
                 }
-                const unsigned char* wb = reinterpret_cast<const unsigned char*>(wout_sp) + ((size_t)half * C + l31) * 16;
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    bf16x8t wf[3][2];
-#pragma unroll
-                    for (int kc = 0; kc < 2; ++kc)
-#pragma unroll
-                        for (int pl = 0; pl < 3; ++pl)
-                            wf[pl][kc] = *reinterpret_cast<const bf16x8t*>(
-                                wb + ((size_t)(((2 * h + kc) * 3 + pl) * 2) * C + 32 * nt) * 16);
+                for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
                     for (int kc = 0; kc < 2; ++kc)
 #pragma unroll
                         for (int u = 0; u < 6; ++u)
-                            outT[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[PA6[u]][kc], op[PB6[u]][kc], outT[nt], 0, 0, 0);
-                }
+                            outT[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt][PA6[u]][kc], op[PB6[u]][kc], outT[nt], 0, 0, 0);
             } else {
                 // ---- out^T += Wout_h^T . O^T   (fp32 MFMA; A = to_out rows h*32 + d, columns n)
 #pragma unroll
@@ -940,7 +1043,9 @@ extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int 
     const size_t base2 = ((size_t)32 * nrt * (96 + KLD + DH) + band_floats) * sizeof(float);
     // WMODE 3 (also S and P.V on the bf16 pipe): X + K planes for Fext rows, V^T for 32 nrt keys
     const int delta = (((q0 - win) % 16) + 16) % 16;
-    const size_t base3 = (size_t)Fext * 576 + (size_t)nrt * 6144 + band_floats * sizeof(float);
+    const bool fac200 = Fext <= 200 && !(flags & 64) &&
+                        (size_t)200 * 576 + (size_t)nrt * 6144 + band_floats * sizeof(float) <= 163840;
+    const size_t base3 = (size_t)(fac200 ? 200 : Fext) * 576 + (size_t)nrt * 6144 + band_floats * sizeof(float);
     bool mode3 = wqkv_bf3 != nullptr && base3 <= 163840 && Fq + delta <= 256 && (force == 0 || force == 4);
     if (force == 4 && !mode3) return dawn_set_error_msg(-36, "dawn_temporal_layer_c64: WMODE 3 does not fit this shape");
     const bool split = !mode3 && wqkv_bf3 != nullptr && base2 <= 163840 && (force == 0 || force == 3);
@@ -957,12 +1062,17 @@ extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int 
     const unsigned short* wsp = (const unsigned short*)wout_bf3p;
     const bool hl = 32 + 2 * win <= 32 * nkt - 16;       // the upper 16 keys of the last key tile are never in a window
     const bool ob = wout_bf3p != nullptr && !(flags & 32);
+#define LAUNCH_TL3C(N, SC, HLV, OBV, FACV)                                                                     \
+    do {                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV, FACV>,          \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        hipLaunchKernelGGL((temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV, FACV>), dim3(HW), dim3(512), lds,  \
+                           s, x, Fext, HW, q0, Fq, win, ws, wout, wsp, rot_cos, rot_sin, band, eps, out, nrt,  \
+                           delta);                                                                             \
+    } while (0)
 #define LAUNCH_TL3B(N, SC, HLV, OBV)                                                                           \
     do {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV>,                \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-        hipLaunchKernelGGL((temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV>), dim3(HW), dim3(512), lds, s, x,  \
-                           Fext, HW, q0, Fq, win, ws, wout, wsp, rot_cos, rot_sin, band, eps, out, nrt, delta); \
+        if (fac200) LAUNCH_TL3C(N, SC, HLV, OBV, 200); else LAUNCH_TL3C(N, SC, HLV, OBV, 0);                   \
     } while (0)
 #define LAUNCH_TL3(N, SC)                                                                                      \
     do {                                                                                                       \
@@ -1001,6 +1111,7 @@ extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int 
 #undef LAUNCH_TL
 #undef LAUNCH_TL3
 #undef LAUNCH_TL3B
+#undef LAUNCH_TL3C
     DAWN_LAUNCH_CHECK();
     return 0;
 }

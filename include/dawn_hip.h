@@ -141,7 +141,7 @@ int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, in
  * does), m + 1 forces WMODE m: 0 fp32 MFMA with weights from L2, 1 fp32 MFMA with per-head weight slices in LDS, 2 Q/K/V
  * projections on the bf16 pipe (exact 3-way operand split), 3 additionally S = K.Q^T and O = V^T.P^T on the bf16 pipe
  * (K / V split once per head into bf16 planes in LDS, Q / P split from the accumulators; fits up to Fext ~ 200 rows:
- * the benchmark clip); flags & 16 adds explicit MFMA/VALU interleave hints to WMODE 3 (measured: no gain); flags & 32 keeps
+ * the benchmark clip); flags & 16 adds explicit sched_group_barrier MFMA/VALU interleave hints to WMODE 3 (measured: within noise, 1550 vs 1513 us); flags & 32 keeps
  * the out-projection of WMODE 3 on the fp32 MFMA even when wout_bf3p is given.  wout_bf3p (optional, WMODE 3): the exact
  * 3-way bf16 split of to_out with the rows of every head permuted to the accumulator order of O^T, [256/16][3][2][64][8]
  * (pack.pack_bf3_temporal_out).  All families compute the same function to fp32 round-off. */

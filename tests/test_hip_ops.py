@@ -441,7 +441,7 @@ def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
     check(f"temporal_layer_c64_split/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 3e-5)
     # every kernel family explicitly (flags: m + 1 forces WMODE m; 16 = WMODE 3 without the interleave hints)
     try:
-        for flags, name in ((1, "wmode0"), (2, "wmode1"), (3, "wmode2"), (4, "wmode3"), (4 | 16, "wmode3_sched"),
+        for flags, name in ((1, "wmode0"), (2, "wmode1"), (3, "wmode2"), (4, "wmode3"), (4 | 16, "wmode3_hints"),
                             (4 | 32, "wmode3_out_fp32")):
             if flags & 7 == 4 and (Fext * 576 + ((Fext + 31) // 32) * 6144 + 8 * (32 * ((32 + 2 * win + 31) // 32) + 32) * 4 > 163840
                                    or Fq + (q0 - win) % 16 > 256):

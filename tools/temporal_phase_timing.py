@@ -27,8 +27,8 @@ ops.L.dawn_temporal_set_debug.argtypes = [ctypes.c_void_p]
 assert ops.L.dawn_temporal_set_debug(dbg.data_ptr()) == 0
 names = ["start", "phase0+setup", "h0 start", "h0 KV proj", "h0 barrier", "h0 Q proj", "h0 S(A)", "h0 S(B)+smA", "h0 PV(A)+smB", "h0 PV(B)", "h0 out",
          "h1 start", "h1 KV proj", "h1 barrier", "h1 Q proj", "h1 S(A)", "h1 S(B)+smA", "h1 PV(A)+smB", "h1 PV(B)", "h1 out", "end (6 more heads + store)"]
-for label, s, flags in (("fp32 (WMODE 1)", None, 0), ("split projections (WMODE 2)", wqkv_s, 3),
-                        ("all-bf16-pipe (WMODE 3)", wqkv_s, 4), ("WMODE 3, out-projection on fp32 MFMA", wqkv_s, 4 | 32)):
+for label, s, flags in (
+                        ("all-bf16-pipe (WMODE 3, runtime row stride)", wqkv_s, 4 | 64), ("WMODE 3 with interleave hints", wqkv_s, 4 | 64 | 16)):
     ops.temporal_flags = flags
     for _ in range(2):
         dbg.zero_()
