@@ -1,0 +1,895 @@
+// C-side evaluator of the denoising path: dawn_ctx_* / dawn_clip_* / dawn_unet_forward /
+// dawn_sampler_run.  Host-only C++ (no kernels here): the launch sequence of ONE `Unet3D.forward` evaluation
+// (MT:892-956) and of the DDIM loop around it (MT:1156-1208), issued through the per-op entry points of this library,
+// so that a non-Python host (C, C++, Go/cgo, Java/JNI ...) can run the denoiser with nothing but this .so.
+//
+// It is the same orchestration as dawn-pytorch_amd/unet_forward.py + sampler.py (kept for the T-sharded path and for
+// the per-op tests) and launches the same kernels with the same arguments: the GPU test
+// tests/test_hip_ctx.py::test_ctx_forward_equals_python_path requires bit-identical outputs.
+//
+// Conventions (include/dawn_hip.h): no allocation on the device -- the caller provides the per-clip table memory
+// (dawn_clip_bytes) and the activation workspace (dawn_workspace_bytes); every launch goes to the caller's stream plus
+// one internal side stream that is forked / joined with events (cross-attention || conv1 of each ResBlock); tuning
+// state lives in the ctx, never in globals; int return codes + dawn_last_error().
+#include "dawn_common.h"
+#include "../../include/dawn_hip.h"
+
+#include <math.h>
+#include <string.h>
+#include <iterator>
+#include <map>
+#include <string>
+#include <vector>
+
+extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1);
+
+namespace {
+
+#define CK(expr)                              \
+    do {                                      \
+        const int rc__ = (expr);              \
+        if (rc__ != 0) return rc__;           \
+    } while (0)
+#define HCK(expr)                                                     \
+    do {                                                              \
+        const hipError_t e__ = (expr);                                \
+        if (e__ != hipSuccess) return dawn_set_error(e__, __FILE__, __LINE__); \
+    } while (0)
+
+struct RB {                       // pack.PackedResBlock
+    int Cin = 0, Co = 0;
+    bool conditioned = false;
+    int cond_index = -1, film_off = 0;
+    const float *w1 = nullptr, *b1 = nullptr, *g1 = nullptr, *be1 = nullptr, *w2 = nullptr, *b2 = nullptr, *g2 = nullptr,
+                *be2 = nullptr, *wr = nullptr, *br = nullptr;
+    const void *w1s = nullptr, *w2s = nullptr, *wrs = nullptr, *wqs = nullptr;
+    const float *wq = nullptr, *q_scale = nullptr, *g3 = nullptr;
+    const float* wo[3] = {nullptr, nullptr, nullptr};
+    const void* wos[3] = {nullptr, nullptr, nullptr};
+    const float *mlp_w[3] = {}, *mlp_b[3] = {}, *kv_w[3] = {}, *k_scale[3] = {}, *null_kv[3] = {};
+};
+struct AT {                       // pack.PackedAttn
+    int C = 0;
+    const float *wqkv = nullptr, *wout = nullptr, *bout = nullptr;
+    const void *wqkv_s = nullptr, *wout_s = nullptr, *wout_sp = nullptr;
+};
+struct Level {
+    RB rb1, rb2;
+    AT sla, tattn;
+    const float *rs_w = nullptr, *rs_b = nullptr;   // down (4x4/s2) or up (transposed 4x4) conv
+};
+
+// Host-side sub-allocator over the caller's workspace.  First fit with coalescing; `dry` = measuring pass (no base
+// pointer, nothing is launched): the sequence of alloc/free calls of an evaluation is a pure function of the shapes, so
+// the high-water mark of the dry pass IS the workspace requirement of the real one.
+struct Arena {
+    char* base = nullptr;
+    size_t cap = 0, high = 0;
+    bool dry = false, defer = false;
+    std::map<size_t, size_t> freeb;          // offset -> size
+    std::map<size_t, size_t> used;           // offset -> size
+    std::vector<size_t> deferred;
+    void reset(void* b, size_t c, bool d) {
+        base = (char*)b; cap = c; dry = d; high = 0; defer = false;
+        freeb.clear(); used.clear(); deferred.clear();
+        freeb[0] = d ? ((size_t)1 << 62) : c;
+    }
+    void* alloc(size_t bytes) {
+        bytes = (bytes + 255) & ~(size_t)255;
+        if (bytes == 0) bytes = 256;
+        for (auto it = freeb.begin(); it != freeb.end(); ++it) {
+            if (it->second >= bytes) {
+                const size_t off = it->first, sz = it->second;
+                freeb.erase(it);
+                if (sz > bytes) freeb[off + bytes] = sz - bytes;
+                used[off] = bytes;
+                if (off + bytes > high) high = off + bytes;
+                return dry ? (void*)(uintptr_t)(off + 4096) : (void*)(base + off);   // dry: fake non-null addresses
+            }
+        }
+        return nullptr;
+    }
+    void release_off(size_t off) {
+        auto u = used.find(off);
+        if (u == used.end()) return;
+        size_t sz = u->second;
+        used.erase(u);
+        auto nx = freeb.lower_bound(off);
+        if (nx != freeb.end() && off + sz == nx->first) { sz += nx->second; nx = freeb.erase(nx); }
+        if (nx != freeb.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == off) { pv->second += sz; return; }
+        }
+        freeb[off] = sz;
+    }
+    void free(const void* p) {
+        if (!p) return;
+        const size_t off = dry ? (size_t)((uintptr_t)p - 4096) : (size_t)((const char*)p - base);
+        if (defer) deferred.push_back(off);       // buffers released inside a side-stream region: reusable after the join
+        else release_off(off);
+    }
+    void flush_deferred() {
+        for (size_t o : deferred) release_off(o);
+        deferred.clear();
+    }
+};
+
+struct ProfEntry { hipEvent_t e0, e1; double flops, bytes; int kind; };
+
+}  // namespace
+
+struct dawn_ctx {
+    dawn_unet_cfg cfg;
+    int dims[10];
+    std::map<std::string, const void*> W;
+    const float *w3, *wfea, *b_init, *sin_freqs, *t_w1, *t_b1, *t_w2, *t_b2, *film_w, *film_b, *wg, *bg, *wo, *bo;
+    AT init_tattn;
+    std::vector<Level> downs, ups;
+    RB mid1, mid2, head_g, head_o;
+    AT mid_sattn, mid_tattn;
+    int n_cond = 0, film_total = 0, time_dim = 0;
+    float rel_emb[32 * 8];
+    float rot_freqs[16];
+    const float* rot_freqs_dev = nullptr;
+    std::vector<float> host_tab;            // staging of the per-clip band table (kept alive for the async copy)
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    int conv_policy = 0, temporal_flags = 0, overlap = 1;
+    Arena arena;
+    // profiling of conv launches (bench.py roofline): optional
+    bool prof_on = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+const void* getw(const dawn_ctx* c, const std::string& k, bool required, bool* ok) {
+    auto it = c->W.find(k);
+    if (it == c->W.end() || it->second == nullptr) {
+        if (required) {
+            *ok = false;
+            std::string m = "dawn_ctx_create: missing packed weight '" + k + "'";
+            dawn_set_error_msg(-200, m.c_str());
+        }
+        return nullptr;
+    }
+    return it->second;
+}
+
+bool load_rb(dawn_ctx* c, const std::string& p, int Cin, int Co, bool conditioned, RB& rb, int& film_off) {
+    bool ok = true;
+    auto F = [&](const char* n, bool req = true) { return (const float*)getw(c, p + n, req, &ok); };
+    auto V = [&](const char* n) { return getw(c, p + n, false, &ok); };
+    rb.Cin = Cin; rb.Co = Co; rb.conditioned = conditioned;
+    rb.w1 = F("w1"); rb.b1 = F("b1"); rb.g1 = F("g1"); rb.be1 = F("be1");
+    rb.w2 = F("w2"); rb.b2 = F("b2"); rb.g2 = F("g2"); rb.be2 = F("be2");
+    rb.w1s = V("w1s"); rb.w2s = V("w2s");
+    if (Cin != Co) { rb.wr = F("wr"); rb.br = F("br"); rb.wrs = V("wrs"); }
+    if (conditioned) {
+        rb.cond_index = c->n_cond++;
+        rb.film_off = film_off;
+        film_off += 2 * Co;
+        rb.wq = F("wq"); rb.wqs = V("wqs"); rb.q_scale = F("q_scale"); rb.g3 = F("g3");
+        for (int b = 0; b < 3; ++b) {
+            const std::string s = std::to_string(b);
+            rb.wo[b] = F(("wo." + s).c_str());
+            rb.wos[b] = V(("wos." + s).c_str());
+            rb.mlp_w[b] = F(("mlp_w." + s).c_str());
+            rb.mlp_b[b] = F(("mlp_b." + s).c_str());
+            rb.kv_w[b] = F(("kv_w." + s).c_str());
+            rb.k_scale[b] = F(("k_scale." + s).c_str());
+            rb.null_kv[b] = F(("null_kv." + s).c_str());
+        }
+    }
+    return ok;
+}
+
+bool load_at(dawn_ctx* c, const std::string& p, int C, bool bias, AT& a) {
+    bool ok = true;
+    a.C = C;
+    a.wqkv = (const float*)getw(c, p + "wqkv", true, &ok);
+    a.wout = (const float*)getw(c, p + "wout", true, &ok);
+    if (bias) a.bout = (const float*)getw(c, p + "bout", true, &ok);
+    a.wqkv_s = getw(c, p + "wqkv_s", false, &ok);
+    a.wout_s = getw(c, p + "wout_s", false, &ok);
+    a.wout_sp = getw(c, p + "wout_sp", false, &ok);
+    return ok;
+}
+
+// RelativePositionBias._relative_position_bucket (MT:92-109), rel = k_pos - q_pos, num_buckets 32, max_distance 32,
+// with the reference's fp32 log arithmetic
+int rel_pos_bucket(int rel) {
+    int n = -rel;
+    const int half = 16, max_exact = 8;
+    int ret = n < 0 ? half : 0;
+    if (n < 0) n = -n;
+    if (n < max_exact) return ret + n;
+    const float v = logf((float)n / (float)max_exact) / (float)log(32.0 / 8.0) * (float)(half - max_exact);
+    int large = max_exact + (int)v;
+    if (large > half - 1) large = half - 1;
+    return ret + large;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// evaluation state: the ops of ops.py on raw pointers
+
+struct T2 {                       // (rows, C) activation, contiguous
+    float* p = nullptr;
+    long rows = 0;
+    int C = 0;
+};
+
+struct ClipLayout {
+    size_t fea_pre, rcos, rsin, band, total;
+    std::vector<size_t> kvtab, nulltab, xtab;     // per conditioned block (xtab = SIZE_MAX when absent)
+};
+
+inline size_t al256(size_t b) { return (b + 255) & ~(size_t)255; }
+
+bool can_fuse_xattn(int Cin, int Co, int C0, int HW) { return Co == 64 && (Cin == 64 || Cin == 128) && C0 % 8 == 0 && HW % 32 == 0; }
+bool can_fuse_xattn_out(int Co, int HW) { return Co % 32 == 0 && Co >= 32 && Co <= 512 && HW % 4 == 0; }
+bool can_fuse_temporal(int C, int Fext, int Fq, int win) { return C == 64 && Fext <= 288 && Fq <= 256 && win <= 48; }
+
+void cond_blocks(dawn_ctx* c, std::vector<RB*>& out) {
+    for (auto& l : c->downs) { out.push_back(&l.rb1); out.push_back(&l.rb2); }
+    out.push_back(&c->mid1); out.push_back(&c->mid2);
+    for (auto& l : c->ups) { out.push_back(&l.rb1); out.push_back(&l.rb2); }
+}
+
+ClipLayout clip_layout(dawn_ctx* c, int F, int h, int w) {
+    ClipLayout L;
+    size_t off = 0;
+    auto take = [&](size_t floats) { const size_t o = off; off += al256(floats * 4); return o; };
+    L.fea_pre = take((size_t)h * w * c->cfg.dim);
+    const int n = F + 2 * c->cfg.win;
+    L.rcos = take((size_t)n * 16);
+    L.rsin = take((size_t)n * 16);
+    L.band = take((size_t)(2 * c->cfg.win + 1) * 8);
+    std::vector<RB*> blocks;
+    cond_blocks(c, blocks);
+    for (RB* rb : blocks) {
+        L.kvtab.push_back(take((size_t)F * 3 * 128));
+        L.nulltab.push_back(take(3 * 16));
+        if (can_fuse_xattn(rb->Cin, rb->Co, 8, 32) || can_fuse_xattn_out(rb->Co, 4)) L.xtab.push_back(take((size_t)F * 3 * (64 + 9 * rb->Co)));
+        else L.xtab.push_back((size_t)-1);
+    }
+    L.total = off;
+    return L;
+}
+
+struct Eval {
+    dawn_ctx* c;
+    hipStream_t cur, main;
+    Arena& A;
+    bool dry;
+    int F, H0, W0;
+    const char* clip;
+    ClipLayout L;
+    int rc = 0;
+
+    Eval(dawn_ctx* ctx, hipStream_t s, int F_, int h, int w, const void* clip_mem)
+        : c(ctx), cur(s), main(s), A(ctx->arena), dry(ctx->arena.dry), F(F_), H0(h), W0(w), clip((const char*)clip_mem) {
+        L = clip_layout(ctx, F_, h, w);
+    }
+    const float* clipf(size_t off) const { return (const float*)(clip + off); }
+
+    float* falloc(size_t floats) {
+        float* p = (float*)A.alloc(floats * 4);
+        if (!p && rc == 0) rc = dawn_set_error_msg(-201, "dawn_ctx: activation workspace too small (dawn_workspace_bytes)");
+        return p;
+    }
+    T2 t2(long rows, int C) { T2 t; t.rows = rows; t.C = C; t.p = falloc((size_t)rows * C); return t; }
+    void rel(T2& t) { A.free(t.p); t.p = nullptr; }
+#define LAUNCH(call)                                   \
+    do {                                               \
+        if (!dry && rc == 0) { const int r__ = (call); if (r__ != 0) rc = r__; } \
+    } while (0)
+
+    // ---- conv / linear on MFMA (ops.conv_gemm)
+    struct ConvArgs {
+        const float* in0 = nullptr; int C0 = 0; int ld0 = 0;
+        const float* in1 = nullptr; int C1 = 0; int ld1 = 0;
+        const float* w = nullptr; const void* w_bf3 = nullptr; const float* bias = nullptr; int N = 0;
+        int Fr = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0, KH = 1, KW = 1, stride = 1, pad = 0, mode = 0;
+        const float *row_mean = nullptr, *row_rstd = nullptr;
+        const float* res = nullptr; int ld_res = 0;
+        const float *tr = nullptr, *tr_a = nullptr, *tr_b = nullptr; int ld_tr = 0;
+        float* out = nullptr; int ld_out = 0;
+        double* gn_part = nullptr; int* gn_rows = nullptr;
+    };
+    void conv(const ConvArgs& a) {
+        dawn_conv_desc d;
+        memset(&d, 0, sizeof(d));
+        d.in0 = a.in0; d.in1 = a.in1; d.C0 = a.C0; d.C1 = a.C1; d.ld0 = a.ld0; d.ld1 = a.ld1;
+        d.F = a.Fr; d.Hi = a.Hi; d.Wi = a.Wi; d.Ho = a.Ho ? a.Ho : a.Hi; d.Wo = a.Wo ? a.Wo : a.Wi;
+        d.KH = a.KH; d.KW = a.KW; d.stride = a.stride; d.pad = a.pad; d.mode = a.mode;
+        d.w = a.w; d.bias = a.bias; d.N = a.N; d.row_mean = a.row_mean; d.row_rstd = a.row_rstd;
+        d.res = a.res; d.ld_res = a.ld_res; d.tr = a.tr; d.ld_tr = a.ld_tr; d.tr_a = a.tr_a; d.tr_b = a.tr_b;
+        d.out = a.out; d.ld_out = a.ld_out; d.gn_part = a.gn_part; d.w_bf3 = a.w_bf3; d.gn_rows = a.gn_rows;
+        d.policy = c->conv_policy;
+        if (dry || rc) { if (a.gn_rows) *a.gn_rows = 1; return; }
+        const bool prof = c->prof_on;
+        ProfEntry pe;
+        if (prof) {
+            auto ev = [&]() { hipEvent_t e; if (c->ev_pool.empty()) { (void)hipEventCreate(&e); } else { e = c->ev_pool.back(); c->ev_pool.pop_back(); } return e; };
+            pe.e0 = ev(); pe.e1 = ev();
+            const long rows_out = (long)d.F * d.Ho * d.Wo, rows_gemm = d.mode == 0 ? rows_out : (long)d.F * d.Hi * d.Wi * 4;
+            const int K = d.KH * d.KW * (d.C0 + d.C1);
+            pe.flops = 2.0 * rows_gemm * d.N * K;
+            pe.bytes = 4.0 * ((double)d.F * d.Hi * d.Wi * (d.C0 + d.C1) + (double)rows_out * d.N + (double)K * d.N * (d.mode ? 4 : 1));
+            const bool split3 = d.w_bf3 && d.mode == 0 && d.stride == 1 && d.KH == 3 && d.KW == 3;
+            const bool split1 = d.w_bf3 && d.mode == 0 && d.stride == 1 && d.KH == 1 && d.KW == 1 && !d.gn_part &&
+                                dawn_gemm1x1_split_ok(rows_out, d.N, d.C0, d.C1);
+            pe.kind = split3 ? 0 : (split1 ? 1 : 2);
+            (void)hipEventRecord(pe.e0, cur);
+        }
+        const int r = dawn_conv_gemm(&d, cur);
+        if (r != 0) rc = r;
+        if (prof) { (void)hipEventRecord(pe.e1, cur); c->prof.push_back(pe); }
+    }
+    double* gn_part_alloc(long rows_out, int N) { return (double*)falloc((size_t)dawn_conv_gemm_nblocks(rows_out, N) * 16 * 2); }
+    // per-channel (a, b): silu(x*a+b) == SiLU(FiLM(GroupNorm8(x)))   (ops.gn_coeffs, single-GPU form)
+    void gn_coeffs(const double* part, int nblk, long total_rows, int Cc, const float* gamma, const float* beta, const float* fs,
+                   const float* fsh, float* a, float* b) {
+        LAUNCH(dawn_gn_reduce_finalize(part, nblk, (double)total_rows * (Cc / 8), gamma, beta, fs, fsh, Cc, 1e-5f, a, b, cur));
+    }
+    T2 gn_apply_res(const T2& x, const float* a, const float* b, const float* res) {
+        T2 o = t2(x.rows, x.C);
+        LAUNCH(dawn_gn_apply_res(x.p, a, b, res, o.p, x.rows, x.C, cur));
+        return o;
+    }
+    // LayerNorm over the channels of [x | x2] (gain folded into w) + projection (unet_forward._ln_gemm)
+    T2 ln_gemm(const T2& x, const T2* x2, const float* w, int N, const void* w_bf3, int Fr, int Hi, int Wi) {
+        const int C1 = x2 ? x2->C : 0;
+        T2 o = t2(x.rows, N);
+        ConvArgs a;
+        a.w = w; a.w_bf3 = w_bf3; a.N = N; a.Fr = Fr; a.Hi = Hi; a.Wi = Wi; a.out = o.p; a.ld_out = N;
+        if (w_bf3 && dawn_gemm1x1_split_ok(x.rows, N, x.C, C1)) {
+            float* mean = falloc(x.rows);
+            float* rstd = falloc(x.rows);
+            LAUNCH(dawn_ln_rowstats(x.p, x.C, x.C, x2 ? x2->p : nullptr, C1, C1, x.rows, 1e-5f, mean, rstd, cur));
+            a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.in1 = x2 ? x2->p : nullptr; a.C1 = C1; a.ld1 = C1;
+            a.row_mean = mean; a.row_rstd = rstd;
+            conv(a);
+            A.free(mean); A.free(rstd);
+        } else {
+            T2 xn = t2(x.rows, x.C + C1);
+            LAUNCH(dawn_ln_rows(x.p, x.C, x.C, x2 ? x2->p : nullptr, C1, C1, x.rows, 1e-5f, xn.p, cur));
+            a.in0 = xn.p; a.C0 = xn.C; a.ld0 = xn.C;
+            conv(a);
+            rel(xn);
+        }
+        return o;
+    }
+
+    void fork() {
+        if (!c->overlap) return;
+        A.defer = true;
+        if (dry || rc) { cur = c->side; return; }
+        (void)hipEventRecord(c->ev_fork, main);
+        (void)hipStreamWaitEvent(c->side, c->ev_fork, 0);
+        cur = c->side;
+    }
+    void to_main() {                    // side-stream work enqueued; continue on the main stream (join later)
+        if (!c->overlap) return;
+        if (!(dry || rc)) (void)hipEventRecord(c->ev_join, c->side);
+        cur = main;
+        A.defer = false;                // (frees made on the main stream inside the region are main-ordered: immediate)
+    }
+    void join() {
+        if (!c->overlap) return;
+        if (!(dry || rc)) (void)hipStreamWaitEvent(main, c->ev_join, 0);
+        A.flush_deferred();
+    }
+
+    // ---- ResnetBlock_ca_mul (unet_forward._resblock)
+    T2 resblock(const RB& rb, const T2& x, const T2* x2, int Fr, int H, int W, const float* film_all) {
+        const int Co = rb.Co, HW = H * W;
+        const long rows = (long)Fr * HW, total_rows = rows;
+        T2 hcond;
+        const float *fs = nullptr, *fsh = nullptr;
+        if (rb.conditioned) {
+            fs = film_all + rb.film_off;
+            fsh = film_all + rb.film_off + Co;
+            // cross-attention chain on the side stream
+            fork();
+            const size_t xt = L.xtab[rb.cond_index];
+            if (can_fuse_xattn(rb.Cin, Co, x.C, HW) && xt != (size_t)-1) {
+                hcond = t2(rows, 64);
+                LAUNCH(dawn_xattn_layer_c64(x.p, x.C, x.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x2 ? x2->C : 0, rows, HW, rb.wq, rb.g3,
+                                            clipf(xt), 1e-5f, hcond.p, cur));
+            } else {
+                T2 q = ln_gemm(x, x2, rb.wq, 192, rb.wqs, Fr, H, W);
+                if (can_fuse_xattn_out(Co, HW) && xt != (size_t)-1) {
+                    hcond = t2(rows, Co);
+                    LAUNCH(dawn_xattn_sigma_out(q.p, rows, HW, clipf(xt), rb.g3, Co, 1e-5f, hcond.p, cur));
+                } else {
+                    LAUNCH(dawn_xattn_core(q.p, q.p, rows, HW, clipf(L.kvtab[rb.cond_index]), clipf(L.nulltab[rb.cond_index]), rb.q_scale, cur));
+                    T2 y3 = t2(rows, 3 * Co);
+                    for (int b = 0; b < 3; ++b) {
+                        ConvArgs a;
+                        a.in0 = q.p + 64 * b; a.C0 = 64; a.ld0 = 192; a.w = rb.wo[b]; a.w_bf3 = rb.wos[b]; a.N = Co;
+                        a.Fr = Fr; a.Hi = H; a.Wi = W; a.out = y3.p + (size_t)b * Co; a.ld_out = 3 * Co;
+                        conv(a);
+                    }
+                    hcond = t2(rows, Co);
+                    LAUNCH(dawn_xattn_ln_sum(y3.p, rb.g3, hcond.p, rows, Co, 1e-5f, cur));
+                    rel(y3);
+                }
+                rel(q);
+            }
+            to_main();
+        }
+        // conv1 + GroupNorm statistics from its epilogue (main stream)
+        double* part = gn_part_alloc(rows, Co);
+        int nblk = 0;
+        T2 c1 = t2(rows, Co);
+        {
+            ConvArgs a;
+            a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.in1 = x2 ? x2->p : nullptr; a.C1 = x2 ? x2->C : 0; a.ld1 = a.C1;
+            a.w = rb.w1; a.w_bf3 = rb.w1s; a.bias = rb.b1; a.N = Co; a.Fr = Fr; a.Hi = H; a.Wi = W; a.KH = 3; a.KW = 3; a.pad = 1;
+            a.out = c1.p; a.ld_out = Co; a.gn_part = part; a.gn_rows = &nblk;
+            conv(a);
+        }
+        float* ab1 = falloc(2 * (size_t)Co);
+        gn_coeffs(part, nblk, total_rows, Co, rb.g1, rb.be1, fs, fsh, ab1, ab1 + Co);
+        if (rb.conditioned) join();
+        T2 h1 = gn_apply_res(c1, ab1, ab1 + Co, hcond.p);
+        rel(c1); A.free(ab1); A.free(part);
+        if (hcond.p) rel(hcond);
+        double* part2 = gn_part_alloc(rows, Co);
+        int nblk2 = 0;
+        T2 c2 = t2(rows, Co);
+        {
+            ConvArgs a;
+            a.in0 = h1.p; a.C0 = Co; a.ld0 = Co; a.w = rb.w2; a.w_bf3 = rb.w2s; a.bias = rb.b2; a.N = Co;
+            a.Fr = Fr; a.Hi = H; a.Wi = W; a.KH = 3; a.KW = 3; a.pad = 1; a.out = c2.p; a.ld_out = Co; a.gn_part = part2; a.gn_rows = &nblk2;
+            conv(a);
+        }
+        rel(h1);
+        float* ab2 = falloc(2 * (size_t)Co);
+        gn_coeffs(part2, nblk2, total_rows, Co, rb.g2, rb.be2, nullptr, nullptr, ab2, ab2 + Co);
+        T2 out;
+        if (rb.wr) {
+            out = t2(rows, Co);
+            ConvArgs a;
+            a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.in1 = x2 ? x2->p : nullptr; a.C1 = x2 ? x2->C : 0; a.ld1 = a.C1;
+            a.w = rb.wr; a.w_bf3 = rb.wrs; a.bias = rb.br; a.N = Co; a.Fr = Fr; a.Hi = H; a.Wi = W;
+            a.tr = c2.p; a.ld_tr = Co; a.tr_a = ab2; a.tr_b = ab2 + Co; a.out = out.p; a.ld_out = Co;
+            conv(a);
+        } else {
+            out = gn_apply_res(c2, ab2, ab2 + Co, x.p);
+        }
+        rel(c2); A.free(ab2); A.free(part2);
+        return out;
+    }
+
+    // ---- temporal attention layer (unet_forward._temporal, single GPU: no halo)
+    T2 temporal(const AT& a, const T2& x, int Fr, int H, int W) {
+        const int HW = H * W, win = c->cfg.win;
+        T2 o;
+        if (can_fuse_temporal(a.C, Fr, Fr, win)) {
+            o = t2(x.rows, 64);
+            LAUNCH(dawn_temporal_layer_c64_ex(x.p, Fr, HW, 0, Fr, win, a.wqkv, a.wqkv_s, a.wout, a.wout_sp, clipf(L.rcos), clipf(L.rsin),
+                                              clipf(L.band), 1e-5f, o.p, c->temporal_flags, cur));
+            return o;
+        }
+        T2 qkv = ln_gemm(x, nullptr, a.wqkv, 768, a.wqkv_s, Fr, H, W);
+        T2 at = t2(x.rows, 256);
+        LAUNCH(dawn_temporal_attn(qkv.p, Fr, HW, 0, Fr, win, clipf(L.rcos), clipf(L.rsin), clipf(L.band), at.p, cur));
+        rel(qkv);
+        o = t2(x.rows, a.C);
+        ConvArgs g;
+        g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.N = a.C; g.Fr = Fr; g.Hi = H; g.Wi = W;
+        g.res = x.p; g.ld_res = a.C; g.out = o.p; g.ld_out = a.C;
+        conv(g);
+        rel(at);
+        return o;
+    }
+    T2 spatial_linear(const AT& a, const T2& x, int Fr, int H, int W) {
+        const int HW = H * W;
+        T2 o;
+        if (a.C == 64) {
+            float* ws = falloc((size_t)Fr * 8 * 8 * 64 * 4);
+            o = t2(x.rows, 64);
+            LAUNCH(dawn_sla_layer_c64(x.p, Fr, HW, a.wqkv, a.wqkv_s, a.wout, a.bout, 1e-5f, ws, o.p, cur));
+            A.free(ws);
+            return o;
+        }
+        T2 qkv = ln_gemm(x, nullptr, a.wqkv, 768, a.wqkv_s, Fr, H, W);
+        float* ctx = falloc((size_t)Fr * 8 * 32 * 32);
+        T2 at = t2(x.rows, 256);
+        LAUNCH(dawn_sla_context(qkv.p, Fr, HW, ctx, cur));
+        LAUNCH(dawn_sla_apply(qkv.p, ctx, Fr, HW, at.p, cur));
+        A.free(ctx);
+        rel(qkv);
+        o = t2(x.rows, a.C);
+        ConvArgs g;
+        g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.bias = a.bout; g.N = a.C; g.Fr = Fr; g.Hi = H; g.Wi = W;
+        g.res = x.p; g.ld_res = a.C; g.out = o.p; g.ld_out = a.C;
+        conv(g);
+        rel(at);
+        return o;
+    }
+    T2 mid_spatial(const AT& a, const T2& x, int Fr, int H, int W) {
+        T2 qkv = ln_gemm(x, nullptr, a.wqkv, 768, a.wqkv_s, Fr, H, W);
+        T2 at = t2(x.rows, 256);
+        LAUNCH(dawn_frame_attn(qkv.p, Fr, H * W, at.p, cur));
+        rel(qkv);
+        T2 o = t2(x.rows, a.C);
+        ConvArgs g;
+        g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.N = a.C; g.Fr = Fr; g.Hi = H; g.Wi = W;
+        g.res = x.p; g.ld_res = a.C; g.out = o.p; g.ld_out = a.C;
+        conv(g);
+        rel(at);
+        return o;
+    }
+
+    // ---- one evaluation: x3 (3,F,h,w) latent, t -> eps (3,F,h,w)   (unet_forward.unet_forward)
+    void forward(const float* x3, float t, float* eps_out) {
+        const int dim = c->cfg.dim;
+        // time_film: sinusoidal -> Linear -> GELU -> Linear -> [SiLU -> Linear] for every block in one GEMV
+        float* e0 = falloc(dim);
+        float* e1 = falloc(c->time_dim);
+        float* e2 = falloc(c->time_dim);
+        float* film = falloc(c->film_total);
+        LAUNCH(dawn_sinusoidal(t, dim, c->sin_freqs, e0, cur));
+        LAUNCH(dawn_linear(e0, 1, dim, dim, c->t_w1, c->t_b1, c->time_dim, 0, e1, c->time_dim, cur));
+        LAUNCH(dawn_linear(e1, 1, c->time_dim, c->time_dim, c->t_w2, c->t_b2, c->time_dim, 2, e2, c->time_dim, cur));
+        LAUNCH(dawn_linear(e2, 1, c->time_dim, c->time_dim, c->film_w, c->film_b, c->film_total, 1, film, c->film_total, cur));
+        A.free(e0); A.free(e1); A.free(e2);
+        int H = H0, W = W0;
+        T2 r = t2((long)F * H * W, dim);
+        LAUNCH(dawn_init_conv_x(x3, c->w3, clipf(L.fea_pre), F, H, W, dim, r.p, cur));
+        T2 x = temporal(c->init_tattn, r, F, H, W);
+        struct Skip { T2 t; int H, W; };
+        std::vector<Skip> skips;
+        for (size_t l = 0; l < c->downs.size(); ++l) {
+            Level& lv = c->downs[l];
+            T2 y = resblock(lv.rb1, x, nullptr, F, H, W, film); rel(x); x = y;
+            y = resblock(lv.rb2, x, nullptr, F, H, W, film); rel(x); x = y;
+            y = spatial_linear(lv.sla, x, F, H, W); rel(x); x = y;
+            y = temporal(lv.tattn, x, F, H, W); rel(x); x = y;
+            skips.push_back({x, H, W});
+            if (lv.rs_w) {
+                T2 dn = t2((long)F * (H / 2) * (W / 2), x.C);
+                ConvArgs a;
+                a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.w = lv.rs_w; a.bias = lv.rs_b; a.N = x.C; a.Fr = F; a.Hi = H; a.Wi = W;
+                a.Ho = H / 2; a.Wo = W / 2; a.KH = 4; a.KW = 4; a.stride = 2; a.pad = 1; a.out = dn.p; a.ld_out = x.C;
+                conv(a);
+                x = dn;                         // (the skip keeps the level's output alive)
+                H /= 2; W /= 2;
+            } else {
+                // last level: x continues to the mid block AND is the skip: the skip entry aliases it (freed at its pop)
+            }
+        }
+        const bool last_aliases = !c->downs.empty() && c->downs.back().rs_w == nullptr;
+        {
+            T2 y = resblock(c->mid1, x, nullptr, F, H, W, film);
+            if (!last_aliases) rel(x);
+            x = y;
+            y = mid_spatial(c->mid_sattn, x, F, H, W); rel(x); x = y;
+            y = temporal(c->mid_tattn, x, F, H, W); rel(x); x = y;
+            y = resblock(c->mid2, x, nullptr, F, H, W, film); rel(x); x = y;
+        }
+        for (size_t l = 0; l < c->ups.size(); ++l) {
+            Level& lv = c->ups[l];
+            Skip sk = skips.back();
+            skips.pop_back();
+            T2 y = resblock(lv.rb1, x, &sk.t, F, H, W, film);     // torch.cat((x, h.pop())) MT:948
+            rel(x); rel(sk.t); x = y;
+            y = resblock(lv.rb2, x, nullptr, F, H, W, film); rel(x); x = y;
+            y = spatial_linear(lv.sla, x, F, H, W); rel(x); x = y;
+            y = temporal(lv.tattn, x, F, H, W); rel(x); x = y;
+            if (lv.rs_w) {
+                T2 up = t2((long)F * (2 * H) * (2 * W), x.C);
+                ConvArgs a;
+                a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.w = lv.rs_w; a.bias = lv.rs_b; a.N = x.C; a.Fr = F; a.Hi = H; a.Wi = W;
+                a.Ho = 2 * H; a.Wo = 2 * W; a.KH = 2; a.KW = 2; a.mode = 1; a.out = up.p; a.ld_out = x.C;
+                conv(a);
+                rel(x); x = up;
+                H *= 2; W *= 2;
+            }
+        }
+        T2 hg = resblock(c->head_g, x, &r, F, H, W, film);            // torch.cat((x, r)) MT:955
+        T2 ho = resblock(c->head_o, x, &r, F, H, W, film);
+        rel(x); rel(r);
+        LAUNCH(dawn_head_out(hg.p, ho.p, c->wg, c->bg, c->wo, c->bo, (long)F * H * W, hg.C, eps_out, cur));
+        rel(hg); rel(ho);
+        A.free(film);
+    }
+};
+
+int build_levels(dawn_ctx* c) {
+    const dawn_unet_cfg& g = c->cfg;
+    int film_off = 0;
+    bool ok = true;
+    ok &= load_at(c, "init_tattn.", g.dim, false, c->init_tattn);
+    c->downs.resize(g.n_levels);
+    c->ups.resize(g.n_levels);
+    for (int l = 0; l < g.n_levels; ++l) {
+        const int din = c->dims[l], dout = c->dims[l + 1];
+        const std::string p = "downs." + std::to_string(l) + ".";
+        Level& lv = c->downs[l];
+        ok &= load_rb(c, p + "rb1.", din, dout, true, lv.rb1, film_off);
+        ok &= load_rb(c, p + "rb2.", dout, dout, true, lv.rb2, film_off);
+        ok &= load_at(c, p + "sla.", dout, true, lv.sla);
+        ok &= load_at(c, p + "tattn.", dout, false, lv.tattn);
+        if (l + 1 < g.n_levels) {
+            lv.rs_w = (const float*)getw(c, p + "down.w", true, &ok);
+            lv.rs_b = (const float*)getw(c, p + "down.b", true, &ok);
+        }
+    }
+    const int dm = c->dims[g.n_levels];
+    ok &= load_rb(c, "mid.rb1.", dm, dm, true, c->mid1, film_off);
+    ok &= load_at(c, "mid.sattn.", dm, false, c->mid_sattn);
+    ok &= load_at(c, "mid.tattn.", dm, false, c->mid_tattn);
+    ok &= load_rb(c, "mid.rb2.", dm, dm, true, c->mid2, film_off);
+    for (int l = 0; l < g.n_levels; ++l) {
+        const int li = g.n_levels - 1 - l;                 // reversed(in_out) (MT:826)
+        const int din = c->dims[li], dout = c->dims[li + 1];
+        const std::string p = "ups." + std::to_string(l) + ".";
+        Level& lv = c->ups[l];
+        ok &= load_rb(c, p + "rb1.", 2 * dout, din, true, lv.rb1, film_off);
+        ok &= load_rb(c, p + "rb2.", din, din, true, lv.rb2, film_off);
+        ok &= load_at(c, p + "sla.", din, true, lv.sla);
+        ok &= load_at(c, p + "tattn.", din, false, lv.tattn);
+        if (l + 1 < g.n_levels) {
+            lv.rs_w = (const float*)getw(c, p + "up.w", true, &ok);
+            lv.rs_b = (const float*)getw(c, p + "up.b", true, &ok);
+        }
+    }
+    int dummy = 0;
+    ok &= load_rb(c, "head_g.", 2 * g.dim, g.dim, false, c->head_g, dummy);
+    ok &= load_rb(c, "head_o.", 2 * g.dim, g.dim, false, c->head_o, dummy);
+    c->film_total = film_off;
+    if (!ok) return -200;
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dawn_rel_pos_bucket(int rel) { return rel_pos_bucket(rel); }
+
+extern "C" int dawn_ctx_create(const dawn_unet_cfg* cfg, const dawn_named_ptr* weights, int n_weights, dawn_ctx** out) {
+    if (!cfg || !weights || !out) return dawn_set_error_msg(-202, "dawn_ctx_create: null argument");
+    if (cfg->n_levels < 1 || cfg->n_levels > 8 || cfg->dim % 16 != 0 || cfg->fea_ch % 16 != 0 || cfg->win < 0 || cfg->win > 80)
+        return dawn_set_error_msg(-203, "dawn_ctx_create: unsupported configuration (dim / fea_ch multiples of 16, 1..8 levels, win <= 80)");
+    dawn_ctx* c = new dawn_ctx();
+    c->cfg = *cfg;
+    c->dims[0] = cfg->dim;
+    for (int l = 0; l < cfg->n_levels; ++l) c->dims[l + 1] = cfg->dim * cfg->dim_mults[l];
+    c->time_dim = 4 * cfg->dim;
+    for (int i = 0; i < n_weights; ++i)
+        if (weights[i].name) c->W[weights[i].name] = weights[i].ptr;
+    bool ok = true;
+    auto F = [&](const char* n) { return (const float*)getw(c, n, true, &ok); };
+    c->w3 = F("w3"); c->wfea = F("wfea"); c->b_init = F("b_init"); c->sin_freqs = F("sin_freqs");
+    c->t_w1 = F("t_w1"); c->t_b1 = F("t_b1"); c->t_w2 = F("t_w2"); c->t_b2 = F("t_b2");
+    c->film_w = F("film_w"); c->film_b = F("film_b");
+    c->wg = F("wg"); c->bg = F("bg"); c->wo = F("wo"); c->bo = F("bo");
+    const float* rel = F("rel_emb");
+    c->rot_freqs_dev = F("rot_freqs");
+    int rc = ok ? build_levels(c) : -200;
+    if (rc == 0) {
+        hipError_t e = hipMemcpy(c->rel_emb, rel, sizeof(c->rel_emb), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipMemcpy(c->rot_freqs, c->rot_freqs_dev, sizeof(c->rot_freqs), hipMemcpyDeviceToHost);
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) rc = dawn_set_error(e, __FILE__, __LINE__);
+    }
+    if (rc != 0) { delete c; return rc; }
+    *out = c;
+    return 0;
+}
+
+extern "C" void dawn_ctx_destroy(dawn_ctx* c) {
+    if (!c) return;
+    if (c->side) (void)hipStreamDestroy(c->side);
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_join) (void)hipEventDestroy(c->ev_join);
+    for (auto& p : c->prof) { (void)hipEventDestroy(p.e0); (void)hipEventDestroy(p.e1); }
+    for (auto e : c->ev_pool) (void)hipEventDestroy(e);
+    delete c;
+}
+
+extern "C" int dawn_ctx_set_option(dawn_ctx* c, int option, int value) {
+    if (!c) return dawn_set_error_msg(-202, "dawn_ctx_set_option: null ctx");
+    switch (option) {
+        case DAWN_OPT_CONV_POLICY: c->conv_policy = value; return 0;
+        case DAWN_OPT_TEMPORAL_FLAGS: c->temporal_flags = value; return 0;
+        case DAWN_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
+        case DAWN_OPT_PROFILE:
+            c->prof_on = value != 0;
+            return 0;
+        default: return dawn_set_error_msg(-204, "dawn_ctx_set_option: unknown option");
+    }
+}
+
+extern "C" size_t dawn_clip_bytes(dawn_ctx* c, int F, int h, int w) {
+    if (!c || F <= 0 || h <= 0 || w <= 0) return 0;
+    return clip_layout(c, F, h, w).total;
+}
+
+// scratch needed by dawn_clip_prepare (channels-last copy of fea272 + the condition-MLP temporaries)
+static size_t clip_scratch_bytes(dawn_ctx* c, int F, int h, int w) {
+    int maxCo = 0;
+    for (int l = 0; l <= c->cfg.n_levels; ++l) maxCo = c->dims[l] > maxCo ? c->dims[l] : maxCo;
+    return al256((size_t)h * w * c->cfg.fea_ch * 4) + al256((size_t)F * 2 * maxCo * 4) + al256((size_t)F * 128 * 4) + 4096;
+}
+
+extern "C" int dawn_clip_prepare(dawn_ctx* c, int F, int h, int w, const float* fea272, const float* cond, int ld_cond,
+                                 const float* rot_cos, const float* rot_sin, void* clip_mem, size_t clip_bytes,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !fea272 || !cond || !clip_mem) return dawn_set_error_msg(-202, "dawn_clip_prepare: null argument");
+    const ClipLayout L = clip_layout(c, F, h, w);
+    if (clip_bytes < L.total) return dawn_set_error_msg(-205, "dawn_clip_prepare: clip memory too small (dawn_clip_bytes)");
+    if (workspace_bytes < clip_scratch_bytes(c, F, h, w)) return dawn_set_error_msg(-201, "dawn_clip_prepare: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    char* cm = (char*)clip_mem;
+    char* ws = (char*)workspace;
+    const int win = c->cfg.win, n = F + 2 * win;
+    // 1. frame-invariant part of init_conv: 7x7 conv of the fea/bbox channels + bias, once per clip (MT:776-777 by linearity)
+    float* fea_cl = (float*)ws;
+    ws += al256((size_t)h * w * c->cfg.fea_ch * 4);
+    CK(dawn_chw_to_hwc(fea272, c->cfg.fea_ch, (long)h * w, fea_cl, s));
+    {
+        dawn_conv_desc d;
+        memset(&d, 0, sizeof(d));
+        d.in0 = fea_cl; d.C0 = c->cfg.fea_ch; d.ld0 = c->cfg.fea_ch; d.F = 1; d.Hi = h; d.Wi = w; d.Ho = h; d.Wo = w;
+        d.KH = 7; d.KW = 7; d.stride = 1; d.pad = 3; d.w = c->wfea; d.bias = c->b_init; d.N = c->cfg.dim;
+        d.out = (float*)(cm + L.fea_pre); d.ld_out = c->cfg.dim; d.policy = c->conv_policy;
+        CK(dawn_conv_gemm(&d, s));
+    }
+    // 2. rotary tables (rotary-embedding-torch 0.3.x: angle = pos * freqs) and the relative-position band
+    if (rot_cos && rot_sin) {
+        HCK(hipMemcpyAsync(cm + L.rcos, rot_cos, (size_t)n * 16 * 4, hipMemcpyDeviceToDevice, s));
+        HCK(hipMemcpyAsync(cm + L.rsin, rot_sin, (size_t)n * 16 * 4, hipMemcpyDeviceToDevice, s));
+    } else {
+        CK(dawn_rotary_tables(c->rot_freqs_dev, n, 0, (float*)(cm + L.rcos), (float*)(cm + L.rsin), s));
+    }
+    c->host_tab.resize((size_t)(2 * win + 1) * 8);
+    for (int dlt = -win; dlt <= win; ++dlt)
+        for (int hh = 0; hh < 8; ++hh) c->host_tab[(size_t)(dlt + win) * 8 + hh] = c->rel_emb[rel_pos_bucket(dlt) * 8 + hh];
+    HCK(hipMemcpyAsync(cm + L.band, c->host_tab.data(), c->host_tab.size() * 4, hipMemcpyHostToDevice, s));
+    // 3. per conditioned block: condition MLP -> to_kv -> l2norm * k_scale tables, then the sigma-affine tables
+    float* ctxb = (float*)ws;
+    int maxCo = 0;
+    for (int l = 0; l <= c->cfg.n_levels; ++l) maxCo = c->dims[l] > maxCo ? c->dims[l] : maxCo;
+    ws += al256((size_t)F * 2 * maxCo * 4);
+    float* kvb = (float*)ws;
+    // branch order of MT:463 (pose, aud, eye); cond columns [aud | pose | eye] (MT:426-428)
+    const int n_aud = c->cfg.cond_aud, n_pose = c->cfg.cond_pose, n_eye = c->cfg.cond_eye;
+    const int c0s[3] = {n_aud, 0, n_aud + n_pose}, cns[3] = {n_pose, n_aud, n_eye};
+    std::vector<RB*> blocks;
+    cond_blocks(c, blocks);
+    for (size_t bi = 0; bi < blocks.size(); ++bi) {
+        RB* rb = blocks[bi];
+        float* kvtab = (float*)(cm + L.kvtab[bi]);
+        float* nulltab = (float*)(cm + L.nulltab[bi]);
+        for (int b = 0; b < 3; ++b) {
+            CK(dawn_linear(cond + c0s[b], F, cns[b], ld_cond, rb->mlp_w[b], rb->mlp_b[b], 2 * rb->Co, 1, ctxb, 2 * rb->Co, s));
+            CK(dawn_linear(ctxb, F, 2 * rb->Co, 2 * rb->Co, rb->kv_w[b], nullptr, 128, 0, kvb, 128, s));
+            CK(dawn_xattn_prep(kvb, F, rb->k_scale[b], rb->null_kv[b], kvtab, b, nulltab, s));
+        }
+        if (L.xtab[bi] != (size_t)-1)
+            CK(dawn_xattn_tables(kvtab, nulltab, rb->q_scale, rb->wo[0], rb->wo[1], rb->wo[2], F, rb->Co, (float*)(cm + L.xtab[bi]), s));
+    }
+    return 0;
+}
+
+extern "C" size_t dawn_workspace_bytes(dawn_ctx* c, int F, int h, int w) {
+    if (!c || F <= 0 || h <= 0 || w <= 0) return 0;
+    c->arena.reset(nullptr, 0, true);
+    {
+        Eval ev(c, nullptr, F, h, w, nullptr);
+        ev.forward((const float*)4096, 0.f, (float*)4096);
+    }
+    size_t fwd = c->arena.high;
+    c->arena.reset(nullptr, 0, false);
+    // sampler state on top of one evaluation: x, eps, x0, noise (3*F*h*w floats each) + histograms / scalars
+    const size_t lat = al256((size_t)3 * F * h * w * 4);
+    const size_t samp = 4 * lat + al256(2048 * 4) + 2 * al256(1024 * 4) + 4 * 256;
+    const size_t prep = clip_scratch_bytes(c, F, h, w);
+    size_t need = fwd + samp;
+    return need > prep ? need : prep;
+}
+
+extern "C" int dawn_unet_forward(dawn_ctx* c, int F, int h, int w, const void* clip_mem, const float* x3, float t,
+                                 float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !clip_mem || !x3 || !eps_out || !workspace) return dawn_set_error_msg(-202, "dawn_unet_forward: null argument");
+    c->arena.reset(workspace, workspace_bytes, false);
+    Eval ev(c, (hipStream_t)stream, F, h, w, clip_mem);
+    ev.forward(x3, t, eps_out);
+    return ev.rc;
+}
+
+extern "C" int dawn_sampler_run(dawn_ctx* c, int F, int h, int w, const void* clip_mem, const float* x_init, int S,
+                                const dawn_ddim_step* steps, uint64_t seed, const float* const* noises, float* x_out,
+                                float* thresholds, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!c || !clip_mem || !x_init || !steps || !x_out || !workspace) return dawn_set_error_msg(-202, "dawn_sampler_run: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    const long n = (long)3 * F * h * w;
+    const size_t lat = al256((size_t)n * 4);
+    char* ws = (char*)workspace;
+    const size_t samp = 4 * lat + al256(2048 * 4) + 2 * al256(1024 * 4) + 4 * 256;
+    if (workspace_bytes < samp) return dawn_set_error_msg(-201, "dawn_sampler_run: workspace too small");
+    float* x = (float*)ws; ws += lat;
+    float* eps = (float*)ws; ws += lat;
+    float* x0 = (float*)ws; ws += lat;
+    float* noise = (float*)ws; ws += lat;
+    unsigned* hist1 = (unsigned*)ws; ws += al256(2048 * 4);
+    unsigned* hist2 = (unsigned*)ws; ws += al256(1024 * 4);
+    unsigned* hist3 = (unsigned*)ws; ws += al256(1024 * 4);
+    unsigned* state = (unsigned*)ws; ws += 256;
+    unsigned* hmin = (unsigned*)ws; ws += 256;
+    float* sthr = (float*)ws; ws += 256;
+    ws += 256;
+    const size_t fwd_bytes = workspace_bytes - (size_t)(ws - (char*)workspace);
+    HCK(hipMemcpyAsync(x, x_init, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    // quantile rank: torch.quantile's own fp32 arithmetic up to 2^24 elements, exact (fp64) above (ops.quantile_rank)
+    unsigned long long lo;
+    float weight;
+    if (n <= (1L << 24)) {
+        const float pos = 0.9f * (float)(n - 1);
+        const float fl = floorf(pos);
+        lo = (unsigned long long)fl;
+        weight = pos - fl;
+    } else {
+        const double pos = 0.9 * (double)(n - 1);
+        const double fl = floor(pos);
+        lo = (unsigned long long)fl;
+        weight = (float)(pos - fl);
+    }
+    for (int i = 0; i < S; ++i) {
+        const dawn_ddim_step& st = steps[i];
+        c->arena.reset(ws, fwd_bytes, false);
+        {
+            Eval ev(c, s, F, h, w, clip_mem);
+            ev.forward(x, (float)st.t, eps);
+            if (ev.rc) return ev.rc;
+        }
+        HCK(hipMemsetAsync(hist1, 0, 2048 * 4, s));
+        CK(dawn_ddim_x0(x, eps, st.recip, st.recipm1, n, x0, hist1, s));
+        HCK(hipMemsetAsync(state, 0, 16, s));
+        CK(dawn_select_scan(hist1, 2048, lo, state, 1, s));
+        HCK(hipMemsetAsync(hist2, 0, 1024 * 4, s));
+        CK(dawn_select_hist(x0, n, state, 2, hist2, s));
+        CK(dawn_select_scan(hist2, 1024, 0, state, 2, s));
+        HCK(hipMemsetAsync(hist3, 0, 1024 * 4, s));
+        CK(dawn_select_hist(x0, n, state, 3, hist3, s));
+        CK(dawn_select_scan(hist3, 1024, 0, state, 3, s));
+        HCK(hipMemsetD32Async((hipDeviceptr_t)hmin, 0x7fffffff, 4, s));
+        CK(dawn_select_hist(x0, n, state, 4, hmin, s));
+        CK(dawn_select_finalize(state, hmin, weight, sthr, s));
+        if (thresholds) HCK(hipMemcpyAsync(thresholds + 2 * i, sthr, 8, hipMemcpyDeviceToDevice, s));
+        const float* nz = nullptr;
+        if (st.t_next > 0) {                                    // noise only if t_next > 0 (MT:1201)
+            if (noises) nz = noises[i];
+            else { CK(dawn_philox_normal(noise, 3, F, 0, F, h * w, seed, (uint32_t)(i + 1), s)); nz = noise; }
+        }
+        CK(dawn_ddim_update(x0, eps, sthr, nz, st.sqrt_alpha_next, st.c, st.sigma, n, (i + 1 == S) ? x_out : x, s));
+    }
+    if (S == 0) HCK(hipMemcpyAsync(x_out, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
+    return 0;
+}
+
+// profile read-out: after a synchronise, (kind, algorithmic flops, algorithmic bytes, milliseconds) per recorded conv launch
+extern "C" int dawn_ctx_profile_read(dawn_ctx* c, double* out4, int max_entries) {
+    if (!c) return 0;
+    int n = 0;
+    for (auto& p : c->prof) {
+        if (n < max_entries && out4) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, p.e0, p.e1);
+            out4[4 * n] = p.kind; out4[4 * n + 1] = p.flops; out4[4 * n + 2] = p.bytes; out4[4 * n + 3] = ms;
+        }
+        ++n;
+        c->ev_pool.push_back(p.e0);
+        c->ev_pool.push_back(p.e1);
+    }
+    c->prof.clear();
+    return n;
+}

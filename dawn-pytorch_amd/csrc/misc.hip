@@ -216,3 +216,39 @@ extern "C" int dawn_sinusoidal(float t, int dim, const float* freqs, float* out,
     DAWN_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ---- helpers of the C-side evaluator (dawn_ctx.hip) -------------------------------------------------------------
+// (C, HW) planar -> (HW, C) channels-last: the layout change of the frame-invariant fea/bbox channels (once per clip)
+__global__ __launch_bounds__(256) void chw_to_hwc_kernel(const float* __restrict__ in, int C, long HW, float* __restrict__ out) {
+    __shared__ float tile[32][33];
+    const long p0 = (long)blockIdx.x * 32;
+    const int c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8)
+        if (c0 + r < C && p0 + tx < HW) tile[r][tx] = in[(long)(c0 + r) * HW + p0 + tx];
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8)
+        if (p0 + r < HW && c0 + tx < C) out[(p0 + r) * C + c0 + tx] = tile[tx][r];
+}
+extern "C" int dawn_chw_to_hwc(const float* in, int C, long HW, float* out, void* stream) {
+    hipLaunchKernelGGL(chw_to_hwc_kernel, dim3(dawn_cdiv(HW, 32), dawn_cdiv(C, 32)), dim3(256), 0, (hipStream_t)stream, in, C, HW, out);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}
+
+// cos / sin (n, 16) of angle = (pos0 + i) * freqs[j]  (rotary-embedding-torch 0.3.x, interleaved pairs; MT:761): the product
+// is formed in fp32 like the reference's `pos * freqs`, cos / sin evaluated in fp64 and rounded once
+__global__ void rotary_tables_kernel(const float* __restrict__ freqs, int n, int pos0, float* __restrict__ c, float* __restrict__ s) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n * 16) return;
+    const float ang = __fmul_rn((float)(pos0 + i / 16), freqs[i & 15]);
+    c[i] = (float)cos((double)ang);
+    s[i] = (float)sin((double)ang);
+}
+extern "C" int dawn_rotary_tables(const float* freqs, int n, int pos0, float* cos_out, float* sin_out, void* stream) {
+    hipLaunchKernelGGL(rotary_tables_kernel, dim3(dawn_cdiv((long)n * 16, 256)), dim3(256), 0, (hipStream_t)stream, freqs, n, pos0,
+                       cos_out, sin_out);
+    DAWN_LAUNCH_CHECK();
+    return 0;
+}

@@ -42,6 +42,8 @@ class GaussianDiffusion(nn.Module):
         self.noise_seed: Optional[int] = None     # int -> shard-invariant Philox stream on device
         self.use_graph = False                    # capture one UNet evaluation per clip as a HIP graph
         self.eager_every = 0                      # with use_graph: run every n-th step eagerly (profiling hooks)
+        self.use_ctx = False                      # run the DDIM loop through the C-side evaluator (dawn_sampler_run); same
+                                                  # kernels and arguments as the Python orchestration: bit-identical output
         self.last_trace: Optional[list] = None
 
     # ------------------------------------------------------------------ reference call surface
@@ -81,6 +83,26 @@ class GaussianDiffusion(nn.Module):
         if cond is not None and cond.shape[1] != T:
             raise ValueError(f"cond has {cond.shape[1]} frames but num_frames={T}; call update_num_frames first (UVG:370)")
         outs, traces = [], []
+        if self.use_ctx and comm is None and cond_scale == 1.0 and not trace and fea.is_cuda:
+            ev = unet.ctx_evaluator()
+            rcos, rsin = P.rotary_tables(T + 2 * P.win)
+            for b in range(B):
+                clip = ev.prepare_clip(fea[b].contiguous().float(), cond[b].contiguous().float(), rcos, rsin)
+                seed = self.noise_seed
+                if x_init is not None:
+                    x0 = x_init[b].contiguous().float()
+                elif seed is not None:
+                    x0 = ops.philox_normal(3, T, 0, T, h * w, seed + b, 0, device).reshape(3, T, h, w)
+                else:
+                    x0 = torch.randn(3, T, h, w, device=device)                       # MT:1166
+                nz = None
+                if noises is not None:
+                    nz = [noises[i][b].contiguous() if st["t_next"] > 0 else None for i, st in enumerate(steps)]
+                elif seed is None:
+                    nz = [torch.randn(3, T, h, w, device=device) if st["t_next"] > 0 else None for st in steps]   # MT:1201
+                outs.append(ev.sample(clip, x0, steps, seed=(seed or 0) + b, noises=nz))
+            self.last_trace = None
+            return torch.stack(outs, 0)
         for b in range(B):
             cs = unet.build_clip(fea[b].contiguous().float(), cond[b].contiguous().float(), comm=comm,
                                  Ttotal=Ttotal, f0=f0)

@@ -201,6 +201,14 @@ class Unet3D(nn.Module):
             self._packed_key = key
         return self._packed
 
+    def ctx_evaluator(self):
+        """The C-side evaluator (dawn_ctx, csrc/dawn_ctx.hip) of the current packed weights, created on first use."""
+        P = self.packed()
+        if getattr(self, "_ctx", None) is None or self._ctx.P is not P:
+            from .ctx import CtxEvaluator
+            self._ctx = CtxEvaluator(P)
+        return self._ctx
+
     def load_state_dict(self, *a, **k):
         r = super().load_state_dict(*a, **k)
         self._packed = None

@@ -19,6 +19,7 @@
 #ifndef DAWN_HIP_H
 #define DAWN_HIP_H
 #include <stdint.h>
+#include <stddef.h>
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -229,6 +230,67 @@ int dawn_final_conv_blend(const float* x, int T, int H, int W, int C, const floa
  * BGR (bgr != 0: cv2.cvtColor(RGB2BGR) for cv2.VideoWriter / imwrite).  mean0..2 = the caller's mean_c/255 as doubles. */
 int dawn_frames_to_u8(const float* vid, long plane, long npix, double mean0, double mean1, double mean2, int bgr,
                       unsigned char* out, void* stream);
+
+/* ---- whole-path entry points (C-side evaluator, csrc/dawn_ctx.hip) ----------------------------------
+ * A host in any language runs the denoiser with these five calls; the Python package keeps its own orchestration
+ * (unet_forward.py, needed for the T-sharded path) and the GPU tests require both to agree bit for bit.
+ *   dawn_ctx_create    packed weights (device pointers by name, layouts of pack.py) + architecture -> opaque ctx
+ *   dawn_clip_prepare  per-clip tables (hoisted out of the DDIM loop: fea part of init_conv, condition -> k/v tables,
+ *                      sigma-affine cross-attention tables, rotary + relative-position tables)   [FD:332-350, MT:1151,1167]
+ *   dawn_unet_forward  one Unet3D.forward (null_cond_prob = 0) of one clip                       [MT:892-956]
+ *   dawn_sampler_run   the DDIM loop: S x (forward, x0, dynamic-threshold quantile, update)      [MT:1156-1208]
+ * No allocation, no synchronisation: the caller owns the clip memory (dawn_clip_bytes) and the workspace
+ * (dawn_workspace_bytes); launches go to `stream` and to one ctx-owned side stream forked / joined with events.
+ * One host thread per ctx.  Single GPU (the T-shard exchanges live in the Python host, tshard.py). */
+typedef struct dawn_ctx dawn_ctx;
+typedef struct dawn_unet_cfg {
+    int dim;                 /* base width (64) */
+    int n_levels;            /* len(dim_mults) */
+    int dim_mults[8];        /* (1, 2, 4, 8) */
+    int fea_ch;              /* frame-invariant input channels (256 fea + 16 bbox = 272) */
+    int cond_aud, cond_pose, cond_eye;   /* condition columns [aud | pose | eye] (MT:426-428) */
+    int win;                 /* local-attention half window (40) */
+} dawn_unet_cfg;
+typedef struct dawn_named_ptr { const char* name; const void* ptr; } dawn_named_ptr;
+/* weight names = the fields of pack.PackedUNet, dotted: "w3" "wfea" "b_init" "rel_emb" "rot_freqs" "sin_freqs" "t_w1" "t_b1"
+ * "t_w2" "t_b2" "film_w" "film_b" "wg" "bg" "wo" "bo"; attention layers "<init_tattn|downs.L.sla|downs.L.tattn|mid.sattn|
+ * mid.tattn|ups.L.sla|ups.L.tattn>.<wqkv|wout|bout|wqkv_s|wout_s|wout_sp>"; ResBlocks "<downs.L.rb1|...|mid.rb1|mid.rb2|
+ * head_g|head_o>.<w1|b1|g1|be1|w2|b2|g2|be2|wr|br|w1s|w2s|wrs|wq|wqs|q_scale|g3|wo.B|wos.B|mlp_w.B|mlp_b.B|kv_w.B|k_scale.B|
+ * null_kv.B>" (B = 0..2: pose, aud, eye); "downs.L.down.<w|b>", "ups.L.up.<w|b>" (dawn_pytorch_amd/ctx.py builds the table). */
+int dawn_ctx_create(const dawn_unet_cfg* cfg, const dawn_named_ptr* weights, int n_weights, dawn_ctx** out);
+void dawn_ctx_destroy(dawn_ctx* ctx);
+enum { DAWN_OPT_CONV_POLICY = 1, DAWN_OPT_TEMPORAL_FLAGS = 2, DAWN_OPT_OVERLAP = 3, DAWN_OPT_PROFILE = 4 };
+/* tuning state lives in the ctx: conv policy bits (dawn_conv_desc.policy), temporal-layer kernel family, two-stream
+ * overlap on/off, per-launch HIP events around every dawn_conv_gemm (read with dawn_ctx_profile_read) */
+int dawn_ctx_set_option(dawn_ctx* ctx, int option, int value);
+size_t dawn_clip_bytes(dawn_ctx* ctx, int F, int h, int w);
+size_t dawn_workspace_bytes(dawn_ctx* ctx, int F, int h, int w);      /* covers prepare, forward and sampler_run */
+/* fea272 (fea_ch, h, w) reference layout; cond (F, cond_dim) with row stride ld_cond; rot_cos / rot_sin optional
+ * (F + 2 win, 16) tables (NULL: computed on the device from the checkpoint's `freqs`) */
+int dawn_clip_prepare(dawn_ctx* ctx, int F, int h, int w, const float* fea272, const float* cond, int ld_cond,
+                      const float* rot_cos, const float* rot_sin, void* clip_mem, size_t clip_bytes, void* workspace,
+                      size_t workspace_bytes, void* stream);
+/* x3, eps_out: (3, F, h, w) latent / predicted noise in the reference layout; t = the integer diffusion time */
+int dawn_unet_forward(dawn_ctx* ctx, int F, int h, int w, const void* clip_mem, const float* x3, float t,
+                      float* eps_out, void* workspace, size_t workspace_bytes, void* stream);
+typedef struct dawn_ddim_step {          /* per-step scalars of MT:1170-1205 (host arithmetic of the schedule tables) */
+    int t, t_next;
+    float recip, recipm1;                /* sqrt_recip_alphas_cumprod[t], sqrt_recipm1_alphas_cumprod[t] */
+    float sqrt_alpha_next, c, sigma;
+} dawn_ddim_step;
+/* x_init -> x_out (3, F, h, w).  Noise of step i (only when t_next > 0): noises[i] when `noises` is given, else the
+ * counter-based generator (seed, stream i + 1).  thresholds (optional, 2 S floats): [max(1, q), q] of every step. */
+int dawn_sampler_run(dawn_ctx* ctx, int F, int h, int w, const void* clip_mem, const float* x_init, int S,
+                     const dawn_ddim_step* steps, uint64_t seed, const float* const* noises, float* x_out,
+                     float* thresholds, void* workspace, size_t workspace_bytes, void* stream);
+/* after a stream synchronise: (kind, algorithmic flops, algorithmic bytes, ms) per conv launch recorded under
+ * DAWN_OPT_PROFILE; kind 0 = split 3x3, 1 = split 1x1, 2 = fp32 MFMA; returns the number of entries (and clears them) */
+int dawn_ctx_profile_read(dawn_ctx* ctx, double* out4, int max_entries);
+/* helpers the evaluator uses (exported for hosts that build their own orchestration) */
+int dawn_chw_to_hwc(const float* in, int C, long HW, float* out, void* stream);
+int dawn_rotary_tables(const float* freqs16, int n, int pos0, float* cos_out, float* sin_out, void* stream);
+int dawn_rel_pos_bucket(int rel);                                     /* MT:92-109, num_buckets = max_distance = 32 (host) */
+int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1);             /* host: does a 1x1 projection take the split GEMM? */
 
 #ifdef __cplusplus
 }

@@ -20,7 +20,12 @@ def test_library_exports_every_declared_symbol():
     assert len(names) >= 25
     for n in names:
         assert hasattr(L, n), f"{n} declared in include/dawn_hip.h but not exported by libdawn_hip.so"
-    declared = set(names) - {"dawn_last_error", "dawn_abi_version"}
+    # whole-path entry points (bound with their own argtypes in dawn_pytorch_amd/ctx.py) + host-side helpers
+    CTX = {"dawn_ctx_create", "dawn_ctx_destroy", "dawn_ctx_set_option", "dawn_clip_bytes", "dawn_workspace_bytes",
+           "dawn_clip_prepare", "dawn_unet_forward", "dawn_sampler_run", "dawn_ctx_profile_read", "dawn_chw_to_hwc",
+           "dawn_rotary_tables", "dawn_rel_pos_bucket", "dawn_gemm1x1_split_ok"}
+    declared = set(names) - {"dawn_last_error", "dawn_abi_version"} - CTX
+    assert CTX <= set(names)
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     assert L.dawn_abi_version() == 2
     # no process-global tuning hooks / ablation entry points in the shipped library (policy travels in dawn_conv_desc)
@@ -49,3 +54,28 @@ def test_conv_desc_layout_matches_c():
     for name, _ in _lib.ConvDesc._fields_:
         assert getattr(_lib.ConvDesc, name).offset == expect[name], name
     assert ctypes.sizeof(_lib.ConvDesc) == (off + 7) // 8 * 8
+
+
+def test_host_side_helpers_match_python_and_reference():
+    """Pure host functions of the C evaluator, callable without a GPU: the relative-position bucket against the
+    reference-generated table (tests/golden/tables.npz, MT:92-109) and the split-GEMM plan against HipOps' mirror."""
+    import numpy as np
+    from conftest import load_golden
+    from dawn_pytorch_amd.ops import HipOps
+    L = _lib.lib()
+    g = load_golden("tables.npz")
+    for rel, b in zip(g["rel"].tolist(), g["bucket"].tolist()):
+        assert L.dawn_rel_pos_bucket(int(rel)) == int(b), rel
+    L.dawn_gemm1x1_split_ok.argtypes = [ctypes.c_long, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    for M in (256, 12800, 25600, 51200, 204800, 819200, 12801):
+        for N in (64, 128, 192, 256, 512, 768):
+            for C0, C1 in ((64, 0), (128, 0), (256, 256), (512, 512), (48, 0), (64, 64)):
+                assert bool(L.dawn_gemm1x1_split_ok(M, N, C0, C1)) == HipOps.split_gemm_ok(M, N, C0, C1), (M, N, C0, C1)
+
+
+def test_ctx_structs_match_header():
+    """ctypes mirrors of dawn_unet_cfg / dawn_ddim_step have the sizes the C declarations imply."""
+    from dawn_pytorch_amd import ctx
+    assert ctypes.sizeof(ctx.UnetCfg) == 4 * (2 + 8 + 1 + 3 + 1)
+    assert ctypes.sizeof(ctx.DdimStep) == 4 * 7
+    assert ctypes.sizeof(ctx.NamedPtr) == 16
