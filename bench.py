@@ -186,6 +186,10 @@ def main():
                     help="record the per-launch HIP events of the roofline measurement on every n-th DDIM step of the timed "
                          "region (every step costs ~2.5 %% of the run: two marker packets per conv launch)")
     ap.add_argument("--no-overlap", action="store_true", help="disable the two-stream overlap inside ResBlocks")
+    ap.add_argument("--host", choices=["python", "ctx"], default="python",
+                    help="who issues the launches of the DDIM loop: the Python orchestration (unet_forward.py / sampler.py) or "
+                         "the C-side evaluator (dawn_sampler_run, csrc/dawn_ctx.hip; single-GPU / replica modes); same kernels, "
+                         "bit-identical results")
     ap.add_argument("--graph", action="store_true",
                     help="replay one captured HIP graph per DDIM step (measured: no gain, 70.4 vs 72.0 frames/s -- the "
                          "path is not launch-bound; kept as an option)")
@@ -222,6 +226,10 @@ def main():
                                        Ttotal=Ttotal)
     ops = unet._ops()
     ops.overlap = not args.no_overlap
+    diff.use_ctx = args.host == "ctx" and mode != "tshard"
+    if diff.use_ctx:
+        from dawn_pytorch_amd import ctx as _ctx
+        unet.ctx_evaluator().set_option(_ctx.OPT_OVERLAP, 0 if args.no_overlap else 1)
     diff.use_graph = args.graph and mode != "tshard"
     diff.eager_every = args.eager_every
 
@@ -235,7 +243,7 @@ def main():
 
     for _ in range(args.warmup):
         one_clip()
-    if not args.no_kernel_events:
+    if not args.no_kernel_events and not diff.use_ctx:
         ops.prof = []
         ops.prof_every = max(1, args.event_every)
     barrier()
@@ -349,6 +357,7 @@ def main():
         (n_gpus if mode == "replica" else 1)
     result["whole_path"] = {"algorithmic_tflop": alg / 1e12, "achieved_tflops": alg / dt / 1e12,
                             "frac_of_fp32_mfma_peak": alg / dt / 1e12 / (PEAK_FP32_MFMA_TFLOPS * n_gpus)}
+    result["config"]["host"] = ("C-side evaluator (dawn_sampler_run)" if diff.use_ctx else "Python orchestration (ctypes launches)")
     result["config"]["launch"] = ("HIP graph replay per DDIM step" if diff.use_graph and getattr(ops, "graph_error", None) is None
                                   else "eager" + (f" (graph capture failed: {ops.graph_error})" if getattr(ops, "graph_error", None) else ""))
     if n_gpus == 1 and not args.no_decode:

@@ -469,10 +469,24 @@ struct Eval {
     T2 temporal(const AT& a, const T2& x, int Fr, int H, int W) {
         const int HW = H * W, win = c->cfg.win;
         T2 o;
-        if (can_fuse_temporal(a.C, Fr, Fr, win)) {
+        const bool seg_ok = a.C == 64 && win <= 40;
+        if (can_fuse_temporal(a.C, Fr, Fr, win) && (Fr <= 200 || !seg_ok)) {
             o = t2(x.rows, 64);
             LAUNCH(dawn_temporal_layer_c64_ex(x.p, Fr, HW, 0, Fr, win, a.wqkv, a.wqkv_s, a.wout, a.wout_sp, clipf(L.rcos), clipf(L.rsin),
                                               clipf(L.band), 1e-5f, o.p, c->temporal_flags, cur));
+            return o;
+        }
+        if (seg_ok) {
+            // long clips: one launch of the fused layer per 120-query segment on the row window [a - win, b + win) of the
+            // same buffer (ops.temporal_layer_c64_segmented)
+            o = t2(x.rows, 64);
+            for (int qa = 0; qa < Fr; qa += 120) {
+                const int qb = qa + 120 < Fr ? qa + 120 : Fr;
+                const int r0 = qa - win > 0 ? qa - win : 0, r1 = qb + win < Fr ? qb + win : Fr;
+                LAUNCH(dawn_temporal_layer_c64_ex(x.p + (size_t)r0 * HW * 64, r1 - r0, HW, qa - r0, qb - qa, win, a.wqkv, a.wqkv_s, a.wout,
+                                                  a.wout_sp, clipf(L.rcos), clipf(L.rsin), clipf(L.band), 1e-5f,
+                                                  o.p + (size_t)qa * HW * 64, c->temporal_flags, cur));
+            }
             return o;
         }
         T2 qkv = ln_gemm(x, nullptr, a.wqkv, 768, a.wqkv_s, Fr, H, W);

@@ -311,13 +311,44 @@ class HipOps:
     def can_fuse_temporal(C: int, Fext: int, Fq: int, win: int) -> bool:
         return C == 64 and Fext <= 288 and Fq <= 256 and win <= 48
 
+    SEG_QUERIES = 120     # queries per launch of the segmented form: 120 + 2 x 40 halo rows = the 200-row LDS budget of WMODE 3
+
+    @staticmethod
+    def can_fuse_temporal_segmented(C: int, win: int) -> bool:
+        return C == 64 and win <= 40
+
+    def temporal_layer_c64_segmented(self, x: Tensor, Fext: int, HW: int, q0: int, Fq: int, win: int, wqkv: Tensor,
+                                     wout: Tensor, rcos: Tensor, rsin: Tensor, band: Tensor, eps: float = 1e-5,
+                                     wqkv_bf3: Optional[Tensor] = None, wout_bf3p: Optional[Tensor] = None,
+                                     out: Optional[Tensor] = None, segments=None) -> Tensor:
+        """The fused 64-channel layer for frame buffers longer than one launch holds in LDS (long clips, T-shard shards with
+        halos): the query range is cut into segments of <= 120 frames and every segment is ONE launch of the fused kernel
+        on the row window [a - win, b + win) of the same buffer (rows are frame-major, so a window is a contiguous view).
+        Attention is window-local and rotary positions only matter relatively, so the segments are independent; the price
+        is re-projecting K / V of the 2*win overlap rows per segment -- instead of writing and re-reading a (rows, 768)
+        qkv tensor (21 -> ~10 MB per frame of peak memory on long clips).  `segments` = explicit [(a, b)] query ranges
+        (buffer frame indices; the T-shard path runs the halo-free interior segments first)."""
+        assert x.is_contiguous() and x.shape == (Fext * HW, 64)
+        if out is None:
+            out = self.empty(Fq * HW, 64, like=x)
+        if segments is None:
+            segments = [(a, min(a + self.SEG_QUERIES, q0 + Fq)) for a in range(q0, q0 + Fq, self.SEG_QUERIES)]
+        for a, b in segments:
+            r0, r1 = max(0, a - win), min(Fext, b + win)
+            self.temporal_layer_c64(x[r0 * HW:r1 * HW], r1 - r0, HW, a - r0, b - a, win, wqkv, wout, rcos, rsin, band, eps,
+                                    wqkv_bf3=wqkv_bf3, wout_bf3p=wout_bf3p, out=out[(a - q0) * HW:(b - q0) * HW])
+        return out
+
     def temporal_layer_c64(self, x: Tensor, Fext: int, HW: int, q0: int, Fq: int, win: int, wqkv: Tensor,
                            wout: Tensor, rcos: Tensor, rsin: Tensor, band: Tensor, eps: float = 1e-5,
-                           wqkv_bf3: Optional[Tensor] = None, wout_bf3p: Optional[Tensor] = None) -> Tensor:
+                           wqkv_bf3: Optional[Tensor] = None, wout_bf3p: Optional[Tensor] = None,
+                           out: Optional[Tensor] = None) -> Tensor:
         """out = x[q0:q0+Fq] + to_out(attn(LayerNorm(x))) for 64-channel levels, one kernel."""
         assert x.is_contiguous() and x.shape == (Fext * HW, 64)
         self._require(x, wqkv, wout, rcos, rsin, band)
-        out = self.empty(Fq * HW, 64, like=x)
+        if out is None:
+            out = self.empty(Fq * HW, 64, like=x)
+        assert out.is_contiguous() and out.shape == (Fq * HW, 64)
         check(self.L.dawn_temporal_layer_c64_ex(_p(x), Fext, HW, q0, Fq, win, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(wout_bf3p),
                                                 _p(rcos), _p(rsin), _p(band), eps, _p(out), self.temporal_flags,
                                                 self._stream()),

@@ -152,9 +152,13 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
     else:
         xe, q0 = x, 0
     Fext = xe.shape[0] // HW
-    if ops.can_fuse_temporal(a.C, Fext, F, cs.win):
+    if ops.can_fuse_temporal(a.C, Fext, F, cs.win) and (Fext <= 200 or not ops.can_fuse_temporal_segmented(a.C, cs.win)):
         return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
                                       wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp)
+    if ops.can_fuse_temporal_segmented(a.C, cs.win):
+        # long frame buffers (clips > 288 frames, wide T-shard windows): the fused layer, one launch per 120-query segment
+        return ops.temporal_layer_c64_segmented(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
+                                                wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp)
     qkv = _ln_gemm(ops, xe, None, a.wqkv, 768, a.wqkv_s, F=Fext, Hi=H, Wi=W)
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)

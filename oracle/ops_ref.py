@@ -247,7 +247,25 @@ class RefOps:
     def can_fuse_temporal(C, Fext, Fq, win):
         return C == 64 and Fext <= 288 and Fq <= 256 and win <= 48
 
-    def temporal_layer_c64(self, x, Fext, HW, q0, Fq, win, wqkv, wout, rcos, rsin, band, eps=1e-5, wqkv_bf3=None, wout_bf3p=None):
+    @staticmethod
+    def can_fuse_temporal_segmented(C, win):
+        return C == 64 and win <= 40
+
+    def temporal_layer_c64_segmented(self, x, Fext, HW, q0, Fq, win, wqkv, wout, rcos, rsin, band, eps=1e-5, wqkv_bf3=None,
+                                     wout_bf3p=None, out=None, segments=None):
+        """Same segmentation as HipOps (the CPU orchestration tests then also cover the row-window arithmetic)."""
+        if out is None:
+            out = torch.empty(Fq * HW, 64, dtype=x.dtype, device=x.device)
+        if segments is None:
+            segments = [(a, min(a + 120, q0 + Fq)) for a in range(q0, q0 + Fq, 120)]
+        for a, b in segments:
+            r0, r1 = max(0, a - win), min(Fext, b + win)
+            out[(a - q0) * HW:(b - q0) * HW] = self.temporal_layer_c64(x[r0 * HW:r1 * HW], r1 - r0, HW, a - r0, b - a, win, wqkv,
+                                                                       wout, rcos, rsin, band, eps)
+        return out
+
+    def temporal_layer_c64(self, x, Fext, HW, q0, Fq, win, wqkv, wout, rcos, rsin, band, eps=1e-5, wqkv_bf3=None, wout_bf3p=None,
+                           out=None):
         """Composition of the unfused reference ops (what the fused kernel must equal)."""
         stats = self.ln_rowstats(x, None, eps)
         qkv = self.conv_gemm(x, wqkv, 768, row_stats=stats, F=Fext, Hi=1, Wi=HW)

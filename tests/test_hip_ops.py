@@ -456,6 +456,30 @@ def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
         hip.temporal_flags = 0
 
 
+@pytest.mark.parametrize("Fext,HW,q0,Fq", [(400, 8, 0, 400), (280, 8, 40, 200), (330, 4, 17, 301), (240, 8, 0, 200)])
+def test_temporal_layer_c64_segmented(hip, ref, Fext, HW, q0, Fq):
+    """Long frame buffers (BASELINE configs[1]: 400 frames; T-shard windows of 280): one fused launch per 120-query segment
+    on overlapping row windows == the unfused composition on the whole buffer."""
+    from dawn_pytorch_amd.pack import pack_bf3, pack_bf3_temporal_out, unpack_kn
+    win = 40
+    x = rnd(Fext * HW, 64, seed=1) * 1.3 + 0.2
+    wqkv, wout = packw(64, 768, seed=2), packw(256, 64, seed=3)
+    ang = torch.arange(Fext).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
+    rc, rs = ang.cos().contiguous(), ang.sin().contiguous()
+    band = rnd(2 * win + 1, 8, seed=4)
+    want = ref.temporal_layer_c64(x, Fext, HW, q0, Fq, win, wqkv, wout, rc, rs, band)
+    got = hip.temporal_layer_c64_segmented(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band),
+                                           wqkv_bf3=pack_bf3(unpack_kn(wqkv)).cuda(), wout_bf3p=pack_bf3_temporal_out(unpack_kn(wout)).cuda())
+    check(f"temporal_layer_c64_segmented/F{Fext}_q{q0}_{Fq}", got, want, 3e-5)
+    # explicit segment order (interior first, as the T-shard path issues them)
+    segs = [(q0 + 40, q0 + Fq - 40), (q0, q0 + 40), (q0 + Fq - 40, q0 + Fq)] if Fq - 80 <= 120 else None
+    if segs:
+        got = hip.temporal_layer_c64_segmented(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band),
+                                               wqkv_bf3=pack_bf3(unpack_kn(wqkv)).cuda(),
+                                               wout_bf3p=pack_bf3_temporal_out(unpack_kn(wout)).cuda(), segments=segs)
+        check(f"temporal_layer_c64_segmented_interior_first/F{Fext}_q{q0}_{Fq}", got, want, 3e-5)
+
+
 @pytest.mark.parametrize("F,HW", [(3, 64), (2, 256), (5, 16), (2, 100)])
 def test_sla(hip, ref, F, HW):
     qkv = rnd(F * HW, 768, seed=1)
