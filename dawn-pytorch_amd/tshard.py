@@ -21,17 +21,52 @@ import torch
 Tensor = torch.Tensor
 
 
+class HaloExchange:
+    """One temporal-attention halo exchange in flight: `xe` = [lower halo | own frames | upper halo] rows, `hl` / `hh` the
+    halo frame counts actually present (0 at the clip ends), `works` the outstanding P2P requests."""
+
+    def __init__(self, xe: Tensor, hl: int, hh: int, F: int, works):
+        self.xe, self.hl, self.hh, self.F, self.works = xe, hl, hh, F, works
+
+    @property
+    def Fext(self) -> int:
+        return self.hl + self.F + self.hh
+
+
 class TShardComm:
+    """Contiguous, equal frame ranges per rank: rank r owns the global frames [r*F, (r+1)*F) of a clip of Ttotal = world*F.
+
+    The halo exchange is SPLIT in two calls so that the orchestration can compute while the transfer runs
+    (`halo_begin` posts the sends / receives and returns, `halo_end` makes the current stream wait for them): everything
+    that only needs this rank's own frames -- the queries whose window does not reach a neighbour, the qkv projection of
+    the own rows -- is launched in between (unet_forward._temporal).  A halo wider than the neighbour's shard (F < win) is
+    gathered from as many ranks as it spans.  Buffers are cached per shape (no allocation per layer and step)."""
+
     def __init__(self, dist, rank: int, world: int, Ttotal: int, f0: int, F: int, group=None):
         self.dist, self.rank, self.world = dist, rank, world
         self.Ttotal, self.f0, self.F = Ttotal, f0, F
         self.group = group
+        if world > 1 and (f0 != rank * F or Ttotal != world * F):
+            raise ValueError("TShardComm expects equal contiguous shards: f0 == rank*F and Ttotal == world*F")
+        self._bufs = {}
+        self.n_halo = self.n_allreduce = 0
+        self.halo_bytes_sent = self.halo_bytes_recv = self.allreduce_bytes = 0
+
+    def stats(self) -> dict:
+        """Counters since construction (bench.py reports them per rank: RCCL participation is checkable from the JSON)."""
+        return {"rank": self.rank, "world": self.world, "halo_exchanges": self.n_halo,
+                "halo_bytes_sent": self.halo_bytes_sent, "halo_bytes_received": self.halo_bytes_recv,
+                "all_reduces": self.n_allreduce, "all_reduce_bytes": self.allreduce_bytes}
 
     # ---- tiny reductions
     def all_reduce_sum(self, t: Tensor) -> None:
+        self.n_allreduce += 1
+        self.allreduce_bytes += t.numel() * t.element_size()
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
     def all_reduce_min(self, t: Tensor) -> None:
+        self.n_allreduce += 1
+        self.allreduce_bytes += t.numel() * t.element_size()
         self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
 
     def all_gather_cat(self, v: Tensor) -> Tensor:
@@ -41,26 +76,51 @@ class TShardComm:
         return torch.cat(parts)
 
     # ---- neighbour halo exchange for the windowed temporal attention
-    def halo_exchange(self, x: Tensor, HW: int, win: int) -> Tuple[Tensor, int]:
-        """x (F*HW, C) own frames -> (xe ((hl+F+hh)*HW, C), q0=hl) with hl/hh = win frames from the lower /
-        upper T-neighbour (0 at the clip ends)."""
+    def _buffer(self, rows: int, C: int, like: Tensor) -> Tensor:
+        key = (rows, C, like.device, like.dtype)
+        b = self._bufs.get(key)
+        if b is None:
+            b = self._bufs[key] = torch.empty(rows, C, device=like.device, dtype=like.dtype)
+        return b
+
+    def halo_begin(self, x: Tensor, HW: int, win: int) -> HaloExchange:
+        """x (F*HW, C) own frames.  Copies them into the middle of the (cached) extended buffer and posts the point-to-point
+        sends / receives of the halo frames: the lower halo = global frames [f0 - win, f0), the upper = [f0 + F, f0 + F +
+        win), clipped to the clip, each piece from the rank that owns it."""
         F = x.shape[0] // HW
-        if F < win and self.world > 1:
-            raise ValueError(f"T-shard needs at least win={win} frames per rank, got {F}")
-        lo, hi = self.rank > 0, self.rank < self.world - 1
-        hl, hh = (win if lo else 0), (win if hi else 0)
+        assert F == self.F, (F, self.F)
         C = x.shape[1]
-        xe = torch.empty((hl + F + hh) * HW, C, device=x.device, dtype=x.dtype)
+        lo_g, hi_g = max(0, self.f0 - win), min(self.Ttotal, self.f0 + F + win)     # global frame range of the buffer
+        hl, hh = self.f0 - lo_g, hi_g - (self.f0 + F)
+        xe = self._buffer((hl + F + hh) * HW, C, x)
         xe[hl * HW:(hl + F) * HW].copy_(x)
-        ops = []
         d = self.dist
-        if lo:
-            ops.append(d.P2POp(d.isend, x[:win * HW], self.rank - 1, group=self.group))
-            ops.append(d.P2POp(d.irecv, xe[:hl * HW], self.rank - 1, group=self.group))
-        if hi:
-            ops.append(d.P2POp(d.isend, x[(F - win) * HW:], self.rank + 1, group=self.group))
-            ops.append(d.P2POp(d.irecv, xe[(hl + F) * HW:], self.rank + 1, group=self.group))
-        if ops:
-            for w in d.batch_isend_irecv(ops):
-                w.wait()
-        return xe, hl
+        ops = []
+        for r in range(self.world):
+            if r == self.rank:
+                continue
+            r0, r1 = r * F, (r + 1) * F                                             # frames rank r owns
+            # what I receive from r: its frames inside my buffer range
+            a, b = max(r0, lo_g), min(r1, hi_g)
+            if a < b:
+                ops.append(d.P2POp(d.irecv, xe[(a - lo_g) * HW:(b - lo_g) * HW], r, group=self.group))
+                self.halo_bytes_recv += (b - a) * HW * C * x.element_size()
+            # what I send to r: my frames inside ITS buffer range [r0 - win, r1 + win)
+            a, b = max(self.f0, r0 - win), min(self.f0 + F, r1 + win)
+            if a < b:
+                ops.append(d.P2POp(d.isend, x[(a - self.f0) * HW:(b - self.f0) * HW], r, group=self.group))
+                self.halo_bytes_sent += (b - a) * HW * C * x.element_size()
+        works = d.batch_isend_irecv(ops) if ops else []
+        self.n_halo += 1
+        return HaloExchange(xe, hl, hh, F, works)
+
+    def halo_end(self, hx: HaloExchange) -> None:
+        for w in hx.works:
+            w.wait()          # NCCL/RCCL: the current stream waits for the transfer; gloo: the host does
+        hx.works = []
+
+    def halo_exchange(self, x: Tensor, HW: int, win: int) -> Tuple[Tensor, int]:
+        """Blocking form: (xe, first own frame index in xe)."""
+        hx = self.halo_begin(x, HW, win)
+        self.halo_end(hx)
+        return hx.xe, hx.hl

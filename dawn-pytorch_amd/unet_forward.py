@@ -145,22 +145,61 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     return ops.gn_apply_res(c2, a2, b2, x)
 
 
+def _chunks(a: int, b: int, n: int):
+    return [(i, min(i + n, b)) for i in range(a, b, n)]
+
+
 def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState) -> Tensor:
     HW = H * W
     if cs.comm is not None:
-        xe, q0 = cs.comm.halo_exchange(x, HW, cs.win)      # (Fext*HW, C), first own frame index
-    else:
-        xe, q0 = x, 0
-    Fext = xe.shape[0] // HW
+        return _temporal_sharded(ops, a, x, F, H, W, cs)
+    xe, q0, Fext = x, 0, F
     if ops.can_fuse_temporal(a.C, Fext, F, cs.win) and (Fext <= 200 or not ops.can_fuse_temporal_segmented(a.C, cs.win)):
         return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
                                       wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp)
     if ops.can_fuse_temporal_segmented(a.C, cs.win):
-        # long frame buffers (clips > 288 frames, wide T-shard windows): the fused layer, one launch per 120-query segment
+        # long frame buffers (clips > 200 frames): the fused layer, one launch per 120-query segment
         return ops.temporal_layer_c64_segmented(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
                                                 wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp)
     qkv = _ln_gemm(ops, xe, None, a.wqkv, 768, a.wqkv_s, F=Fext, Hi=H, Wi=W)
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)
+    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
+
+
+def _temporal_sharded(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState) -> Tensor:
+    """T-sharded form: the halo exchange is posted first, everything that only needs this rank's own
+    frames is launched while it is in flight, and only the work that reads halo rows waits for it."""
+    HW, win, comm = H * W, cs.win, cs.comm
+    hx = comm.halo_begin(x, HW, win)                      # xe = [lower halo | own | upper halo], transfers in flight
+    xe, q0, Fext = hx.xe, hx.hl, hx.Fext
+    if ops.can_fuse_temporal_segmented(a.C, win):
+        # queries whose +-win window stays inside the own rows need no halo: those segments run first
+        ia, ib = q0 + (win if hx.hl else 0), q0 + F - (win if hx.hh else 0)
+        ia, ib = min(ia, q0 + F), max(ib, min(ia, q0 + F))
+        out = ops.empty(F * HW, a.C, like=x)
+        kw = dict(wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp, out=out)
+        if ib > ia:
+            ops.temporal_layer_c64_segmented(xe, Fext, HW, q0, F, win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
+                                             segments=_chunks(ia, ib, ops.SEG_QUERIES), **kw)
+        comm.halo_end(hx)
+        edges = _chunks(q0, ia, ops.SEG_QUERIES) + _chunks(ib, q0 + F, ops.SEG_QUERIES)
+        if edges:
+            ops.temporal_layer_c64_segmented(xe, Fext, HW, q0, F, win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
+                                             segments=edges, **kw)
+        return out
+    if ops.can_fuse_temporal(a.C, Fext, F, win):
+        comm.halo_end(hx)
+        return ops.temporal_layer_c64(xe, Fext, HW, q0, F, win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
+                                      wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp)
+    # unfused levels: LayerNorm + qkv projection are row-local -> the own rows are projected during the transfer
+    qkv = ops.empty(Fext * HW, 768, like=x)
+    _ln_gemm(ops, xe[q0 * HW:(q0 + F) * HW], None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W, out=qkv[q0 * HW:(q0 + F) * HW])
+    comm.halo_end(hx)
+    if hx.hl:
+        _ln_gemm(ops, xe[:q0 * HW], None, a.wqkv, 768, a.wqkv_s, F=hx.hl, Hi=H, Wi=W, out=qkv[:q0 * HW])
+    if hx.hh:
+        _ln_gemm(ops, xe[(q0 + F) * HW:], None, a.wqkv, 768, a.wqkv_s, F=hx.hh, Hi=H, Wi=W, out=qkv[(q0 + F) * HW:])
+    o = ops.temporal_attn(qkv, Fext, HW, q0, F, win, cs.rcos, cs.rsin, cs.band)
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 

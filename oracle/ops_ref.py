@@ -247,6 +247,8 @@ class RefOps:
     def can_fuse_temporal(C, Fext, Fq, win):
         return C == 64 and Fext <= 288 and Fq <= 256 and win <= 48
 
+    SEG_QUERIES = 120
+
     @staticmethod
     def can_fuse_temporal_segmented(C, win):
         return C == 64 and win <= 40

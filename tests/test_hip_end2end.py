@@ -123,6 +123,13 @@ class _LoopbackComm:
     def halo_exchange(self, x, HW, win):
         return x, 0
 
+    def halo_begin(self, x, HW, win):
+        from dawn_pytorch_amd.tshard import HaloExchange
+        return HaloExchange(x, 0, 0, x.shape[0] // HW, [])
+
+    def halo_end(self, hx):
+        pass
+
 
 def test_sharded_code_paths_world1(tiny):
     g, sd = tiny
@@ -189,3 +196,42 @@ def test_benchmark_size_kernel_families_agree(Tn, res):
     assert err <= 2e-4 * max(1.0, scale), (err, scale)
     # determinism of the shipped path at this size (no atomics in any reduction)
     assert torch.equal(unet_forward(ops, P, cs, x, 500), y_split)
+
+
+def test_tshard_rccl_world1_equals_unsharded():
+    """The T-shard path on the GPU over a real RCCL communicator (world size 1: the only size a 1-GPU box offers):
+    `TShardComm` + the sharded orchestration (interior-first fused segments, separate GroupNorm reduce / all-reduce /
+    finalize, histogram all-reduces) on a 64-channel model must reproduce the unsharded sampler.  Multi-rank equality
+    is covered on CPU (tests/test_tshard_cpu.py, gloo, world 2-4)."""
+    import socket
+    import torch.distributed as dist
+    from dawn_pytorch_amd.tshard import TShardComm
+    Tn, h = 40, 16
+    unet = D.DynamicNfUnet3D(default_num_frames=Tn, dim=64, cond_dim=40, cond_aud=32, cond_pose=6, cond_eye=2,
+                             num_frames=Tn, channels=35, out_grid_dim=2, out_conf_dim=1, dim_mults=(1, 2, 4),
+                             use_hubert_audio_cond=True, win_width=10).cuda()
+    diff = D.DynamicNfGaussianDiffusion(default_num_frames=Tn, denoise_fn=unet, num_frames=Tn, image_size=h,
+                                        sampling_timesteps=3, timesteps=1000, loss_type='l2', use_dynamic_thres=True,
+                                        ddim_sampling_eta=1.0).cuda()
+    diff.noise_seed = 5
+    g = torch.Generator().manual_seed(5)
+    fea, bbox = torch.randn(1, 28, h, h, generator=g).cuda(), torch.randn(1, 4, h, h, generator=g).cuda()
+    cond = torch.randn(1, Tn, 40, generator=g).cuda()
+    want = diff.sample(fea, bbox, cond=cond, cond_scale=1.0)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+    try:
+        comm = TShardComm(dist, 0, 1, Tn, 0, Tn)
+        got = diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)
+        torch.cuda.synchronize()
+        st = comm.stats()
+    finally:
+        if created:
+            dist.destroy_process_group()
+    assert st["all_reduces"] > 0 and st["halo_exchanges"] > 0 and st["halo_bytes_sent"] == 0
+    assert log("tshard_rccl_world1_vs_unsharded", got, want) < 2e-5

@@ -19,14 +19,16 @@ TINY_KW = dict(dim=16, cond_dim=32, cond_aud=24, cond_pose=6, cond_eye=2, num_fr
 TT, S = 24, 3
 
 
-def _build(T):
+def _build(T, win=3, dim=16):
     sys.path.insert(0, ROOT)
     import dawn_pytorch_amd as D
     from oracle.ops_ref import RefOps
     d = np.load(os.path.join(ROOT, "tests", "golden", "tiny_unet.npz"))
     sd = {k[len("sd:denoise_fn."):]: torch.from_numpy(d[k]) for k in d.files if k.startswith("sd:")}
-    unet = D.DynamicNfUnet3D(default_num_frames=T, **TINY_KW)
-    unet.load_state_dict(sd)
+    unet = D.DynamicNfUnet3D(default_num_frames=T, **{**TINY_KW, "win_width": win, "dim": dim}, init_seed=3)
+    if dim == 16:
+        unet.load_state_dict(sd)            # the reference-golden weights; dim 64: deterministic random init (the fused
+                                            # 64-channel temporal / spatial layers and their sharded, segmented form)
     unet.ops = RefOps()
     diff = D.DynamicNfGaussianDiffusion(default_num_frames=T, denoise_fn=unet, num_frames=T, image_size=8,
                                         sampling_timesteps=S, use_dynamic_thres=True, ddim_sampling_eta=1.0)
@@ -42,37 +44,52 @@ def _inputs():
             torch.randn(1, TT, 32, generator=g))
 
 
-def _worker(rank, world, port, out_path):
+def _worker(rank, world, port, out_path, win=3, dim=16):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
     from dawn_pytorch_amd.tshard import TShardComm
     F = TT // world
-    diff = _build(F)
+    diff = _build(F, win, dim)
     fea, bbox, cond = _inputs()
     comm = TShardComm(dist, rank, world, TT, rank * F, F)
     out = diff.sample(fea, bbox, cond=cond[:, rank * F:(rank + 1) * F].contiguous(), cond_scale=1.0, comm=comm,
                       trace=True)
     qs = torch.stack([tr["s"][1] for tr in diff.last_trace[0]])
-    torch.save({"out": out, "qs": qs}, f"{out_path}.{rank}")
+    torch.save({"out": out, "qs": qs, "stats": comm.stats()}, f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_tshard_equals_unsharded(tmp_path):
+@pytest.mark.parametrize("world,win,dim", [(2, 3, 16), (3, 3, 16), (3, 8, 16), (4, 6, 16), (4, 9, 16), (2, 3, 64), (3, 8, 64)],
+                         ids=["w2", "w3-two-neighbours", "w3-F==win", "w4-F==win", "w4-F<win-multi-hop",
+                              "w2-dim64-fused-interior-first", "w3-dim64-F==win"])
+def test_tshard_equals_unsharded(tmp_path, world, win, dim):
+    """24 frames over `world` ranks (F = 12 / 8 / 6 frames per rank): window 3 (one neighbour per side), F == win (the halo
+    is the neighbour's whole shard) and F < win (the halo spans two ranks on each side)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out_path = str(tmp_path / "shard")
-    mp.spawn(_worker, args=(2, port, out_path), nprocs=2, join=True)
-    parts = [torch.load(f"{out_path}.{r}") for r in range(2)]
-    diff = _build(TT)
+    mp.spawn(_worker, args=(world, port, out_path, win, dim), nprocs=world, join=True)
+    parts = [torch.load(f"{out_path}.{r}") for r in range(world)]
+    diff = _build(TT, win, dim)
     fea, bbox, cond = _inputs()
     full = diff.sample(fea, bbox, cond=cond, cond_scale=1.0, trace=True)
     qs = torch.stack([tr["s"][1] for tr in diff.last_trace[0]])
     got = torch.cat([p["out"] for p in parts], dim=2)
-    # identical quantiles on both ranks and equal to the unsharded ones
-    torch.testing.assert_close(parts[0]["qs"], parts[1]["qs"], atol=0, rtol=0)
+    # identical quantiles on every rank and equal to the unsharded ones
+    for p in parts[1:]:
+        torch.testing.assert_close(parts[0]["qs"], p["qs"], atol=0, rtol=0)
     torch.testing.assert_close(parts[0]["qs"], qs, atol=1e-5, rtol=1e-5)
     torch.testing.assert_close(got, full, atol=2e-5, rtol=1e-5)
+    # communication accounting: 6 temporal attentions (init, 2 down, mid, 2 up) x S steps halo exchanges per rank; what is
+    # sent is received
+    st = [p["stats"] for p in parts]
+    assert all(s_["halo_exchanges"] == 6 * S for s_ in st)
+    assert sum(s_["halo_bytes_sent"] for s_ in st) == sum(s_["halo_bytes_received"] for s_ in st) > 0
+    F = TT // world
+    inner = st[1]                                      # a rank with neighbours on both sides
+    assert inner["halo_bytes_received"] == inner["halo_bytes_sent"] or world == 2 or win > F
+    assert all(s_["all_reduces"] > 0 for s_ in st)
