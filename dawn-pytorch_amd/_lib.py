@@ -81,6 +81,12 @@ SIGNATURES = {
     "dawn_warp_blend": [c_f, _i, _i, _i, c_f, _l, c_f, _i, _i, _i, c_f, c_f, c_f, _i, c_f, c_f],
     "dawn_final_conv_blend": [c_f, _i, _i, _i, _i, c_f, c_f, c_f, c_f, _l, c_f, _i, _i, c_f, c_f, _l, c_f],
     "dawn_frames_to_u8": [c_f, _l, _l, _d, _d, _d, _i, c_f, c_f],
+    "dawn_wave_normalize": [c_f, _l, c_f, c_f, c_f],
+    "dawn_hubert_conv0": [c_f, _l, c_f, c_f, _i, _i, _i, c_f, c_f],
+    "dawn_ln_affine_act": [c_f, _l, _i, c_f, c_f, _f, _i, c_f, c_f],
+    "dawn_add_act": [c_f, c_f, _i, _l, c_f, c_f],
+    "dawn_attn64": [c_f, _i, _i, c_f, c_f],
+    "dawn_interp_linear": [c_f, _l, _i, c_f, _l, c_f, c_f],
 }
 
 _lib = None

@@ -36,7 +36,7 @@ constexpr int DAWN_CONV_POLICY_DEFAULT = 0x580D;
 #ifdef DAWN_ABLATION
 constexpr int DAWN_CONV_POLICY_MASK = 0x000FFFFF;
 #else
-constexpr int DAWN_CONV_POLICY_MASK = 0x0000FFCF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x00F0FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
 static thread_local int g_last_nwg = 0;   // gridDim.x of the calling thread's last launch (= rows of gn_part it writes)
@@ -1059,8 +1059,14 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_
 template <int WN, int NT, int ABL>
 __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_conv_desc d, const int xcd_remap,
                                                                     const int TR, const int nf, const int P16,
-                                                                    const int WT) {
+                                                                    const int WT, const int stagger) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; buffer-resource builtins are device-only)
+    // Two workgroups share a CU (LDS-limited).  Launched together they stay phase-locked for the whole grid -- both in their
+    // prologue / epilogue (no MFMA) at the same time, then both in the main loop (sharing the matrix pipe).  Delaying the
+    // second resident set (blocks 256..511 with one workgroup per CU and round) by about half a tile puts one workgroup's
+    // prologue + epilogue under the other's main loop; later workgroups inherit the offset of the slot they replace.
+    if (stagger > 0 && blockIdx.x >= 256 && blockIdx.x < 512)
+        for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
     constexpr int NTHR = 256 * WN, BM = 256, BN = 64 * WN;
     constexpr int TM = 2, TN = 2;
     constexpr int MAXQ = (28 * 16 * 4 + NTHR - 1) / NTHR;      // patch quads per thread (P16 <= 448)
@@ -1415,12 +1421,13 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * (d.N / BN);
     const int remap = ((policy_of(d) & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
+    const int stagger = nwg >= 1024 ? ((policy_of(d) >> 20) & 15) : 0;     // policy bits 20..23: start delay in units of ~8k cycles
 #define LAUNCH_V2(NTV, ABLV)                                                                                          \
     do {                                                                                                              \
         (void)hipFuncSetAttribute((const void*)conv3x3_bf16_v2_kernel<WN, NTV, ABLV>,                                 \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
         hipLaunchKernelGGL((conv3x3_bf16_v2_kernel<WN, NTV, ABLV>), dim3(nwg), dim3(256 * WN), lds, s, d, remap, TR, nf, \
-                           P16, WT);                                                                                  \
+                           P16, WT, stagger);                                                                         \
     } while (0)
     g_last_nwg = nwg;
     if (nine) LAUNCH_V2(9, 0);

@@ -550,3 +550,59 @@ class HipOps:
         check(self.L.dawn_frames_to_u8(_p(vid), vid.stride(0), T * H * W, m[0], m[1], m[2], 1 if bgr else 0, _p(out),
                                        self._stream()), "dawn_frames_to_u8")
         return out
+
+    # ------------------------------------------------------------------ HuBERT audio features
+    def wave_normalize(self, x: Tensor) -> Tensor:
+        """Wav2Vec2FeatureExtractor(do_normalize): (x - mean) / sqrt(var + 1e-7) over the utterance."""
+        assert x.is_contiguous() and x.dim() == 1
+        self._require(x)
+        st = torch.empty(2, dtype=torch.float64, device=x.device)
+        out = torch.empty_like(x)
+        check(self.L.dawn_wave_normalize(_p(x), x.numel(), _p(st), _p(out), self._stream()), "dawn_wave_normalize")
+        return out
+
+    def hubert_conv0(self, x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int) -> Tensor:
+        """Conv1d(1, C, k, stride) of the waveform -> (T0, C) rows; w (C, k)."""
+        Cc, k = w.shape
+        assert x.is_contiguous() and w.is_contiguous()
+        self._require(x, w, bias)
+        T0 = (x.numel() - k) // stride + 1
+        out = self.empty(T0, Cc, like=x)
+        check(self.L.dawn_hubert_conv0(_p(x), x.numel(), _p(w), _p(bias), Cc, k, stride, _p(out), self._stream()),
+              "dawn_hubert_conv0")
+        return out
+
+    def ln_affine_act(self, x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, act: int = 0) -> Tensor:
+        """LayerNorm over the channels of every row, affine, act 0 none / 2 exact GELU."""
+        assert x.is_contiguous()
+        self._require(x, gamma, beta)
+        out = torch.empty_like(x)
+        check(self.L.dawn_ln_affine_act(_p(x), x.shape[0], x.shape[1], _p(gamma), _p(beta), eps, act, _p(out), self._stream()),
+              "dawn_ln_affine_act")
+        return out
+
+    def add_act(self, a: Optional[Tensor], b: Tensor, act: int = 0, out: Optional[Tensor] = None) -> Tensor:
+        """out = a + act(b) (a may be None); act 2 = exact GELU."""
+        assert b.is_contiguous() and (a is None or a.is_contiguous())
+        self._require(a, b)
+        out = torch.empty_like(b) if out is None else out
+        check(self.L.dawn_add_act(_p(a), _p(b), act, b.numel(), _p(out), self._stream()), "dawn_add_act")
+        return out
+
+    def attn64(self, qkv: Tensor, heads: int) -> Tensor:
+        """qkv (T, 3*heads*64) = [q | k | v] -> softmax(q k^T / 8) v per head, (T, heads*64)."""
+        T = qkv.shape[0]
+        assert qkv.is_contiguous() and qkv.shape[1] == 3 * heads * 64
+        self._require(qkv)
+        out = self.empty(T, heads * 64, like=qkv)
+        check(self.L.dawn_attn64(_p(qkv), T, heads, _p(out), self._stream()), "dawn_attn64")
+        return out
+
+    def interp_linear(self, y: Tensor, xi: Tensor) -> Tensor:
+        """scipy interp1d(arange(n), y, kind='linear', axis=0)(xi) as float32; xi float64 positions on the device."""
+        assert y.is_contiguous() and xi.dtype == torch.float64 and xi.is_contiguous()
+        self._require(y, xi)
+        out = self.empty(xi.numel(), y.shape[1], like=y)
+        check(self.L.dawn_interp_linear(_p(y), y.shape[0], y.shape[1], _p(xi), xi.numel(), _p(out), self._stream()),
+              "dawn_interp_linear")
+        return out

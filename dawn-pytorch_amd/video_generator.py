@@ -24,13 +24,14 @@ from .flow_diffusion import FlowDiffusion
 
 class VideoGenerator:
     def __init__(self, args, *, generator=None, frontend=None, config: Optional[dict] = None, device=None,
-                 allow_random_weights: bool = False, deterministic: bool = True):
+                 allow_random_weights: bool = False, deterministic: bool = True, hubert=None):
         """`allow_random_weights`: explicit opt-in (benches, tests) to run with the deterministic random-init denoiser
         when the configured checkpoint is absent; without it a missing checkpoint raises, as the reference's
         `torch.load` does (UVG:527).  `deterministic`: seed the sampler's counter-based noise with the config's
         `random_seed` (the reference never seeds torch); False draws from torch's global generator.
         NOTE (reference quirk, kept): `FlowDiffusion.face_loc_emb` is never saved / loaded by the reference (it is a
         sibling of `.diffusion`, FD:169), so it stays at its constructor initialisation here too."""
+        self.hubert = hubert              # hubert.HubertFeatures: stage 2 (process_audio, UVG:202-250) on the GPU (SURVEY 8f N3)
         self.allow_random_weights = bool(allow_random_weights) or bool(getattr(args, "allow_random_weights", False))
         self.deterministic = deterministic
         self.audio_path = args.audio_path
@@ -82,7 +83,15 @@ class VideoGenerator:
         return self._front("extract_pose")
 
     def process_audio(self):
-        return self._front("process_audio")
+        """UVG:202-250.  With a `hubert.HubertFeatures` object (built from the reference's own HubertModel state_dict) the
+        stage runs here: 16 kHz waveform -> HuBERT hidden states (chunked as UVG:466-501) -> 25 fps linear interpolation ->
+        `target_audio.npy`.  Otherwise it is delegated to `frontend` / the cache like the other upstream stages."""
+        if self.hubert is None or not (self.audio_path and osp.exists(self.audio_path)):
+            return self._front("process_audio")
+        speech = load_wav_16k(self.audio_path)
+        feats = self.hubert.process_audio(speech)
+        print(f'Frame count: {feats.shape[0]}')
+        np.save(self.audio_emb_path, feats)
 
     def generate_pose_blink(self):
         return self._front("generate_pose_blink")
@@ -160,6 +169,36 @@ class VideoGenerator:
         self.generate_pose_blink()
         print("4. Generating final video...")
         return self.generate_final_video()
+
+
+def load_wav_16k(path: str) -> np.ndarray:
+    """The reference converts with `ffmpeg -ar 16000` into a temp file and reads it with soundfile (UVG:220-227, 416-431):
+    float64 samples in [-1, 1).  Host I/O only: a 16 kHz PCM WAV is read directly (stdlib `wave`); anything else goes
+    through the same ffmpeg command first."""
+    import tempfile
+    import wave
+
+    def read_pcm(p):
+        with wave.open(p, "rb") as f:
+            sr, nch, sw, n = f.getframerate(), f.getnchannels(), f.getsampwidth(), f.getnframes()
+            raw = f.readframes(n)
+        if sw != 2:
+            raise ValueError(f"{p}: only 16-bit PCM WAV is read natively (sample width {sw})")
+        x = np.frombuffer(raw, dtype="<i2").astype(np.float64) / 32768.0        # soundfile's int16 -> float64 scaling
+        return (x.reshape(-1, nch) if nch > 1 else x), sr
+
+    try:
+        x, sr = read_pcm(path)
+        if sr == 16000:
+            return x
+    except (wave.Error, ValueError):
+        pass
+    with tempfile.NamedTemporaryFile("w", suffix=".wav") as tmp:
+        subprocess.run(["ffmpeg", "-i", path, "-ar", "16000", "-y", tmp.name], check=True, stdout=subprocess.DEVNULL,
+                       stderr=subprocess.DEVNULL)
+        x, sr = read_pcm(tmp.name)
+    assert sr == 16000
+    return x
 
 
 def parse_args(argv=None):

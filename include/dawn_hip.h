@@ -231,6 +231,24 @@ int dawn_final_conv_blend(const float* x, int T, int H, int W, int C, const floa
 int dawn_frames_to_u8(const float* vid, long plane, long npix, double mean0, double mean1, double mean2, int bgr,
                       unsigned char* out, void* stream);
 
+/* ---- HuBERT audio features + 25 fps interpolation (UVG:202-250, 433-501; transformers.HubertModel with
+ * feat_extract_norm = "layer", do_stable_layer_norm = True = hubert-large-ls960-ft).  Activations are (time, channels)
+ * rows; the conv layers 1..6, the grouped positional conv and every Linear run through dawn_conv_gemm. */
+/* Wav2Vec2FeatureExtractor(do_normalize): out = (x - mean) / sqrt(var + 1e-7) over the utterance; stats2 = 2 doubles scratch */
+int dawn_wave_normalize(const float* x, long n, double* stats2, float* out, void* stream);
+/* conv_layers[0]: Conv1d(1, C, k, stride) (+ bias) of the waveform -> ((n - k) / stride + 1, C); w (C, k) */
+int dawn_hubert_conv0(const float* x, long n, const float* w, const float* bias, int C, int k, int stride, float* out,
+                      void* stream);
+/* LayerNorm over the C channels of each row, affine; act 0 none, 2 exact (erf) GELU */
+int dawn_ln_affine_act(const float* x, long rows, int C, const float* gamma, const float* beta, float eps, int act,
+                       float* out, void* stream);
+/* out = a + act(b) elementwise (a may be NULL); act 0 none, 2 exact GELU */
+int dawn_add_act(const float* a, const float* b, int act, long n, float* out, void* stream);
+/* HubertAttention core: qkv (T, 3*heads*64) = [q | k | v] (q unscaled), full softmax over the T frames, out (T, heads*64) */
+int dawn_attn64(const float* qkv, int T, int heads, float* out, void* stream);
+/* scipy interp1d(arange(n), y (n, C) fp32, kind="linear", axis=0)(xi) -> out (m, C) fp32; xi (m) doubles on the device */
+int dawn_interp_linear(const float* y, long n, int C, const double* xi, long m, float* out, void* stream);
+
 /* ---- whole-path entry points (C-side evaluator, csrc/dawn_ctx.hip) ----------------------------------
  * A host in any language runs the denoiser with these five calls; the Python package keeps its own orchestration
  * (unet_forward.py, needed for the T-sharded path) and the GPU tests require both to agree bit for bit.

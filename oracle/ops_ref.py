@@ -60,6 +60,8 @@ class RefOps:
         if mode == 0:
             wk = _unpack(w).reshape(KH, KW, Cin, N).permute(3, 2, 0, 1)
             y = F_.conv2d(img, wk, None, stride=stride, padding=pad)
+            if y.shape[-2] >= Ho and y.shape[-1] >= Wo:
+                y = y[:, :, :Ho, :Wo]            # the kernel computes the first (Ho, Wo) outputs only (HuBERT's SamePad drop)
         else:
             # 4 phase blocks (py,px) of 2x2 taps -> rebuild the ConvTranspose2d kernel (Cin, N, 4, 4)
             ksel = ((1, 3), (2, 0))
@@ -448,3 +450,35 @@ class RefOps:
         if bgr:
             frame = frame[..., ::-1].copy()
         return torch.from_numpy(frame)
+
+    # ------------------------------------------------------------------ HuBERT audio features
+    def wave_normalize(self, x):
+        x = x.float()
+        return (x - x.mean()) / torch.sqrt(x.var(unbiased=False) + 1e-7)
+
+    def hubert_conv0(self, x, w, bias, stride):
+        y = F_.conv1d(x[None, None], w[:, None, :], bias, stride=stride)[0]          # (C, T0)
+        return y.t().contiguous()
+
+    def ln_affine_act(self, x, gamma, beta, eps=1e-5, act=0):
+        y = F_.layer_norm(x, (x.shape[1],), gamma, beta, eps)
+        return F_.gelu(y) if act == 2 else y
+
+    def add_act(self, a, b, act=0, out=None):
+        y = F_.gelu(b) if act == 2 else b
+        y = y if a is None else a + y
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
+    def attn64(self, qkv, heads):
+        T_ = qkv.shape[0]
+        q, k, v = (t.reshape(T_, heads, 64).transpose(0, 1) for t in qkv.chunk(3, dim=1))
+        att = torch.softmax((q * 0.125) @ k.transpose(1, 2), dim=-1)
+        return (att @ v).transpose(0, 1).reshape(T_, heads * 64).contiguous()
+
+    def interp_linear(self, y, xi):
+        from scipy.interpolate import interp1d
+        f = interp1d(np.arange(y.shape[0]), y.cpu().numpy(), kind="linear", axis=0)
+        return torch.from_numpy(f(xi.cpu().numpy()).astype(np.float32))
