@@ -36,7 +36,7 @@ constexpr int DAWN_CONV_POLICY_DEFAULT = 0x580D;
 #ifdef DAWN_ABLATION
 constexpr int DAWN_CONV_POLICY_MASK = 0x000FFFFF;
 #else
-constexpr int DAWN_CONV_POLICY_MASK = 0x00F0FFCF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x00F1FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
 static thread_local int g_last_nwg = 0;   // gridDim.x of the calling thread's last launch (= rows of gn_part it writes)
@@ -1450,14 +1450,20 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
 // the A rows of stage s+2 are in flight as register loads, those of stage s+1 are split between the MFMAs of
 // stage s and written to the idle plane buffer, the pre-split weights arrive by LDS-DMA one stage ahead -- one
 // barrier per 48 MFMAs per wave.  Accumulated transposed (lane = row) -> 16-byte row-segment stores.
-template <int NT, int WN>
-__global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_desc d, const long M) {
+template <int NT, int WN, int CFG = 0>
+__global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(const dawn_conv_desc d, const long M) {
 #if __HIP_DEVICE_COMPILE__
     // BN = 64*WN output columns, 4*WN waves (64 x 64 each).  WN = 1 serves N % 64 == 0 (to_q: 192 columns, the 64-channel
     // res_conv) and small tile counts; the A rows may come from two channel-concatenated sources (stage s reads in0 while
     // 32 s < C0, in1 afterwards) -- the up-path res_conv / to_q of cat[x, skip] without materialising the cat.
-    constexpr int BM = 256, BN = 64 * WN, NTHR = 256 * WN, NW = 4 * WN, TM = 2, TN = 2;
-    constexpr int NQ = 2048 / NTHR;                            // A quads per thread per stage (4 or 8)
+    // CFG 1: 128 x 64 tile, 4 waves as 2 (M) x 2 (N) of 64 x 32 each -- 77 KB of LDS, so TWO workgroups share a CU and one's
+    // A-row fetch / epilogue stores overlap the other's MFMAs.  The 256-row tiles hold a CU alone (126..150 KB): with the
+    // short K of the projections (4..16 stages) a tile is fetch -> MFMA -> store in sequence, each ~5 us, and the per-CU
+    // share of HBM bandwidth (25 GB/s) is idle two thirds of the time.
+    constexpr int BM = CFG ? 128 : 256, BN = CFG ? 64 : 64 * WN, NTHR = CFG ? 256 : 256 * WN, NW = CFG ? 4 : 4 * WN;
+    constexpr int WNN = CFG ? 2 : WN;                          // waves along N
+    constexpr int TM = 2, TN = CFG ? 1 : 2;
+    constexpr int NQ = BM * 8 / NTHR;                          // A quads per thread per stage (4 or 8)
     constexpr int HPS = BM * 16 + 128;                         // half-plane stride (bytes)
     constexpr int PSZ = 2 * 6 * HPS;                           // planes of one stage (2 sub-chunks of 16 channels)
     constexpr int BSZ = 2 * 6 * BN * 16;                       // weights of one stage
@@ -1469,7 +1475,7 @@ __global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    const int wm = wave / WNN, wn = wave % WNN;
     const int l31 = lane & 31, half = lane >> 5;
     const int K = d.C0 + d.C1;
     const int nS = K / 32, nS0 = d.C0 / 32;
@@ -1483,7 +1489,7 @@ __global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_
     const __amdgpu_buffer_rsrc_t rsa1 = __builtin_amdgcn_make_buffer_rsrc(
         (void*)((d.in1 ? d.in1 : d.in0) + m0 * ld1), 0, BM * ld1 * 4, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, (K / 16) * 6 * d.N * 16, 0x00020000);
-    // A quads of a stage: 256 rows x 8 quads = 2048 -> NQ per thread: q = tid + NTHR i -> row = q >> 3, quad = q & 7
+    // A quads of a stage: BM rows x 8 quads -> NQ per thread: q = tid + NTHR i -> row = q >> 3, quad = q & 7
     const int row0 = tid >> 3, qoff = (tid & 7) * 16;
     unsigned voffB[3];
 #pragma unroll
@@ -1578,7 +1584,7 @@ __global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
                     fb[j][RB[g]] = *reinterpret_cast<const bf16x8*>(
-                        Bb + ((size_t)((sub * 6 + RB[g] * 2 + half) * BN + wn * 64 + j * 32 + l31)) * 16);
+                        Bb + ((size_t)((sub * 6 + RB[g] * 2 + half) * BN + wn * (32 * TN) + j * 32 + l31)) * 16);
             }
             constexpr int PA9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
             constexpr int PB9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
@@ -1615,7 +1621,7 @@ __global__ __launch_bounds__(256 * WN) void gemm1x1_bf16_kernel(const dawn_conv_
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
-                const int n = n0 + wn * 64 + j * 32 + 8 * g + 4 * half;
+                const int n = n0 + wn * (32 * TN) + j * 32 + 8 * g + 4 * half;
                 f32x4 v = {acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]};
                 if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
                 if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
@@ -1646,6 +1652,14 @@ void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
     }
 }
 
+void launch_gemm1x1_bf16_small(const dawn_conv_desc& d, long M, hipStream_t s) {
+    const size_t lds = (size_t)2 * 2 * 6 * (128 * 16 + 128) + (size_t)2 * 2 * 6 * 64 * 16;      // 76.8 KB: two per CU
+    const int nwg = (int)(M / 128) * (d.N / 64);
+    g_last_nwg = nwg;
+    (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<6, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((gemm1x1_bf16_kernel<6, 1, 1>), dim3(nwg), dim3(256), lds, s, d, M);
+}
+
 // Which split-operand 1x1 GEMM tile (0 = none: fp32 kernel, 1 = 256 x 64, 2 = 256 x 128) serves an (M x N) projection of
 // C0 (+ C1) channels.  Tile policy from the per-shape table of the benchmark (profiles/r1_final_gemm1x1_policy.txt):
 // 256 x 128 tiles when they fill the chip; 256 x 64 tiles for N = 192 and for the small GEMMs that would leave more than
@@ -1653,12 +1667,19 @@ void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
 // the fp32 kernel (many small workgroups hide HBM latency better than one 126 KB-LDS workgroup per CU).
 int gemm1x1_split_plan(long M, int N, int C0, int C1) {
     if (C0 % 32 != 0 || C1 % 32 != 0 || N % 64 != 0 || M % 256 != 0 || M < 12800) return 0;
+    int plan;
     if (N % 128 == 0) {
         const long t2 = (M / 256) * (N / 128);
-        if (t2 >= 256 || (t2 >= 128 && M >= 51200)) return 2;
-        return t2 < 128 ? 1 : 0;
+        if (t2 >= 256 || (t2 >= 128 && M >= 51200)) plan = 2;
+        else plan = t2 < 128 ? 1 : 0;
+    } else {
+        plan = N == 64 ? 0 : 1;
     }
-    return N == 64 ? 0 : 1;
+    // plan 3 = 128 x 64 tiles, two workgroups per CU (fetch / store of one under the MFMAs of the other): measured per shape
+    // at the benchmark (profiles/r2_gemm1x1_tiles_*.txt) it wins 12..30 % on the N = 192 to_q projections, on the M = 12800
+    // GEMMs and on the long thin N = 128 ones; the N = 768 qkv GEMMs stay on the 256-row tiles (7..13 % better there)
+    if (plan != 0 && (N % 128 != 0 || M <= 12800 || (N == 128 && M >= 204800))) plan = 3;
+    return plan;
 }
 
 bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
@@ -1667,7 +1688,13 @@ bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
         (long)d.ld0 * 256 * 4 >= (1L << 31) || (long)d.ld1 * 256 * 4 >= (1L << 31))
         return false;
     const int plan = gemm1x1_split_plan(M, d.N, d.C0, d.C1);
-    if (plan == 2) launch_gemm1x1_bf16<2>(d, M, s);
+    // policy bit 0x8000: 128 x 64 tiles for every eligible shape; 0x10000 (A/B only): never (the round-1 tile policy)
+    if (plan != 0 && ((policy_of(d) & 0x8000) || (plan == 3 && !(policy_of(d) & 0x10000)))) launch_gemm1x1_bf16_small(d, M, s);
+    else if (plan == 3) {                            // 0x10000: the round-1 choice for these shapes
+        if (d.N % 128 == 0 && (M / 256) * (d.N / 128) >= 128) launch_gemm1x1_bf16<2>(d, M, s);
+        else launch_gemm1x1_bf16<1>(d, M, s);
+    }
+    else if (plan == 2) launch_gemm1x1_bf16<2>(d, M, s);
     else if (plan == 1) launch_gemm1x1_bf16<1>(d, M, s);
     else return false;
     return true;

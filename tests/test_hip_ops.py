@@ -193,12 +193,12 @@ def test_gemm1x1_split(hip, ref, M, K, N, res, bias):
         kw["bias"] = rnd(N, seed=4)
     want = ref.conv_gemm(x, w, N, **kw)
     gkw = {k_: (v.cuda() if torch.is_tensor(v) else v) for k_, v in kw.items()}
-    for variant in (22541, 30733):
+    for variant in (22541, 30733, 22541 | 0x8000):           # shipped policy, 9 cross terms, 128 x 64 tiles (2 WG / CU)
         hip.conv_policy = variant
         got = hip.conv_gemm(x.cuda(), w.cuda(), N, w_bf3=pack_bf3(unpack_kn(w)).cuda(), **gkw)
         torch.cuda.synchronize()
         check(f"gemm1x1_split/M{M}_K{K}_N{N}/v{variant}", got, want)
-    hip.conv_policy = 22541
+    hip.conv_policy = 0
 
 
 @pytest.mark.parametrize("M,C0,C1,N,extra", [(51200, 64, 64, 64, "tr"), (12800, 512, 512, 256, "tr"), (25600, 128, 0, 192, ""),
@@ -242,6 +242,11 @@ def test_gemm1x1_split_variants(hip, ref, M, C0, C1, N, extra):
     got = hip.conv_gemm(x0g, w.cuda(), N, in1=None if x1 is None else x1.cuda(), w_bf3=pack_bf3(unpack_kn(w)).cuda(), out=out, **gkw)
     torch.cuda.synchronize()
     check(f"gemm1x1_split_variants/M{M}_C{C0}+{C1}_N{N}_{extra}", got, want)
+    hip.conv_policy = 22541 | 0x8000                          # the 128 x 64-tile configuration of the same kernel
+    got_small = hip.conv_gemm(x0g, w.cuda(), N, in1=None if x1 is None else x1.cuda(), w_bf3=pack_bf3(unpack_kn(w)).cuda(),
+                              out=None if out is None else torch.empty_like(out), **gkw)
+    hip.conv_policy = 0
+    check(f"gemm1x1_split_variants_128x64/M{M}_C{C0}+{C1}_N{N}_{extra}", got_small, want)
     if "rowstats" in extra:            # with the statistics of the HIP LayerNorm kernel itself (the product's pairing)
         st = hip.ln_rowstats(x0.cuda(), None if x1 is None else x1.cuda())
         got_hs = hip.conv_gemm(x0.cuda(), w.cuda(), N, in1=None if x1 is None else x1.cuda(), row_stats=st,

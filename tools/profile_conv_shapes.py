@@ -13,6 +13,7 @@ ap.add_argument("--frames", type=int, default=200)
 ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--iters", type=int, default=3)
 ap.add_argument("--no-overlap", action="store_true")
+ap.add_argument("--policy", type=lambda v: int(v, 0), default=0)
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 T, h = a.frames, a.res // 4
@@ -21,6 +22,7 @@ fea, bbox, cond = bench.synthetic_inputs(T, h, dev)
 ops = unet._ops()
 if a.no_overlap:
     ops.overlap = False
+ops.conv_policy = a.policy
 from dawn_pytorch_amd.unet_forward import unet_forward
 P = unet.packed()
 cs = unet.build_clip(torch.cat((fea, bbox), 1)[0].contiguous(), cond[0].contiguous())
