@@ -1421,7 +1421,10 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * (d.N / BN);
     const int remap = ((policy_of(d) & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
-    const int stagger = nwg >= 1024 ? ((policy_of(d) >> 20) & 15) : 0;     // policy bits 20..23: start delay in units of ~8k cycles
+    // start delay of the second resident workgroup set in units of ~8k cycles (policy bits 20..23; default 0 = none): in
+    // isolation it takes 8..11 % off the 64-input-channel launches (354 -> 316..328 us, profiles/r2_conv_stagger.txt) and nothing
+    // off deeper K; inside an evaluation, next to the side stream's kernels, it changes nothing (385.4 vs 384.5 us): off
+    const int stagger = nwg >= 1024 ? ((policy_of(d) >> 20) & 15) : 0;
 #define LAUNCH_V2(NTV, ABLV)                                                                                          \
     do {                                                                                                              \
         (void)hipFuncSetAttribute((const void*)conv3x3_bf16_v2_kernel<WN, NTV, ABLV>,                                 \

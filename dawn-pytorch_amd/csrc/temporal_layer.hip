@@ -572,19 +572,15 @@ __device__ __forceinline__ void proj_KV_split(const __amdgpu_buffer_rsrc_t rw, u
 
 // the same, as two passes: K^T first (returned early so that the caller's rotary + split of K runs in the shadow of the V
 // pass) -- the V pass is `proj_V_pass`; weight fragments of both are requested up front by the caller
-struct KVWeights { bf16x8t wk[4][3], wv[4][3]; };
-__device__ __forceinline__ void kv_weights_request(const __amdgpu_buffer_rsrc_t rw, unsigned wvoff, int colk, int colv, KVWeights& w) {
+struct KVWeights { bf16x8t w[4][3]; };
+template <bool VPASS>
+__device__ __forceinline__ void kv_weights_request(const __amdgpu_buffer_rsrc_t rw, unsigned wvoff, int col, KVWeights& w) {
     constexpr int WS = 2 * 768 * 16;
 #pragma unroll
     for (int kc = 0; kc < 4; ++kc)
 #pragma unroll
         for (int pl = 0; pl < 3; ++pl)
-            w.wk[kc][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colk * 16 + (kc * 3 + pl) * WS, 0));
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl)
-            w.wv[kc][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, colv * 16 + (kc * 3 + pl) * WS, 0));
+            w.w[kc][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rw, wvoff, col * 16 + (kc * 3 + pl) * WS, 0));
     __builtin_amdgcn_sched_barrier(0);
 }
 template <bool VPASS>
@@ -599,8 +595,8 @@ __device__ __forceinline__ f32x16 proj_pass(const KVWeights& w, const unsigned c
             xs[pl] = *reinterpret_cast<const bf16x8t*>(xp + (size_t)((pl * 4 + kc) * 2) * FA * 16);
 #pragma unroll
         for (int u = 0; u < 6; ++u) {
-            if (VPASS) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[PX[u]], w.wv[kc][PW[u]], d, 0, 0, 0);    // D   = X . W
-            else d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.wk[kc][PW[u]], xs[PX[u]], d, 0, 0, 0);          // D^T = W^T . X^T
+            if (VPASS) d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xs[PX[u]], w.w[kc][PW[u]], d, 0, 0, 0);     // D   = X . W
+            else d = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w.w[kc][PW[u]], xs[PX[u]], d, 0, 0, 0);           // D^T = W^T . X^T
         }
     }
     return d;
@@ -631,7 +627,7 @@ __device__ __forceinline__ f32x16 proj_Q_split(const __amdgpu_buffer_rsrc_t rw, 
     return d;
 }
 
-template <int NKT, int SCHED, bool HL, bool OB, int FAC>
+template <int NKT, int SCHED, bool HL, bool OB, int FAC, bool KVI>
 __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     const float* __restrict__ x, int Fext, int HW, int q0, int Fq, int win, const unsigned short* __restrict__ wqkv_s,
     const float* __restrict__ wout, const unsigned short* __restrict__ wout_sp, const float* __restrict__ rcos,
@@ -719,6 +715,72 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     for (int h = 0; h < HEADS; ++h) {
         if (h < 2) TSTAMP();   // head start
         // ---- K^T / V projection of every frame row; rotary on K; both split into bf16 planes in LDS
+        if (KVI) {
+        // 2 * nrt work items (row tile, K | V) over the 8 waves: a wave per 32-row tile left the SIMDs that host two of the
+        // 6..7 tiles with twice the work of the others (7.7 k vs 5.9 k cycles per head in the s_memtime profile)
+        for (int it = wave; it < 2 * nrt; it += 8) {
+            const int rt = it >> 1;
+            const bool isV = it & 1;                                    // wave-uniform
+            const int j = 32 * rt + l31;
+            const int jc = min(j, Fext - 1);
+            const unsigned char* xrow = Xp + ((size_t)half * FA + jc) * 16;
+            KVWeights kvw;
+            if (!isV) {
+                float2 kcs[4], ksn[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    kcs[c] = *reinterpret_cast<const float2*>(rcos + jc * 16 + 4 * c + 2 * half);
+                    ksn[c] = *reinterpret_cast<const float2*>(rsin + jc * 16 + 4 * c + 2 * half);
+                }
+                kv_weights_request<false>(rsw, wvoff, HEADS * DH + h * DH, kvw);
+                const f32x16 kT = proj_pass<false>(kvw, xrow, FA);
+#pragma unroll
+                for (int kc = 0; kc < 2; ++kc) {
+                    float kr[8];
+#pragma unroll
+                    for (int cc = 0; cc < 2; ++cc) {
+                        const int c = 2 * kc + cc;
+                        const float2 cs = kcs[c], sn = ksn[c];
+                        kr[4 * cc] = kT[4 * c] * cs.x - kT[4 * c + 1] * sn.x;
+                        kr[4 * cc + 1] = kT[4 * c + 1] * cs.x + kT[4 * c] * sn.x;
+                        kr[4 * cc + 2] = kT[4 * c + 2] * cs.y - kT[4 * c + 3] * sn.y;
+                        kr[4 * cc + 3] = kT[4 * c + 3] * cs.y + kT[4 * c + 2] * sn.y;
+                    }
+                    bf16x8t k1, k2, k3;
+                    split3_oct(kr, k1, k2, k3);
+                    if (j < Fext) {
+                        unsigned char* dst = Kp + ((size_t)(kc * 2 + half) * FA + j) * 16;
+                        *reinterpret_cast<bf16x8t*>(dst) = k1;
+                        *reinterpret_cast<bf16x8t*>(dst + (size_t)4 * FA * 16) = k2;
+                        *reinterpret_cast<bf16x8t*>(dst + (size_t)8 * FA * 16) = k3;
+                    }
+                }
+            } else {
+                kv_weights_request<true>(rsw, wvoff, 2 * HEADS * DH + h * DH, kvw);
+                const f32x16 vv = proj_pass<true>(kvw, xrow, FA);
+                // V: lane = feature d = l31, registers 8g..8g+7 = keys 32 rt + 16 g + 4 half + (i & 3) + 8 (i >> 2)
+#pragma unroll
+                for (int g = 0; g < 2; ++g) {
+                    float vr[8];
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) vr[i] = vv[8 * g + i];
+                    if (32 * rt + 32 > Fext) {                          // wave-uniform: only the last row tile has padded keys
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) {
+                            const int key = 32 * rt + 16 * g + 4 * half + (i & 3) + 8 * (i >> 2);
+                            vr[i] = key < Fext ? vr[i] : 0.f;           // finite zeros (their P is exactly 0)
+                        }
+                    }
+                    bf16x8t v1, v2, v3;
+                    split3_oct(vr, v1, v2, v3);
+                    unsigned char* dst = Vt + ((size_t)((2 * rt + g) * 2 + half) * 32 + l31) * 16;
+                    *reinterpret_cast<bf16x8t*>(dst) = v1;
+                    *reinterpret_cast<bf16x8t*>(dst + (size_t)NBV * 64 * 16) = v2;
+                    *reinterpret_cast<bf16x8t*>(dst + (size_t)2 * NBV * 64 * 16) = v3;
+                }
+            }
+        }
+        } else {
         for (int rt = wave; rt < nrt; rt += 8) {
             const int j = 32 * rt + l31;
             const int jc = min(j, Fext - 1);
@@ -728,11 +790,12 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                 kcs[c] = *reinterpret_cast<const float2*>(rcos + jc * 16 + 4 * c + 2 * half);
                 ksn[c] = *reinterpret_cast<const float2*>(rsin + jc * 16 + 4 * c + 2 * half);
             }
-            KVWeights kvw;
-            kv_weights_request(rsw, wvoff, HEADS * DH + h * DH, 2 * HEADS * DH + h * DH, kvw);
+            KVWeights kvk, kvv;
+            kv_weights_request<false>(rsw, wvoff, HEADS * DH + h * DH, kvk);
+            kv_weights_request<true>(rsw, wvoff, 2 * HEADS * DH + h * DH, kvv);
             const unsigned char* xrow = Xp + ((size_t)half * FA + jc) * 16;
-            const f32x16 kT = proj_pass<false>(kvw, xrow, FA);
-            const f32x16 vv = proj_pass<true>(kvw, xrow, FA);       // its MFMAs cover the rotary + split of K below
+            const f32x16 kT = proj_pass<false>(kvk, xrow, FA);
+            const f32x16 vv = proj_pass<true>(kvv, xrow, FA);       // its MFMAs cover the rotary + split of K below
 #pragma unroll
             for (int kc = 0; kc < 2; ++kc) {
                 float kr[8];
@@ -774,6 +837,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                 *reinterpret_cast<bf16x8t*>(dst + (size_t)NBV * 64 * 16) = v2;
                 *reinterpret_cast<bf16x8t*>(dst + (size_t)2 * NBV * 64 * 16) = v3;
             }
+        }
         }
         if (h < 2) TSTAMP();   // K/V projected (before barrier)
         __syncthreads();
@@ -1062,13 +1126,17 @@ extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int 
     const unsigned short* wsp = (const unsigned short*)wout_bf3p;
     const bool hl = 32 + 2 * win <= 32 * nkt - 16;       // the upper 16 keys of the last key tile are never in a window
     const bool ob = wout_bf3p != nullptr && !(flags & 32);
+#define LAUNCH_TL3D(N, SC, HLV, OBV, FACV, KVIV)                                                               \
+    do {                                                                                                       \
+        (void)hipFuncSetAttribute((const void*)temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV, FACV, KVIV>,    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
+        hipLaunchKernelGGL((temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV, FACV, KVIV>), dim3(HW), dim3(512), \
+                           lds, s, x, Fext, HW, q0, Fq, win, ws, wout, wsp, rot_cos, rot_sin, band, eps, out,  \
+                           nrt, delta);                                                                        \
+    } while (0)
 #define LAUNCH_TL3C(N, SC, HLV, OBV, FACV)                                                                     \
     do {                                                                                                       \
-        (void)hipFuncSetAttribute((const void*)temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV, FACV>,          \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                       \
-        hipLaunchKernelGGL((temporal_layer_c64_bf16_kernel<N, SC, HLV, OBV, FACV>), dim3(HW), dim3(512), lds,  \
-                           s, x, Fext, HW, q0, Fq, win, ws, wout, wsp, rot_cos, rot_sin, band, eps, out, nrt,  \
-                           delta);                                                                             \
+        if (flags & 128) LAUNCH_TL3D(N, SC, HLV, OBV, FACV, false); else LAUNCH_TL3D(N, SC, HLV, OBV, FACV, true); \
     } while (0)
 #define LAUNCH_TL3B(N, SC, HLV, OBV)                                                                           \
     do {                                                                                                       \
@@ -1112,6 +1180,7 @@ extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int 
 #undef LAUNCH_TL3
 #undef LAUNCH_TL3B
 #undef LAUNCH_TL3C
+#undef LAUNCH_TL3D
     DAWN_LAUNCH_CHECK();
     return 0;
 }
