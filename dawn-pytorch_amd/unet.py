@@ -243,8 +243,12 @@ class Unet3D(nn.Module):
         self.null_cond_mask = torch.full((B, self.num_frames), bool(null_cond_prob), dtype=torch.bool, device=x.device)
         if null_cond_prob:
             cond = torch.zeros_like(cond)         # learn_null_cond=False: null embedding is zeros (MT:920)
-        if not torch.equal(x[:, 3:, 0], x[:, 3:, -1]):
-            raise NotImplementedError("fea/bbox channels must be identical for every frame (MT:1167)")
+        # input validation (the hoisted init-conv part assumes it): EVERY frame carries the same fea / bbox channels, as
+        # `ddim_sample` builds them (MT:1167); checked in 32-frame slabs to bound the temporary
+        ref0 = x[:, 3:, :1]
+        for f0 in range(0, T, 32):
+            if not bool((x[:, 3:, f0:f0 + 32] == ref0).all()):
+                raise NotImplementedError("fea/bbox channels must be identical for every frame (MT:1167)")
         ops, P = self._ops(), self.packed()
         outs = []
         for b in range(B):

@@ -85,6 +85,19 @@ def test_module_api_with_ref_ops(tiny):
     torch.testing.assert_close(y2, T(g["y_cond_scale_2p5"]), atol=1e-4, rtol=1e-5)
 
 
+def test_forward_rejects_frame_varying_fea(tiny):
+    """The operator contract requires frame-invariant fea / bbox channels (MT:1167): any frame that differs -- not only
+    the first or last -- is an error, never silently wrong output."""
+    g, sd = tiny
+    unet = D.DynamicNfUnet3D(default_num_frames=12, **TINY_KW)
+    unet.load_state_dict({k[len("denoise_fn."):]: v for k, v in sd.items()})
+    unet.ops = RefOps()
+    x = T(g["x"]).clone()
+    x[0, 7, 5, 2, 3] += 1.0                                   # one value of one middle frame
+    with pytest.raises(NotImplementedError):
+        unet.forward_with_cond_scale(x, T(g["time"]), cond=T(g["cond"]), cond_scale=1.0)
+
+
 def test_ddim_matches_golden(tiny):
     g, sd = tiny
     d = load_golden("ddim_tiny.npz")
