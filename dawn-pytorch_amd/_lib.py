@@ -63,6 +63,7 @@ SIGNATURES = {
     "dawn_temporal_layer_c64_ex": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, _f, c_f, _i, c_f],
     "dawn_sla_context": [c_f, _i, _i, c_f, c_f],
     "dawn_sla_apply": [c_f, c_f, _i, _i, c_f, c_f],
+    "dawn_sla_ws_floats": [_i, _i, _i],
     "dawn_sla_layer_c64": [c_f, _i, _i, c_f, c_f, c_f, c_f, _f, c_f, c_f, c_f],
     "dawn_frame_attn": [c_f, _i, _i, c_f, c_f],
     "dawn_init_conv_x": [c_f, c_f, c_f, _i, _i, _i, _i, c_f, c_f],
@@ -96,6 +97,9 @@ class DawnHipError(RuntimeError):
     pass
 
 
+LONG_RESULT = {"dawn_sla_ws_floats"}       # entry points that return a size (long), not a status
+
+
 def lib() -> C.CDLL:
     """Load libdawn_hip.so once; raise (never fall back) if it is absent."""
     global _lib
@@ -110,7 +114,7 @@ def lib() -> C.CDLL:
         for name, args in SIGNATURES.items():
             fn = getattr(L, name)
             fn.argtypes = args
-            fn.restype = _i
+            fn.restype = _l if name in LONG_RESULT else _i
         _lib = L
     return _lib
 

@@ -505,7 +505,7 @@ struct Eval {
         const int HW = H * W;
         T2 o;
         if (a.C == 64) {
-            float* ws = falloc((size_t)Fr * 8 * 8 * 64 * 4);
+            float* ws = falloc((size_t)dawn_sla_ws_floats(Fr, HW, a.wqkv_s != nullptr));
             o = t2(x.rows, 64);
             LAUNCH(dawn_sla_layer_c64(x.p, Fr, HW, a.wqkv, a.wqkv_s, a.wout, a.bout, 1e-5f, ws, o.p, cur));
             A.free(ws);

@@ -177,12 +177,18 @@ __device__ __forceinline__ void split3_quad(const f32x4 v, uint2& p1, uint2& p2,
     p3 = *reinterpret_cast<uint2*>(&h3);
 }
 
-// planes of one 32-pixel tile: [plane 3][chunk 4][k-half 2][px 32] x 16 B (8 channels) = 12 KB
-__device__ __forceinline__ void stage_tile_bf3(const float* __restrict__ xf, int n0, int HW, float eps, unsigned char* Pt, int tid) {
+// planes of one 32-pixel tile: [plane 3][chunk 4][k-half 2][px 32] x 16 B (8 channels) = 12 KB.  The tile is requested one
+// iteration ahead (stage_load: thread t -> pixel t>>4, float4 t&15) and normalised / split / written after the MFMAs of the
+// current tile were issued (stage_store), so the HBM latency of the request hides under a whole tile of matrix work.
+__device__ __forceinline__ f32x4 stage_load(const float* __restrict__ xf, int n0, int HW, int tid) {
+    const int n = n0 + (tid >> 4);
+    f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    if (n < HW) v = *reinterpret_cast<const f32x4*>(xf + (long)n * C + (tid & 15) * 4);
+    return v;
+}
+__device__ __forceinline__ void stage_store(const f32x4 v, int n0, int HW, float eps, unsigned char* Pt, int tid) {
     const int px = tid >> 4, sub = tid & 15;
     const int n = n0 + px;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (n < HW) v = *reinterpret_cast<const f32x4*>(xf + (long)n * C + sub * 4);
     float s = v.x + v.y + v.z + v.w;
     s = wave_sum(s, 16);
     const float mu = s * (1.0f / C);
@@ -199,112 +205,6 @@ __device__ __forceinline__ void stage_tile_bf3(const float* __restrict__ xf, int
     *reinterpret_cast<uint2*>(dst) = p1;
     *reinterpret_cast<uint2*>(dst + 4096) = p2;
     *reinterpret_cast<uint2*>(dst + 8192) = p3;
-}
-
-__global__ __launch_bounds__(512) void sla_c64_context_bf16_kernel(const float* __restrict__ x, int HW,
-                                                                   const unsigned short* __restrict__ wqkv_s,
-                                                                   const float* __restrict__ wout, float eps,
-                                                                   float* __restrict__ Mout) {
-    __shared__ __attribute__((aligned(16))) unsigned char Ps[2][12288];
-    __shared__ __attribute__((aligned(16))) float cT[HEADS][32 * 36];
-    __shared__ float dens[HEADS * 32];
-    const int tid = threadIdx.x;
-    const int h = tid >> 6, lane = tid & 63;
-    const int l31 = lane & 31, half = lane >> 5;
-    const int f = blockIdx.x;
-    const float* xf = x + (long)f * HW * C;
-    const int ntiles = (HW + 31) >> 5;
-
-    // weight pieces of this wave's head (B operands: lane column = feature, 8 channels of the chunk per k-half)
-    bf16x8s wk[4][3], wv[4][3];
-#pragma unroll
-    for (int kc = 0; kc < 4; ++kc)
-#pragma unroll
-        for (int pl = 0; pl < 3; ++pl) {
-            const size_t base = ((size_t)((kc * 3 + pl) * 2 + half) * QKVN) * 8;
-            wk[kc][pl] = *reinterpret_cast<const bf16x8s*>(wqkv_s + base + (size_t)(HEADS * DH + h * DH + l31) * 8);
-            wv[kc][pl] = *reinterpret_cast<const bf16x8s*>(wqkv_s + base + (size_t)(2 * HEADS * DH + h * DH + l31) * 8);
-        }
-
-    f32x16 ctx = z16();
-    float den = 0.f, mx = -3.0e38f;
-    stage_tile_bf3(xf, 0, HW, eps, Ps[0], tid);
-    __syncthreads();
-    for (int t = 0; t < ntiles; ++t) {
-        if (t + 1 < ntiles) stage_tile_bf3(xf, 32 * (t + 1), HW, eps, Ps[(t + 1) & 1], tid);
-        const unsigned char* Pt = Ps[t & 1];
-        f32x16 kt = z16(), vt = z16();
-        constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
-#pragma unroll
-        for (int kc = 0; kc < 4; ++kc) {
-            bf16x8s xa[3];
-#pragma unroll
-            for (int pl = 0; pl < 3; ++pl)
-                xa[pl] = *reinterpret_cast<const bf16x8s*>(Pt + pl * 4096 + ((size_t)((kc * 2 + half) * 32 + l31)) * 16);
-#pragma unroll
-            for (int u = 0; u < 6; ++u) {
-                kt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[u]], wk[kc][PB[u]], kt, 0, 0, 0);
-                vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[u]], wv[kc][PB[u]], vt, 0, 0, 0);
-            }
-        }
-        // running column max (lane column = feature d, rows = pixels of the tile)
-        float tm = -3.0e38f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (n < HW) tm = fmaxf(tm, kt[r]);
-        }
-        tm = fmaxf(tm, __shfl_xor(tm, 32, 64));
-        const float mnew = fmaxf(mx, tm);
-        if (__builtin_amdgcn_ballot_w64(mnew > mx) != 0ull) {      // rare after the first tiles: rescale ctx rows / den
-            const float alpha = __builtin_amdgcn_exp2f((mx - mnew) * 1.4426950408889634f);   // lane l31 = d (0 on the first tile)
-            den *= alpha;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int d0 = (r & 3) + 8 * (r >> 2);
-                const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), d0));
-                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), d0 + 4));
-                ctx[r] *= half ? a1 : a0;
-            }
-            mx = mnew;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const float e = n < HW ? __builtin_amdgcn_exp2f((kt[r] - mx) * 1.4426950408889634f) : 0.f;     // one v_exp_f32
-            kt[r] = e;
-            den += e;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; ++r) ctx = __builtin_amdgcn_mfma_f32_32x32x2f32(kt[r], vt[r], ctx, 0, 0, 0);
-        __syncthreads();
-    }
-    den += __shfl_xor(den, 32, 64);
-    if (half == 0) dens[h * 32 + l31] = 1.0f / den;
-    __syncthreads();
-    float* ct = cT[h];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
-        ct[d * 36 + l31] = ctx[r] * dens[h * 32 + d];
-    }
-    __syncthreads();
-#pragma unroll
-    for (int nt = 0; nt < 2; ++nt) {
-        f32x16 m = z16();
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ct + l31 * 36 + 8 * c + 4 * half);
-            const f32x4 b4 = *reinterpret_cast<const f32x4*>(wout + ((size_t)(h * 8 + 2 * c + half) * C + 32 * nt + l31) * 4);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) m = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], m, 0, 0, 0);
-        }
-        float* mo = Mout + (long)f * (HEADS * 8 * C * 4);
-#pragma unroll
-        for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(mo + ((size_t)(h * 8 + 2 * g + half) * C + 32 * nt + l31) * 4) =
-                f32x4{m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]};
-    }
 }
 
 // one block per (frame, split): LDS = Wq for all heads [16][256][4] (64 KB) + the frame's M [8][8][64][4] (64 KB)
@@ -412,24 +312,426 @@ __global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* __restr
     }
 }
 
+// Split-operand version of sla_c64_apply_kernel (used with the pack_bf3 image of to_qkv): the Q projection -- half of the
+// kernel's matrix work -- runs on the bf16 pipe with the exact 3-way split (6 cross terms, fp32 accumulate): the pixel's
+// LayerNorm'ed channels are split once per tile in registers (B operand: lane = pixel), the pre-split Wq planes of all heads
+// live in LDS (96 KB) next to the frame's fp32 M (64 KB) = the whole 160 KB, so the out^T = M^T q^T product stays on the fp32
+// pipe (its A operand M is per frame; three bf16 planes of it would not fit).  Per tile and wave 192 bf16 + 256 fp32 MFMAs
+// (22.5 k pipe cycles) instead of 512 fp32 ones (32.8 k).
+// Work split: `tiles_per_block` consecutive (frame, 32-pixel tile) units per block, grid = number of CUs: every CU gets the
+// same number of tiles (the (frame, half) grid of the fp32 kernel was 400 one-per-CU blocks on 256 CUs = 1.56 rounds).
+typedef __bf16 bf16x8a __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_oct(const float (&v)[8], bf16x8a& p1, bf16x8a& p2, bf16x8a& p3) {
+    // exact truncation split (see temporal_layer.hip): p1 + p2 + p3 == v bit for bit
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q1, q2, q3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        const unsigned a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
+        const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
+        const unsigned a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
+        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+        q1[i] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+        q2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+        q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    }
+    p1 = __builtin_bit_cast(bf16x8a, q1);
+    p2 = __builtin_bit_cast(bf16x8a, q2);
+    p3 = __builtin_bit_cast(bf16x8a, q3);
+}
+
+__global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* __restrict__ x, int HW, int F,
+                                                                 const unsigned short* __restrict__ wqkv_s,
+                                                                 const float* __restrict__ Mg, const float* __restrict__ bias,
+                                                                 float eps, float* __restrict__ out, int tiles_per_block) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    unsigned char* Wq = smem_b;                                     // [kc 4][plane 3][k-half 2][256 features] x 16 B
+    float* Ms = reinterpret_cast<float*>(smem_b + 24 * 256 * 16);   // [64][64][4]  (h*8 + d/4, n)
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    for (int i = tid; i < 24 * 256; i += 512) {
+        const int row = i >> 8, n = i & 255;
+        *reinterpret_cast<uint4*>(Wq + (size_t)i * 16) = *reinterpret_cast<const uint4*>(wqkv_s + ((size_t)row * QKVN + n) * 8);
+    }
+    const int ntiles = (HW + 31) >> 5;
+    const long total = (long)F * ntiles;
+    const long g0 = (long)blockIdx.x * tiles_per_block;
+    const long g1 = g0 + tiles_per_block < total ? g0 + tiles_per_block : total;
+    const float scale = 0.17677669529663687f;
+    for (long g = g0; g < g1;) {
+        const int f = (int)(g / ntiles);
+        const int tA = (int)(g - (long)f * ntiles);
+        const int tB = (long)ntiles - tA < g1 - g ? ntiles : tA + (int)(g1 - g);
+        __syncthreads();                                            // the previous frame's M is no longer read (and Wq is written)
+        const float* mf = Mg + (long)f * (HEADS * 8 * C * 4);
+        for (int i = tid; i < 64 * 64; i += 512)
+            *reinterpret_cast<f32x4*>(Ms + i * 4) = *reinterpret_cast<const f32x4*>(mf + (size_t)i * 4);
+        __syncthreads();
+        // B operand of the transposed projection: lane = pixel, 8 consecutive channels 16 kc + 8 half + {0..7} per k-step; the
+        // rows of the wave's next tile are requested before this tile's matrix work (latency hidden under ~20 k cycles)
+        f32x4 xq[8];
+        auto request = [&](int t) {
+            const int n = 32 * t + l31;
+            const float* xr = x + ((long)f * HW + (n < HW ? n : HW - 1)) * C + 8 * half;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                xq[2 * kc] = *reinterpret_cast<const f32x4*>(xr + 16 * kc);
+                xq[2 * kc + 1] = *reinterpret_cast<const f32x4*>(xr + 16 * kc + 4);
+            }
+        };
+        if (tA + wave < tB) request(tA + wave);
+        for (int t = tA + wave; t < tB; t += 8) {
+            const int n = 32 * t + l31;
+            float xv[4][8];
+            float s = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    xv[kc][e] = xq[2 * kc][e];
+                    xv[kc][4 + e] = xq[2 * kc + 1][e];
+                    s += xq[2 * kc][e] + xq[2 * kc + 1][e];
+                }
+            if (t + 8 < tB) request(t + 8);
+            s += __shfl_xor(s, 32, 64);
+            const float mu = s * (1.0f / C);
+            float ss = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float dl = xv[kc][e] - mu; ss += dl * dl; }
+            ss += __shfl_xor(ss, 32, 64);
+            const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
+            bf16x8a xs[4][3];
+#pragma unroll
+            for (int kc = 0; kc < 4; ++kc) {
+                float xn[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xn[e] = (xv[kc][e] - mu) * rs;
+                split3_oct(xn, xs[kc][0], xs[kc][1], xs[kc][2]);
+            }
+
+            f32x16 oT[2];
+            oT[0] = z16();
+            oT[1] = z16();
+#pragma unroll 1
+            for (int h = 0; h < HEADS; ++h) {
+                // Q^T (32 d x 32 px): A = Wq_h plane fragments (LDS, lane = feature d), B = the pixel's split channels
+                f32x16 qT = z16();
+                constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc) {
+                    bf16x8a wa[3];
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        wa[pl] = *reinterpret_cast<const bf16x8a*>(Wq + ((size_t)(((kc * 3 + pl) * 2 + half) * 256 + h * DH + l31)) * 16);
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+                        qT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PW[u]], xs[kc][PX[u]], qT, 0, 0, 0);
+                }
+                float m = qT[0];
+#pragma unroll
+                for (int r = 1; r < 16; ++r) m = fmaxf(m, qT[r]);
+                m = fmaxf(m, __shfl_xor(m, 32, 64));
+                float l = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    qT[r] = __builtin_amdgcn_exp2f((qT[r] - m) * 1.4426950408889634f);
+                    l += qT[r];
+                }
+                l += __shfl_xor(l, 32, 64);
+                const float inv = scale * __builtin_amdgcn_rcpf(l);
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ms + ((h * 8 + 2 * c + half) * C + 32 * nt + l31) * 4);
+#pragma unroll
+                        for (int s2 = 0; s2 < 4; ++s2)
+                            oT[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s2], qT[4 * c + s2] * inv, oT[nt], 0, 0, 0);
+                    }
+            }
+            if (n < HW) {
+                const float* xrow = x + ((long)f * HW + n) * C;
+                float* orow = out + ((long)f * HW + n) * C;
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                    for (int g2 = 0; g2 < 4; ++g2) {
+                        const int ch = 32 * nt + 8 * g2 + 4 * half;
+                        const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + ch);
+                        const f32x4 xres = *reinterpret_cast<const f32x4*>(xrow + ch);      // residual (L1 / L2 hit)
+                        f32x4 o = {oT[nt][4 * g2], oT[nt][4 * g2 + 1], oT[nt][4 * g2 + 2], oT[nt][4 * g2 + 3]};
+                        *reinterpret_cast<f32x4*>(orow + ch) = o + b4 + xres;
+                    }
+            }
+        }
+        g += tB - tA;
+    }
+}
+
+// Sliced, single-sweep, split-operand form of sla_c64_context_kernel: block (frame f, slice sl) sweeps `per` consecutive 32-pixel tiles of the frame and
+// writes its partial context (8 heads x [32 x 32 un-normalised ctx | 32 den | 32 running max]) to the workspace; a small merge
+// kernel combines the slices (softmax shift invariance: ctx = sum_s 2^((mx_s - mx) log2 e) ctx_s), normalises and folds with
+// to_out.  One block per frame left 56 of the 256 CUs idle at the 200-frame benchmark; 5 slices per frame = 1000 blocks.
+// The exp(K)^T . V product is on the bf16 pipe too here: both operands are accumulator tiles with the same (lane, register) ->
+// pixel map, so registers 8j..8j+7 of each are the 8 k-values of k-step j of a 32x32x16 MFMA (the k order is a free
+// permutation); exact 3-way split of each, 6 cross terms: 12 bf16 MFMAs (384 pipe cycles) instead of 16 fp32 ones (1024).
+constexpr int SLA_PART = HEADS * (DH * DH + 2 * DH);       // floats per (frame, slice) partial
+
+// K / V projection of one 32-pixel tile for one head: 48 bf16 MFMAs, the only LDS reads of a tile
+__device__ __forceinline__ void sla_ctx_proj(const unsigned char* Pt, int l31, int half, const bf16x8a (&wk)[4][3],
+                                             const bf16x8a (&wv)[4][3], f32x16& kt, f32x16& vt) {
+    kt = z16();
+    vt = z16();
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc) {
+        bf16x8a xa[3];
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl)
+            xa[pl] = *reinterpret_cast<const bf16x8a*>(Pt + pl * 4096 + ((size_t)((kc * 2 + half) * 32 + l31)) * 16);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) {
+            kt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[u]], wk[kc][PB[u]], kt, 0, 0, 0);
+            vt = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xa[PA[u]], wv[kc][PB[u]], vt, 0, 0, 0);
+        }
+    }
+}
+
+// running-max softmax numerators of the tile's K and ctx += exp(K - max)^T . V (VALU-heavy: max, exp, two operand splits)
+template <bool FULL>
+__device__ __forceinline__ void sla_ctx_post(f32x16& kt, const f32x16& vt, int t, int HW, int half, f32x16& ctx, float& den,
+                                             float& mx) {
+    constexpr int PA[6] = {2, 0, 1, 1, 0, 0}, PB[6] = {0, 2, 1, 0, 1, 0};
+    // `mx` is the softmax reference of column d in log2 units (any reference gives the same quotient; it only has to keep
+    // 2^(k - mx) in range): it is raised to the running maximum only when that exceeds it by more than 2^8, so that the
+    // rescale of ctx / den is rare even in a short slice.  Numerators stay <= 2^8 (den <= 2^20 per slice): no overflow.
+    constexpr float LOG2E = 1.4426950408889634f;
+    float tm = -3.0e38f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+        if (FULL || n < HW) tm = fmaxf(tm, kt[r]);
+    }
+    tm = fmaxf(tm, __shfl_xor(tm, 32, 64)) * LOG2E;
+    if (__builtin_amdgcn_ballot_w64(tm > mx + 8.0f) != 0ull) {
+        const float mnew = fmaxf(mx, tm);
+        const float alpha = __builtin_amdgcn_exp2f(mx - mnew);        // lane l31 = d (0 on the first tile)
+        den *= alpha;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int d0 = (r & 3) + 8 * (r >> 2);
+            const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), d0));
+            const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, alpha), d0 + 4));
+            ctx[r] *= half ? a1 : a0;
+        }
+        mx = mnew;
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = 32 * t + (r & 3) + 8 * (r >> 2) + 4 * half;
+        float e = __builtin_amdgcn_exp2f(__builtin_fmaf(kt[r], LOG2E, -mx));     // v_fma + v_exp
+        if (!FULL) e = n < HW ? e : 0.f;
+        kt[r] = e;
+        den += e;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        float ek[8], vv[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { ek[i] = kt[8 * j + i]; vv[i] = vt[8 * j + i]; }
+        bf16x8a e3[3], v3[3];
+        split3_oct(ek, e3[0], e3[1], e3[2]);
+        split3_oct(vv, v3[0], v3[1], v3[2]);
+#pragma unroll
+        for (int u = 0; u < 6; ++u) ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e3[PA[u]], v3[PB[u]], ctx, 0, 0, 0);
+    }
+}
+
+__global__ __launch_bounds__(512) void sla_c64_context_part_kernel(const float* __restrict__ x, int HW,
+                                                                   const unsigned short* __restrict__ wqkv_s, float eps,
+                                                                   float* __restrict__ part, int ns, int per) {
+    __shared__ __attribute__((aligned(16))) unsigned char Ps[2][12288];
+    const int tid = threadIdx.x;
+    const int h = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int f = blockIdx.x / ns, sl = blockIdx.x - f * ns;
+    const float* xf = x + (long)f * HW * C;
+    const int ntiles = (HW + 31) >> 5;
+    const int tA = sl * per, tB = min(ntiles, tA + per);
+
+    bf16x8a wk[4][3], wv[4][3];
+#pragma unroll
+    for (int kc = 0; kc < 4; ++kc)
+#pragma unroll
+        for (int pl = 0; pl < 3; ++pl) {
+            const size_t base = ((size_t)((kc * 3 + pl) * 2 + half) * QKVN) * 8;
+            wk[kc][pl] = *reinterpret_cast<const bf16x8a*>(wqkv_s + base + (size_t)(HEADS * DH + h * DH + l31) * 8);
+            wv[kc][pl] = *reinterpret_cast<const bf16x8a*>(wqkv_s + base + (size_t)(2 * HEADS * DH + h * DH + l31) * 8);
+        }
+
+    f32x16 ctx = z16();
+    float den = 0.f, mx = -3.0e38f;
+    f32x4 vnext = {0.f, 0.f, 0.f, 0.f};
+    if (tA < tB) stage_store(stage_load(xf, 32 * tA, HW, tid), 32 * tA, HW, eps, Ps[0], tid);
+    if (tA + 1 < tB) vnext = stage_load(xf, 32 * (tA + 1), HW, tid);
+    __syncthreads();
+    // Waves w and w + 4 share a SIMD.  The projection is pure matrix-pipe work, the softmax / split part mostly VALU: heads 4..7
+    // run one tile behind in the second part (post(t-1) first, then proj(t)), so that on every SIMD one wave feeds the
+    // matrix pipe while the other one is in its VALU part, instead of both queueing for the same pipe in lockstep.  Both orders
+    // read the LDS planes of tile t inside iteration t only: one barrier per tile as before.
+    f32x16 kt, vt;
+    auto post = [&](int t) {
+        if (32 * t + 32 <= HW) sla_ctx_post<true>(kt, vt, t, HW, half, ctx, den, mx);
+        else sla_ctx_post<false>(kt, vt, t, HW, half, ctx, den, mx);
+    };
+    if (h < 4) {
+        for (int t = tA; t < tB; ++t) {
+            const f32x4 vcur = vnext;                                    // tile t+1 (requested one iteration ago)
+            if (t + 2 < tB) vnext = stage_load(xf, 32 * (t + 2), HW, tid);
+            sla_ctx_proj(Ps[(t - tA) & 1], l31, half, wk, wv, kt, vt);
+            post(t);
+            if (t + 1 < tB) stage_store(vcur, 32 * (t + 1), HW, eps, Ps[(t + 1 - tA) & 1], tid);
+            __syncthreads();
+        }
+    } else {
+        for (int t = tA; t < tB; ++t) {
+            const f32x4 vcur = vnext;
+            if (t + 2 < tB) vnext = stage_load(xf, 32 * (t + 2), HW, tid);
+            if (t > tA) post(t - 1);
+            if (t + 1 < tB) stage_store(vcur, 32 * (t + 1), HW, eps, Ps[(t + 1 - tA) & 1], tid);
+            sla_ctx_proj(Ps[(t - tA) & 1], l31, half, wk, wv, kt, vt);
+            __syncthreads();
+        }
+        if (tA < tB) post(tB - 1);
+    }
+    den += __shfl_xor(den, 32, 64);
+    float* P = part + ((long)f * ns + sl) * SLA_PART;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int d = (r & 3) + 8 * (r >> 2) + 4 * half;
+        P[h * (DH * DH) + d * DH + l31] = ctx[r];
+    }
+    if (half == 0) {
+        P[HEADS * DH * DH + h * DH + l31] = den;
+        P[HEADS * DH * DH + HEADS * DH + h * DH + l31] = mx;
+    }
+}
+
+__global__ __launch_bounds__(512) void sla_c64_context_merge_kernel(const float* __restrict__ part, int ns,
+                                                                    const float* __restrict__ wout, float* __restrict__ Mout) {
+    __shared__ __attribute__((aligned(16))) float cT[HEADS][32 * 36];
+    const int tid = threadIdx.x;
+    const int h = tid >> 6, lane = tid & 63;
+    const int l31 = lane & 31, half = lane >> 5;
+    const int f = blockIdx.x;
+    const float* P0 = part + (long)f * ns * SLA_PART;
+    float* ct = cT[h];
+    // lane (l31 = e, half) owns the context elements (d = 2 i + half, e), i = 0..15: slice loop outside, the 16 rows unrolled
+    // inside, so that every slice costs one round of independent loads
+    constexpr int OD = HEADS * DH * DH, OM = OD + HEADS * DH;
+    float m[16], den[16], acc[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { m[i] = -3.0e38f; den[i] = 0.f; acc[i] = 0.f; }
+    for (int sl = 0; sl < ns; ++sl) {
+        const float* P = P0 + (long)sl * SLA_PART;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) m[i] = fmaxf(m[i], P[OM + h * DH + 2 * i + half]);
+    }
+    for (int sl = 0; sl < ns; ++sl) {
+        const float* P = P0 + (long)sl * SLA_PART;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int d = 2 * i + half;
+            const float a = __builtin_amdgcn_exp2f(P[OM + h * DH + d] - m[i]);      // references are log2-scaled
+            den[i] += a * P[OD + h * DH + d];
+            acc[i] += a * P[h * (DH * DH) + d * DH + l31];
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) ct[(2 * i + half) * 36 + l31] = acc[i] * (1.0f / den[i]);
+    __syncthreads();
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt) {
+        f32x16 m = z16();
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 a4 = *reinterpret_cast<const f32x4*>(ct + l31 * 36 + 8 * c + 4 * half);
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(wout + ((size_t)(h * 8 + 2 * c + half) * C + 32 * nt + l31) * 4);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) m = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s], b4[s], m, 0, 0, 0);
+        }
+        float* mo = Mout + (long)f * (HEADS * 8 * C * 4);
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(mo + ((size_t)(h * 8 + 2 * g + half) * C + 32 * nt + l31) * 4) =
+                f32x4{m[4 * g], m[4 * g + 1], m[4 * g + 2], m[4 * g + 3]};
+    }
+}
+
+int sla_ncu() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        ncu = n;
+    }
+    return ncu;
+}
+
+// slices per frame of the context sweep: the count that minimises ceil(F ns / CUs) / ns (frame-sweeps per CU), at least 8 tiles each
+int sla_slices(int F, int HW) {
+    const int ntiles = (HW + 31) / 32, ncu = sla_ncu();
+    int best = 1;
+    double bc = 1e30;
+    for (int ns = 1; ns <= 8 && (ns == 1 || ntiles / ns >= 8); ++ns) {
+        const double c = (double)(((long)F * ns + ncu - 1) / ncu) / ns + 0.01 * ns;
+        if (c < bc - 1e-9) { bc = c; best = ns; }
+    }
+    return best;
+}
+
 }  // namespace
+
+extern "C" long dawn_sla_ws_floats(int F, int HW, int split) {
+    return (long)F * (HEADS * 8 * C * 4) + (split ? (long)F * sla_slices(F, HW) * SLA_PART : 0);
+}
 
 extern "C" int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const void* wqkv_bf3,
                                   const float* wout, const float* bias, float eps, float* M_ws, float* out,
                                   void* stream) {
     if (F <= 0 || HW <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (wqkv_bf3)
-        hipLaunchKernelGGL(sla_c64_context_bf16_kernel, dim3(F), dim3(512), 0, s, x, HW,
-                           (const unsigned short*)wqkv_bf3, wout, eps, M_ws);
-    else
+    if (wqkv_bf3) {
+        const int ns = sla_slices(F, HW), nt = (HW + 31) / 32;
+        float* part = M_ws + (size_t)F * (HEADS * 8 * C * 4);
+        hipLaunchKernelGGL(sla_c64_context_part_kernel, dim3(F * ns), dim3(512), 0, s, x, HW, (const unsigned short*)wqkv_bf3, eps,
+                           part, ns, (nt + ns - 1) / ns);
+        hipLaunchKernelGGL(sla_c64_context_merge_kernel, dim3(F), dim3(512), 0, s, part, ns, wout, M_ws);
+    } else
         hipLaunchKernelGGL(sla_c64_context_kernel, dim3(F), dim3(512), 0, s, x, HW, wqkv, wout, eps, M_ws);
     const int ntiles = (HW + 31) / 32;
-    const int nsplit = (ntiles >= 64) ? 2 : 1;
-    const int lds = (16 * 256 * 4 + 64 * 64 * 4) * 4;   // 128 KB
-    (void)hipFuncSetAttribute((const void*)sla_c64_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    hipLaunchKernelGGL(sla_c64_apply_kernel, dim3(F * nsplit), dim3(512), lds, s, x, HW, wqkv, M_ws, bias, eps, out,
-                       nsplit);
+    if (wqkv_bf3) {
+        const int ncu = sla_ncu();
+        const long total = (long)F * ntiles;
+        const int per = (int)((total + ncu - 1) / ncu);
+        const int nblk = (int)((total + per - 1) / per);
+        const int lds = 24 * 256 * 16 + 64 * 64 * 4 * 4;    // 96 KB of Wq planes + 64 KB of M = 160 KB
+        (void)hipFuncSetAttribute((const void*)sla_c64_apply_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(sla_c64_apply_bf16_kernel, dim3(nblk), dim3(512), lds, s, x, HW, F, (const unsigned short*)wqkv_bf3,
+                           M_ws, bias, eps, out, per);
+    } else {
+        const int nsplit = (ntiles >= 64) ? 2 : 1;
+        const int lds = (16 * 256 * 4 + 64 * 64 * 4) * 4;   // 128 KB
+        (void)hipFuncSetAttribute((const void*)sla_c64_apply_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(sla_c64_apply_kernel, dim3(F * nsplit), dim3(512), lds, s, x, HW, wqkv, M_ws, bias, eps, out,
+                           nsplit);
+    }
     DAWN_LAUNCH_CHECK();
     return 0;
 }

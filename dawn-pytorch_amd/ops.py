@@ -369,7 +369,7 @@ class HipOps:
         """out = x + to_out(linear_attention(LayerNorm(x))) for 64-channel levels (two kernels, no qkv tensor)."""
         assert x.is_contiguous() and x.shape == (F * HW, 64)
         self._require(x, wqkv, wout, bias)
-        ws = self.empty(F, 8 * 8 * 64 * 4, like=x)
+        ws = self.empty(self.L.dawn_sla_ws_floats(F, HW, int(wqkv_bf3 is not None)), like=x)
         out = self.empty(F * HW, 64, like=x)
         check(self.L.dawn_sla_layer_c64(_p(x), F, HW, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(bias), eps, _p(ws), _p(out),
                                         self._stream()), "dawn_sla_layer_c64")

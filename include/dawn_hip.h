@@ -155,10 +155,13 @@ int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);
 int dawn_sla_apply(const float* qkv, const float* ctx, int F, int HW, float* out, void* stream); /* out (F*HW,256) */
 
 /* Fused LAYER for 64-channel levels: out = x + to_out(linattn(LayerNorm(x))) + bias, q/k/v never materialised.
- * M_ws: caller workspace of F*8*8*64*4 floats (per-frame folded context . to_out matrices).
+ * M_ws: caller workspace of dawn_sla_ws_floats(F, HW, wqkv_bf3 != NULL) floats (per-frame folded context . to_out matrices
+ * and, on the split-operand path, the per-slice partial contexts of the sliced sweep).
  * wqkv_bf3 (optional): the exact 3-way bf16 split of wqkv, [64/16][3][2][768][8] (pack_bf3 order): the context
  * kernel then runs its K / V projections on the bf16 matrix pipe (fp32 results) in a single sweep with a running
- * column max; NULL = two-sweep fp32-MFMA kernel. */
+ * column max, sliced over the frame's pixels so that every CU works (partials merged by a small second kernel), and the
+ * apply kernel runs its Q projection there; NULL = two-sweep fp32-MFMA kernels. */
+long dawn_sla_ws_floats(int F, int HW, int split);
 int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const void* wqkv_bf3, const float* wout,
                        const float* bias, float eps, float* M_ws, float* out, void* stream);
 

@@ -491,7 +491,7 @@ def test_sla(hip, ref, F, HW):
     check(f"sla/F{F}_HW{HW}", hip.sla(qkv.cuda(), F, HW), ref.sla(qkv, F, HW), 2e-5)
 
 
-@pytest.mark.parametrize("F,HW", [(3, 64), (2, 1024), (5, 256), (1, 4096), (2, 100)])
+@pytest.mark.parametrize("F,HW", [(3, 64), (2, 1024), (5, 256), (1, 4096), (2, 100), (3, 1000), (9, 2080)])
 def test_sla_layer_c64(hip, ref, F, HW):
     """Fused layer == LN stats + qkv GEMM + linear attention + out GEMM (+bias) + residual."""
     x = rnd(F * HW, 64, seed=1) * 1.3 + 0.2
