@@ -397,7 +397,7 @@ struct Eval {
             const size_t xt = L.xtab[rb.cond_index];
             if (can_fuse_xattn(rb.Cin, Co, x.C, HW) && xt != (size_t)-1) {
                 hcond = t2(rows, 64);
-                LAUNCH(dawn_xattn_layer_c64(x.p, x.C, x.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x2 ? x2->C : 0, rows, HW, rb.wq, rb.g3,
+                LAUNCH(dawn_xattn_layer_c64(x.p, x.C, x.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x2 ? x2->C : 0, rows, HW, rb.wq, rb.wqs, rb.g3,
                                             clipf(xt), 1e-5f, hcond.p, cur));
             } else {
                 T2 q = ln_gemm(x, x2, rb.wq, 192, rb.wqs, Fr, H, W);

@@ -51,22 +51,29 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const float* __restrict
 }
 
 // fixed-order (deterministic) column sums of part[nblk][16]; 1024 threads: column t&15, row phase t>>4 (64 phases),
-// four independent accumulators per thread so that the loads of a phase are in flight together.
+// independent accumulators per thread so that many loads are in flight together.
 template <int NT>
 __device__ __forceinline__ void gn_reduce_block(const double* __restrict__ part, int nblk, double* sh, double* out16) {
     constexpr int NP = NT / 16;                      // row phases
     const int t = threadIdx.x;
     const int c = t & 15, r = t >> 4;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    // 16 independent accumulators: 16 loads in flight per thread (with 4, the 3200-row partials of a level-0 conv took ~50
+    // dependent L2 round trips = 20..35 us on the critical path of every ResBlock)
+    constexpr int U = 16;
+    double acc[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) acc[u] = 0.0;
     int b = r;
-    for (; b + 3 * NP < nblk; b += 4 * NP) {
-        a0 += part[(long)b * 16 + c];
-        a1 += part[(long)(b + NP) * 16 + c];
-        a2 += part[(long)(b + 2 * NP) * 16 + c];
-        a3 += part[(long)(b + 3 * NP) * 16 + c];
+    for (; b + (U - 1) * NP < nblk; b += U * NP) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) acc[u] += part[(long)(b + u * NP) * 16 + c];
     }
-    for (; b < nblk; b += NP) a0 += part[(long)b * 16 + c];
-    sh[t] = (a0 + a1) + (a2 + a3);
+    for (; b < nblk; b += NP) acc[0] += part[(long)b * 16 + c];
+#pragma unroll
+    for (int w = U / 2; w >= 1; w >>= 1)
+#pragma unroll
+        for (int u = 0; u < w; ++u) acc[u] += acc[u + w];
+    sh[t] = acc[0];
     __syncthreads();
     if (t < 16) {
         double s = 0.0;

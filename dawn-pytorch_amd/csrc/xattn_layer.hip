@@ -38,24 +38,57 @@ __device__ __forceinline__ f32x16 zz16() {
 }
 __device__ __forceinline__ float x32(float v) { return v + __shfl_xor(v, 32, 64); }
 
-template <int CIN>
-__global__ __launch_bounds__(512, CIN == 64 ? 4 : 2) void xattn_c64_kernel(const float* __restrict__ in0, int C0, int ld0,
+// SPLIT: to_q -- 87 % of the kernel's matrix work -- on the bf16 pipe with the exact 3-way operand split (6 cross terms, fp32
+// accumulate, see conv_gemm.hip): the pre-split weight planes (pack_bf3 image, [CIN/16][3][2][192][8]) take the place of the fp32
+// weights in LDS (72 / 144 KB), the lane's LayerNorm'ed channels (8 consecutive ones per k-step: B operand, lane = pixel) are
+// split once per tile in registers.  144 (288) bf16 MFMAs of 32 cycles instead of 192 (384) fp32 ones of 64 per tile.
+typedef __bf16 bf16x8x __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ void split3_oct(const float (&v)[8], bf16x8x& p1, bf16x8x& p2, bf16x8x& p3) {
+    // exact truncation split (see temporal_layer.hip): p1 + p2 + p3 == v bit for bit
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q1, q2, q3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        const unsigned a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
+        const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
+        const unsigned a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
+        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+        q1[i] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+        q2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+        q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    }
+    p1 = __builtin_bit_cast(bf16x8x, q1);
+    p2 = __builtin_bit_cast(bf16x8x, q2);
+    p3 = __builtin_bit_cast(bf16x8x, q3);
+}
+
+template <int CIN, bool SPLIT>
+__global__ __launch_bounds__(512, (CIN == 64 && !SPLIT) ? 4 : 2) void xattn_c64_kernel(const float* __restrict__ in0, int C0, int ld0,
                                                         const float* __restrict__ in1, int ld1, long rows, int HW,
-                                                        const float* __restrict__ wq, const float* __restrict__ g3,
+                                                        const float* __restrict__ wq, const unsigned short* __restrict__ wq_s,
+                                                        const float* __restrict__ g3,
                                                         const float* __restrict__ xtab, float eps,
                                                         float* __restrict__ out, long ntiles) {
     constexpr int NC = CIN / 8;
+    constexpr int WQF = SPLIT ? CIN * 1152 / 4 : (CIN / 4) * 192 * 4;       // floats of LDS taken by the to_q weights
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* Wq = smem;                         // [CIN/4][192][4]
-    float* Cs = smem + (CIN / 4) * 192 * 4;   // g3 [3][64]
+    float* Wq = smem;                         // fp32: [CIN/4][192][4]; SPLIT: planes [CIN/16][3][2][192] x 16 B
+    float* Cs = smem + WQF;                   // g3 [3][64]
     float* Dw = Cs + 192;                     // per-wave copy of the current frame's D rows: [8 waves][3][64]
     const int tid = threadIdx.x;
     for (int i = tid; i < 192; i += 512) Cs[i] = g3[i];
-    for (int i = tid; i < (CIN / 4) * 192; i += 512)
-        *reinterpret_cast<f32x4*>(Wq + i * 4) = *reinterpret_cast<const f32x4*>(wq + (size_t)i * 4);
+    if (SPLIT) {
+        for (int i = tid; i < WQF / 4; i += 512)
+            *reinterpret_cast<f32x4*>(Wq + i * 4) = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(wq_s) + (size_t)i * 4);
+    } else {
+        for (int i = tid; i < (CIN / 4) * 192; i += 512)
+            *reinterpret_cast<f32x4*>(Wq + i * 4) = *reinterpret_cast<const f32x4*>(wq + (size_t)i * 4);
+    }
     __syncthreads();
 
-    const int wave = tid >> 6, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
 #ifdef DAWN_XA_TIMING
     unsigned long long* tsb = reinterpret_cast<unsigned long long*>(Dw + 8 * 192);  // after the per-wave tables
@@ -64,20 +97,46 @@ __global__ __launch_bounds__(512, CIN == 64 ? 4 : 2) void xattn_c64_kernel(const
 #else
 #define TSTAMP() do { } while (0)
 #endif
-    for (long t = (long)blockIdx.x * 8 + wave; t < ntiles; t += (long)gridDim.x * 8) {
-        TSTAMP();   // tile start
-        const long row = t * 32 + l31;
-        const long rc = row < rows ? row : rows - 1;
-        // ---- x fragments + LayerNorm (biased variance, eps) in registers
-        f32x4 xn[NC];
-        float s = 0.f;
+    // Each wave owns a contiguous range of 32-pixel tiles (same frame for ~all of them: the frame's D rows are copied to LDS
+    // only when the frame changes, and the rows stream through HBM in order).  With room in the register file (SPLIT, Cin = 64:
+    // two waves per SIMD) the next tile's rows are requested before this tile's work.
+    constexpr bool PREF = SPLIT && CIN == 64;
+    const long nwaves = (long)gridDim.x * 8;
+    const long per = (ntiles + nwaves - 1) / nwaves;
+    const long tbeg = ((long)blockIdx.x * 8 + wave) * per;
+    const long tend = tbeg + per < ntiles ? tbeg + per : ntiles;
+    f32x4 xq[PREF ? NC : 1];
+    // rows of a tile through buffer descriptors rebuilt per tile from scalar bases (t is wave-uniform): the per-lane part of
+    // an address is a small 32-bit offset, no 64-bit vector arithmetic (rows % 32 == 0: there are no partial tiles)
+    auto request = [&](long t, f32x4* dst) {
+        const __amdgpu_buffer_rsrc_t r0 = __builtin_amdgcn_make_buffer_rsrc((void*)(in0 + t * 32 * ld0), 0, 32 * ld0 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t r1 =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(in1 ? in1 + t * 32 * ld1 : in0), 0, 32 * ld1 * 4, 0x00020000);
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
-            const int col = 8 * c + 4 * half;
-            xn[c] = (col < C0) ? *reinterpret_cast<const f32x4*>(in0 + rc * ld0 + col)
-                               : *reinterpret_cast<const f32x4*>(in1 + rc * ld1 + (col - C0));
-            s += xn[c].x + xn[c].y + xn[c].z + xn[c].w;
+            const int cb = SPLIT ? 16 * (c >> 1) + 4 * (c & 1) : 8 * c;          // wave-uniform part of the column
+            const int col = cb + (SPLIT ? 8 : 4) * half;
+            dst[c] = __builtin_bit_cast(f32x4, cb < C0 ? __builtin_amdgcn_raw_buffer_load_b128(r0, (l31 * ld0 + col) * 4, 0, 0)
+                                                       : __builtin_amdgcn_raw_buffer_load_b128(r1, (l31 * ld1 + col - C0) * 4, 0, 0));
         }
+    };
+    if (PREF && tbeg < tend) request(tbeg, xq);
+    long cur_frame = -1;
+    for (long t = tbeg; t < tend; ++t) {
+        TSTAMP();   // tile start
+        // ---- x fragments + LayerNorm (biased variance, eps) in registers.  fp32: quads 8c + 4 half (k = 2s + half of the
+        // 32x32x2 MFMA); SPLIT: the 8 consecutive channels 16 kc + 8 half + {0..7} of each 32x32x16 k-step = quads 2kc, 2kc+1
+        f32x4 xn[NC];
+        if (PREF) {
+#pragma unroll
+            for (int c = 0; c < NC; ++c) xn[c] = xq[c];
+            if (t + 1 < tend) request(t + 1, xq);
+        } else {
+            request(t, xn);
+        }
+        float s = 0.f;
+#pragma unroll
+        for (int c = 0; c < NC; ++c) s += xn[c].x + xn[c].y + xn[c].z + xn[c].w;
         s = x32(s);
         const float mu = s * (1.0f / CIN);
         float ss = 0.f;
@@ -90,15 +149,28 @@ __global__ __launch_bounds__(512, CIN == 64 ? 4 : 2) void xattn_c64_kernel(const
         const float rs = __builtin_amdgcn_rsqf(ss * (1.0f / CIN) + eps);
 #pragma unroll
         for (int c = 0; c < NC; ++c) xn[c] = xn[c] * rs;
+        bf16x8x xs[SPLIT ? CIN / 16 : 1][3];
+        if (SPLIT) {
+#pragma unroll
+            for (int kc = 0; kc < CIN / 16; ++kc) {
+                const float v8[8] = {xn[2 * kc].x, xn[2 * kc].y, xn[2 * kc].z, xn[2 * kc].w,
+                                     xn[2 * kc + 1].x, xn[2 * kc + 1].y, xn[2 * kc + 1].z, xn[2 * kc + 1].w};
+                split3_oct(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
+            }
+        }
         TSTAMP();   // x loaded + LayerNorm
 
         // the tile's frame (HW % 32 == 0: a 32-pixel tile never straddles frames) and its table [3][D 64 | U 9 x 64]:
         // the D rows go to this wave's LDS copy (no global-load latency in the head loops)
-        const float* xt = xtab + ((t * 32) / HW) * (3 * 640);
+        const long frame = (t * 32) / HW;
+        const float* xt = xtab + frame * (3 * 640);
         float* dw = Dw + (tid >> 6) * 192;
-        if (lane < 48) {
-            const int b = lane >> 4, j = (lane & 15) * 4;
-            *reinterpret_cast<f32x4*>(dw + b * 64 + j) = *reinterpret_cast<const f32x4*>(xt + b * 640 + j);
+        if (frame != cur_frame) {                                  // wave-uniform
+            cur_frame = frame;
+            if (lane < 48) {
+                const int b = lane >> 4, j = (lane & 15) * 4;
+                *reinterpret_cast<f32x4*>(dw + b * 64 + j) = *reinterpret_cast<const f32x4*>(xt + b * 640 + j);
+            }
         }
         f32x16 hc[2];
         hc[0] = zz16();
@@ -118,6 +190,20 @@ __global__ __launch_bounds__(512, CIN == 64 ? 4 : 2) void xattn_c64_kernel(const
             for (int tt = 0; tt < 2; ++tt) {
                 // ---- Q^T tile: features 64b + 32tt + {0..31}
                 f32x16 acc = zz16();
+                if (SPLIT) {
+                    constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};     // smallest cross terms first
+                    const unsigned char* Wp = reinterpret_cast<const unsigned char*>(Wq);
+#pragma unroll
+                    for (int kc = 0; kc < CIN / 16; ++kc) {
+                        bf16x8x wa[3];
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            wa[pl] = *reinterpret_cast<const bf16x8x*>(Wp + ((size_t)(((kc * 3 + pl) * 2 + half) * 192 + 64 * b + 32 * tt + l31)) * 16);
+#pragma unroll
+                        for (int u = 0; u < 6; ++u)
+                            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PW[u]], xs[kc][PX[u]], acc, 0, 0, 0);
+                    }
+                } else {
                 // weight fragments requested PF at a time ahead of their MFMAs (all 16 for CIN = 128 with its 256-register
                 // budget; 4 for CIN = 64, which runs 4 waves per SIMD on 128 registers)
                 constexpr int PF = CIN == 64 ? 4 : NC;
@@ -133,6 +219,7 @@ __global__ __launch_bounds__(512, CIN == 64 ? 4 : 2) void xattn_c64_kernel(const
                         for (int s2 = 0; s2 < 4; ++s2)
                             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wq4[c][s2], xn[c0 + c][s2], acc, 0, 0, 0);
                     }
+                }
                 }
                 // ---- 2-key cosine-sim attention per head (head = 4tt + c4; lane holds features 4half..4half+3)
 #pragma unroll
@@ -187,14 +274,17 @@ __global__ __launch_bounds__(512, CIN == 64 ? 4 : 2) void xattn_c64_kernel(const
                 }
             TSTAMP();   // branch LayerNorm + accumulate
         }
-        if (row < rows) {
-            float* orow = out + row * CO;
+        {
+            const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + t * 32 * CO), 0, 32 * CO * 4, 0x00020000);
+            typedef int i32x4 __attribute__((ext_vector_type(4)));
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
-                for (int g = 0; g < 4; ++g)
-                    *reinterpret_cast<f32x4*>(orow + 32 * ot + 8 * g + 4 * half) =
-                        f32x4{hc[ot][4 * g], hc[ot][4 * g + 1], hc[ot][4 * g + 2], hc[ot][4 * g + 3]};
+                for (int g = 0; g < 4; ++g) {
+                    const f32x4 v = {hc[ot][4 * g], hc[ot][4 * g + 1], hc[ot][4 * g + 2], hc[ot][4 * g + 3]};
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), ro,
+                                                           (l31 * CO + 32 * ot + 8 * g + 4 * half) * 4, 0, 0);
+                }
         }
         TSTAMP();   // stored
 #ifdef DAWN_XA_TIMING
@@ -254,8 +344,8 @@ extern "C" int dawn_xattn_tables(const float* kvtab, const float* nulltab, const
 }
 
 extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
-                                    int HW, const float* wq, const float* g3, const float* xtab, float eps, float* out,
-                                    void* stream) {
+                                    int HW, const float* wq, const void* wq_bf3, const float* g3, const float* xtab, float eps,
+                                    float* out, void* stream) {
     const int Cin = C0 + C1;
     if ((Cin != 64 && Cin != 128) || C0 % 8 != 0 || (ld0 % 4) || (in1 && (ld1 % 4)))
         return dawn_set_error_msg(-51, "dawn_xattn_layer_c64: Cin must be 64 or 128 (two sources allowed), Co = 64");
@@ -265,21 +355,23 @@ extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const flo
     hipStream_t s = (hipStream_t)stream;
     const long ntiles = rows / 32;
     long grid = (ntiles + 7) / 8;
-    const long cap = Cin == 64 ? 512 : 256;     // resident blocks: 2 per CU at 56 KB of LDS (Cin = 64), 1 at 105 KB
+    const bool split = wq_bf3 != nullptr && C0 % 16 == 0;
+    // resident blocks: fp32 weights 2 per CU at 56 KB of LDS (Cin = 64), 1 at 105 KB; split planes 2 per CU at 79 KB, 1 at 151 KB
+    const long cap = (Cin == 64 && !split) ? 512 : 256;       // the split Cin = 64 kernel runs two 256-register waves per SIMD
     if (grid > cap) grid = cap;
-    int lds = ((Cin / 4) * 192 * 4 + 192 + 8 * 192) * 4;
+    int lds = ((split ? Cin * 1152 / 4 : (Cin / 4) * 192 * 4) + 192 + 8 * 192) * 4;
 #ifdef DAWN_XA_TIMING
     lds += 8 * 24 * 8;
 #endif
-    if (Cin == 64) {
-        (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(xattn_c64_kernel<64>, dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows, HW,
-                           wq, g3, xtab, eps, out, ntiles);
-    } else {
-        (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(xattn_c64_kernel<128>, dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows,
-                           HW, wq, g3, xtab, eps, out, ntiles);
-    }
+#define LAUNCH_XA(CINV, SPV)                                                                                                 \
+    do {                                                                                                                     \
+        (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<CINV, SPV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
+        hipLaunchKernelGGL((xattn_c64_kernel<CINV, SPV>), dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows, \
+                           HW, wq, (const unsigned short*)wq_bf3, g3, xtab, eps, out, ntiles);                              \
+    } while (0)
+    if (Cin == 64) { if (split) LAUNCH_XA(64, true); else LAUNCH_XA(64, false); }
+    else { if (split) LAUNCH_XA(128, true); else LAUNCH_XA(128, false); }
+#undef LAUNCH_XA
     DAWN_LAUNCH_CHECK();
     return 0;
 }

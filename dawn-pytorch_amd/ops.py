@@ -283,9 +283,11 @@ class HipOps:
         return out
 
     def xattn_layer_c64(self, x: Tensor, x2: Optional[Tensor], HW: int, wq: Tensor, wo, g3: Tensor, q_scale: Tensor,
-                        kvtab: Tensor, nulltab: Tensor, eps: float = 1e-5, xtab: Optional[Tensor] = None) -> Tensor:
+                        kvtab: Tensor, nulltab: Tensor, eps: float = 1e-5, xtab: Optional[Tensor] = None,
+                        wq_bf3: Optional[Tensor] = None) -> Tensor:
         """h_cond (rows,64) = sum over the three branches of LN(to_out(attn(LN(x)))) in one launch.  The kernel reads
-        the per-clip tables `xtab` (xattn_tables of kvtab / nulltab / q_scale / wo); built here if not supplied."""
+        the per-clip tables `xtab` (xattn_tables of kvtab / nulltab / q_scale / wo); built here if not supplied.
+        `wq_bf3` (pack_bf3 of to_q) puts the Q projection on the bf16 matrix pipe (exact operand split)."""
         rows = x.shape[0]
         if xtab is None:
             xtab = self.xattn_tables(kvtab, nulltab, q_scale, wo, 64)
@@ -293,7 +295,7 @@ class HipOps:
         assert xtab.is_contiguous() and xtab.shape[1:] == (3, 640) and rows == xtab.shape[0] * HW
         out = self.empty(rows, 64, like=x)
         check(self.L.dawn_xattn_layer_c64(_p(x), x.shape[1], _ld(x), _p(x2), 0 if x2 is None else x2.shape[1], _ld(x2),
-                                          rows, HW, _p(wq), _p(g3), _p(xtab), eps, _p(out), self._stream()),
+                                          rows, HW, _p(wq), _p(wq_bf3), _p(g3), _p(xtab), eps, _p(out), self._stream()),
               "dawn_xattn_layer_c64")
         return out
 

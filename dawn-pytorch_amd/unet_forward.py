@@ -107,7 +107,7 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     def cross_attention():
         if ops.can_fuse_xattn(rb.Cin, Co, x.shape[1], H * W) and cs.xtab[rb.cond_index] is not None:
             return ops.xattn_layer_c64(x, x2, H * W, rb.wq, rb.wo, rb.g3, rb.q_scale, cs.kvtab[rb.cond_index],
-                                       cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index])
+                                       cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index], wq_bf3=rb.wqs)
         # LayerNorm_img is materialised (one streaming pass) so that to_q runs as a prologue-free GEMM
         q = _ln_gemm(ops, x, x2, rb.wq, 192, rb.wqs, **g)
         if ops.can_fuse_xattn_out(Co, H * W) and cs.xtab[rb.cond_index] is not None:

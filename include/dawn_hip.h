@@ -118,9 +118,12 @@ int dawn_xattn_sigma_out(const float* q, long rows, int HW, const float* xtab, c
                          float* out, void* stream);
 /* Fused cross-attention branch for Co = 64, Cin in {64, 128} (two sources allowed), H*W % 32 == 0:
  * out[row][:] = sum_b LN(to_out_b(attn_b(LN([in0|in1][row]))))  -- everything of MT:454-468 / MT:516-559 in one launch.
- * wq packed (Cin -> 192, LayerNorm gains folded), g3 (3,64), xtab (F,3,640) from dawn_xattn_tables. */
+ * wq packed (Cin -> 192, LayerNorm gains folded), g3 (3,64), xtab (F,3,640) from dawn_xattn_tables.
+ * wq_bf3 (optional): the exact 3-way bf16 split of wq, [Cin/16][3][2][192][8] (pack_bf3 order): to_q then runs on the bf16
+ * matrix pipe (fp32 results, 6 cross terms); NULL = fp32-MFMA projection. */
 int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows, int HW,
-                         const float* wq, const float* g3, const float* xtab, float eps, float* out, void* stream);
+                         const float* wq, const void* wq_bf3, const float* g3, const float* xtab, float eps, float* out,
+                         void* stream);
 
 /* ---- A9/A10 windowed temporal self-attention per pixel (MT:665-725 with the MT:117 window mask,
  * == LA:71-99/300-342).  qkv (Fext*HW, 768) = [q|k|v][head 8][32]; queries are frames

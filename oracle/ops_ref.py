@@ -209,7 +209,7 @@ class RefOps:
             out[:, b, 64 + 8 * Co:] = y0[None]
         return out.float().to(kvtab.device)
 
-    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5, xtab=None):
+    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5, xtab=None, wq_bf3=None):
         """The ORIGINAL formulation (MT:516-559 op by op); `xtab` (the kernel's per-clip tables) is not used here, so the
         GPU test of the fused kernel also proves the table algebra."""
         rows = x.shape[0]

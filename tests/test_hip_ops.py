@@ -374,6 +374,10 @@ def test_xattn_layer_c64(hip, ref, C0, C1, Fn, HW):
     got = hip.xattn_layer_c64(x.cuda(), None if x2 is None else x2.cuda(), HW, wq.cuda(), [w.cuda() for w in wo],
                               g3.cuda(), qs.cuda(), kvtab.cuda(), nulltab.cuda())
     check(f"xattn_layer_c64/{C0}+{C1}_F{Fn}_HW{HW}", got, want, 3e-5)
+    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+    got = hip.xattn_layer_c64(x.cuda(), None if x2 is None else x2.cuda(), HW, wq.cuda(), [w.cuda() for w in wo],
+                              g3.cuda(), qs.cuda(), kvtab.cuda(), nulltab.cuda(), wq_bf3=pack_bf3(unpack_kn(wq)).cuda())
+    check(f"xattn_layer_c64_split/{C0}+{C1}_F{Fn}_HW{HW}", got, want, 3e-5)
 
 
 @pytest.mark.parametrize("Co,Fn,HW", [(128, 3, 1024), (256, 5, 64), (512, 7, 16), (32, 2, 4), (96, 3, 36), (64, 2, 64)])

@@ -65,7 +65,9 @@ kvtab = torch.randn(F, 3, 128, device=dev)
 nulltab = torch.randn(3, 16, device=dev)
 x2 = torch.randn(F * HW, 64, device=dev)
 xtab = ops.xattn_tables(kvtab, nulltab, q_scale, wo, 64)            # once per clip in the product
-t = timeit(lambda: ops.xattn_layer_c64(x, None, HW, wq64, wo, g3, q_scale, kvtab, nulltab, xtab=xtab))
-print(f"xattn_layer_c64 Cin=64   : {t:8.1f} us")
-t = timeit(lambda: ops.xattn_layer_c64(x, x2, HW, wq128, wo, g3, q_scale, kvtab, nulltab, xtab=xtab))
-print(f"xattn_layer_c64 Cin=64+64: {t:8.1f} us")
+from dawn_pytorch_amd.pack import unpack_kn
+for name, s64, s128 in (("fp32 ", None, None), ("split", pack_bf3(unpack_kn(wq64.cpu())).to(dev), pack_bf3(unpack_kn(wq128.cpu())).to(dev))):
+    t = timeit(lambda: ops.xattn_layer_c64(x, None, HW, wq64, wo, g3, q_scale, kvtab, nulltab, xtab=xtab, wq_bf3=s64))
+    print(f"xattn_layer_c64 Cin=64    {name}: {t:8.1f} us")
+    t = timeit(lambda: ops.xattn_layer_c64(x, x2, HW, wq128, wo, g3, q_scale, kvtab, nulltab, xtab=xtab, wq_bf3=s128))
+    print(f"xattn_layer_c64 Cin=64+64 {name}: {t:8.1f} us")
