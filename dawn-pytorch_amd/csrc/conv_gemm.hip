@@ -36,7 +36,7 @@ constexpr int DAWN_CONV_POLICY_DEFAULT = 0x580D;
 #ifdef DAWN_ABLATION
 constexpr int DAWN_CONV_POLICY_MASK = 0x000FFFFF;
 #else
-constexpr int DAWN_CONV_POLICY_MASK = 0x00F1FFCF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x00F3FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
 static thread_local int g_last_nwg = 0;   // gridDim.x of the calling thread's last launch (= rows of gn_part it writes)
@@ -830,6 +830,26 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& p1, uint2& p2, uint
     p1 = *reinterpret_cast<uint2*>(&h1);
     p2 = *reinterpret_cast<uint2*>(&h2);
     p3 = *reinterpret_cast<uint2*>(&h3);
+}
+
+// exact truncation split of 8 values into three bf16x8 fragments (see temporal_layer.hip split3_oct): p1 + p2 + p3 == v
+__device__ __forceinline__ void split3_trunc8(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 q1, q2, q3;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float a = v[2 * i], b = v[2 * i + 1];
+        const unsigned a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
+        const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
+        const unsigned a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
+        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
+        q1[i] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
+        q2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
+        q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
+    }
+    p1 = __builtin_bit_cast(bf16x8, q1);
+    p2 = __builtin_bit_cast(bf16x8, q2);
+    p3 = __builtin_bit_cast(bf16x8, q3);
 }
 
 template <int BN, int WN, int NT>
@@ -1640,6 +1660,191 @@ __global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(cons
 #endif
 }
 
+// Persistent form of gemm1x1_bf16_kernel (256 x 64*WN tiles): one workgroup per CU walks a contiguous range of tiles in
+// row-panel-major order (all N tiles of a 256-row panel, then the next panel) as ONE software pipeline over (tile, stage)
+// pairs -- the A rows and weights of the next tile's first stages are requested while the current tile's last stages run,
+// so its 16 row-segment stores per lane drain under the next tile's MFMAs instead of closing a fetch -> MFMA -> store
+// sequence per tile (40 k cycles per tile against 12 k of matrix work at K = 128), the A panel is read from HBM once (its
+// other N tiles hit L2), and every CU gets the same number of tiles (+-1) whatever the tile count.
+// Row-stationary split-operand GEMM for the short-K projections (K = 64 / 128: to_qkv and to_q of the 64 / 128-channel
+// levels).  What bounds gemm1x1_bf16_kernel there is not the matrix pipe: with 4..8 MFMA stages per tile its phases (fetch +
+// split + LDS round trip of the A rows | MFMA | stores) run back to back and ADD (ablation at M = 204800, N = 768, K = 128:
+// 465 us = 251 us with neither MFMAs nor stores + 86 us of MFMAs + 113 us of stores), and every one of the N / 128 column
+// tiles of a row panel re-fetches and re-splits the same rows.  Here a lane owns ONE row (B operand of the transposed MFMA,
+// 8 consecutive channels per k-step -- the layout of sla_c64_apply / xattn_c64): the wave reads its 32 rows once, normalises
+// and splits them once into K/16 x 3 register fragments (96 VGPRs at K = 128) and keeps them while the workgroup walks the N
+// dimension in 64-column chunks whose pre-split weights arrive by LDS-DMA (double-buffered, one barrier per chunk).  The
+// activations never touch LDS, the split work per row drops by N / 128, waves only meet at the weight-chunk barrier, and a
+// workgroup's (panel, chunk) range is balanced over the CUs to +-1 unit.
+template <int KS>
+__global__ __launch_bounds__(512) void gemm1x1_rowreg_kernel(const dawn_conv_desc d, const long M, const int units_per_wg) {
+#if __HIP_DEVICE_COMPILE__
+    constexpr int BM = 256, BNC = 64;                     // rows per panel (8 waves x 32), columns per chunk
+    constexpr int CHB = KS * 6 * BNC * 16;                // bytes of one weight chunk: [KS][3 planes][2 k-halves][64 cols][16 B]
+    constexpr int NDMA = KS * 6 / 8;                      // 1 KB DMA instructions per wave per chunk (KS = 4: 3, KS = 8: 6)
+    static_assert(KS * 6 % 8 == 0, "weight DMA split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int nCh = d.N / BNC;
+    const long nunits = (M / BM) * nCh;
+    const long u0 = (long)blockIdx.x * units_per_wg;
+    const long u1 = u0 + units_per_wg < nunits ? u0 + units_per_wg : nunits;
+    if (u0 >= u1) return;
+    const int ld1 = d.in1 ? d.ld1 : d.ld0;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, KS * 6 * d.N * 16, 0x00020000);
+    auto issueB = [&](long u, int buf) __attribute__((always_inline)) {
+        const int n0 = (int)(u % nCh) * BNC;
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            const int piece = j * 8 + wave;                // (kc, plane, k-half) row of the packed weights: 64 cols x 16 B
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem_b + (size_t)buf * CHB + piece * 1024),
+                                                     16, (unsigned)(lane * 16), (piece * d.N + n0) * 16, 0, 0);
+        }
+    };
+    bf16x8 xs[KS][3];
+    auto load_panel = [&](long panel) __attribute__((always_inline)) {
+        const long r0 = panel * BM + wave * 32;            // wave-uniform first row
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + r0 * d.ld0), 0, 32 * d.ld0 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((d.in1 ? d.in1 : d.in0) + r0 * ld1), 0, 32 * ld1 * 4, 0x00020000);
+        f32x4 raw[KS][2];
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc) {
+            const int cb = 16 * kc;                        // wave-uniform: C0 % 16 == 0
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                raw[kc][h2] = __builtin_bit_cast(
+                    f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((l31 * d.ld0 + cb + 8 * half + 4 * h2) * 4), 0, 0)
+                                     : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((l31 * ld1 + cb - d.C0 + 8 * half + 4 * h2) * 4), 0, 0));
+        }
+        float mu = 0.f, rs = 1.f;
+        if (d.row_mean) { mu = d.row_mean[r0 + l31]; rs = d.row_rstd[r0 + l31]; }
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v8[e] = raw[kc][0][e]; v8[4 + e] = raw[kc][1][e]; }
+            if (d.row_mean) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (v8[e] - mu) * rs;      // == dawn_ln_rows
+            }
+            split3_trunc8(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
+        }
+    };
+
+    long panel = u0 / nCh;
+    issueB(u0, 0);
+    load_panel(panel);
+    for (long u = u0; u < u1; ++u) {
+        const int cur = (int)((u - u0) & 1);
+        const long pn = u / nCh;
+        bool full_wait = u == u0;
+        if (pn != panel) { panel = pn; load_panel(panel); full_wait = true; }   // wave-uniform; rows of the new panel (no LDS involved)
+        // this chunk's weights (this wave's pieces) have landed.  VMEM operations complete in issue order: the 8 row-segment
+        // stores of the previous chunk, issued after the weight request, may stay in flight
+        if (full_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        __builtin_amdgcn_s_barrier();                                   // ... everyone's; the other buffer is no longer read
+        if (u + 1 < u1) issueB(u + 1, cur ^ 1);
+        const unsigned char* Bb = smem_b + (size_t)cur * CHB;
+        f32x16 acc[2];
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+        // weight fragments of k-step kc+1 are requested before the MFMAs of k-step kc (register double buffer): the LDS
+        // latency hides under 12 MFMAs instead of stalling both waves of the SIMD at every step
+        bf16x8 fb[2][2][3];
+        auto read_frags = [&](int kc, int slot) __attribute__((always_inline)) {
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    fb[slot][j][pl] = *reinterpret_cast<const bf16x8*>(Bb + ((size_t)((kc * 3 + pl) * 2 + half) * BNC + j * 32 + l31) * 16);
+        };
+        read_frags(0, 0);
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc) {
+            if (kc + 1 < KS) read_frags(kc + 1, (kc + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);            // keep the requests above this step's MFMAs
+            constexpr int PW[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};     // smallest cross terms first
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[kc & 1][j][PW[t]], xs[kc][PX[t]], acc[j], 0, 0, 0);
+                }
+        }
+        // ---- epilogue.  The accumulators hold lane = row, registers 4g..4g+3 = columns 8g + 4*half + {0..3}: stored directly,
+        // one instruction touches 32 rows x 32 B = 32 cache lines, and the CU's address unit -- one line per cycle or so --
+        // becomes the bottleneck (8 waves x 8 such stores = 4.4 k cycles per chunk, measured as 83 us of 309 that did not
+        // overlap with anything).  Each 32 x 32 tile goes through a wave-private LDS staging tile instead and leaves as
+        // 4 stores of 8 rows x 128 B: whole lines, a quarter of the line touches.
+        const long m = panel * BM + wave * 32 + l31;
+        const int n0 = (int)(u % nCh) * BNC;
+        float* stg = reinterpret_cast<float*>(smem_b + 2 * CHB) + wave * (32 * 36);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int n = n0 + j * 32 + 8 * g + 4 * half;
+                f32x4 v = {acc[j][4 * g], acc[j][4 * g + 1], acc[j][4 * g + 2], acc[j][4 * g + 3]};
+                if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
+                if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
+                if (d.tr) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(d.tr + m * d.ld_tr + n);
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(d.tr_a + n), tb = *reinterpret_cast<const f32x4*>(d.tr_b + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += dawn_silu(t4[e] * ta[e] + tb[e]);
+                }
+                *reinterpret_cast<f32x4*>(stg + l31 * 36 + 8 * g + 4 * half) = v;
+            }
+            // (LDS operations of one wave execute in order: no barrier between the writes above and these reads)
+            float* orow = d.out + (panel * BM + wave * 32 + (lane >> 3)) * d.ld_out + n0 + j * 32 + 4 * (lane & 7);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(stg + ((lane >> 3) + 8 * i) * 36 + 4 * (lane & 7));
+                *reinterpret_cast<f32x4*>(orow + (long)(8 * i) * d.ld_out) = v;
+            }
+        }
+    }
+#endif
+}
+
+static int dawn_ncu() {
+    static int ncu = 0;
+    if (!ncu) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        ncu = n;
+    }
+    return ncu;
+}
+
+bool try_launch_gemm1x1_rowreg(const dawn_conv_desc& d, long M, hipStream_t s) {
+    const int K = d.C0 + d.C1;
+    if ((K != 64 && K != 128) || d.C0 % 16 != 0 || d.C1 % 16 != 0 || d.N % 64 != 0 || M % 256 != 0) return false;
+    if ((long)d.ld0 * 32 * 4 >= (1L << 31) || (long)d.ld1 * 32 * 4 >= (1L << 31)) return false;
+    const long nunits = (M / 256) * (d.N / 64);
+    const int ncu = dawn_ncu();
+    const int per = (int)((nunits + ncu - 1) / ncu);
+    const int nwg = (int)((nunits + per - 1) / per);
+    g_last_nwg = nwg;
+    const size_t lds = (size_t)2 * (K / 16) * 6 * 64 * 16 + 8 * 32 * 36 * 4;      // two weight chunks + the waves' staging tiles
+    if (K == 128) {
+        (void)hipFuncSetAttribute((const void*)gemm1x1_rowreg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm1x1_rowreg_kernel<8>), dim3(nwg), dim3(512), lds, s, d, M, per);
+    } else {
+        (void)hipFuncSetAttribute((const void*)gemm1x1_rowreg_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((gemm1x1_rowreg_kernel<4>), dim3(nwg), dim3(512), lds, s, d, M, per);
+    }
+    return true;
+}
+
 template <int WN>
 void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
     constexpr int BN = 64 * WN;
@@ -1691,6 +1896,8 @@ bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
         (long)d.ld0 * 256 * 4 >= (1L << 31) || (long)d.ld1 * 256 * 4 >= (1L << 31))
         return false;
     const int plan = gemm1x1_split_plan(M, d.N, d.C0, d.C1);
+    // short K: rows stationary in registers (policy bit 0x20000, A/B only: the tiled kernels)
+    if (plan != 0 && !(policy_of(d) & 0x20000) && try_launch_gemm1x1_rowreg(d, M, s)) return true;
     // policy bit 0x8000: 128 x 64 tiles for every eligible shape; 0x10000 (A/B only): never (the round-1 tile policy)
     if (plan != 0 && ((policy_of(d) & 0x8000) || (plan == 3 && !(policy_of(d) & 0x10000)))) launch_gemm1x1_bf16_small(d, M, s);
     else if (plan == 3) {                            // 0x10000: the round-1 choice for these shapes
