@@ -1735,20 +1735,24 @@ __global__ __launch_bounds__(512) void gemm1x1_rowreg_kernel(const dawn_conv_des
         }
     };
 
+    // N = 64: one chunk for every unit -- the weights are fetched once and the waves never meet again
+    const bool single = nCh == 1;
     long panel = u0 / nCh;
     issueB(u0, 0);
     load_panel(panel);
     for (long u = u0; u < u1; ++u) {
-        const int cur = (int)((u - u0) & 1);
+        const int cur = single ? 0 : (int)((u - u0) & 1);
         const long pn = u / nCh;
         bool full_wait = u == u0;
         if (pn != panel) { panel = pn; load_panel(panel); full_wait = true; }   // wave-uniform; rows of the new panel (no LDS involved)
-        // this chunk's weights (this wave's pieces) have landed.  VMEM operations complete in issue order: the 8 row-segment
-        // stores of the previous chunk, issued after the weight request, may stay in flight
-        if (full_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        __builtin_amdgcn_s_barrier();                                   // ... everyone's; the other buffer is no longer read
-        if (u + 1 < u1) issueB(u + 1, cur ^ 1);
+        if (!single || u == u0) {
+            // this chunk's weights (this wave's pieces) have landed.  VMEM operations complete in issue order: the 8 row-segment
+            // stores of the previous chunk, issued after the weight request, may stay in flight
+            if (full_wait) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                               // ... everyone's; the other buffer is no longer read
+            if (!single && u + 1 < u1) issueB(u + 1, cur ^ 1);
+        }
         const unsigned char* Bb = smem_b + (size_t)cur * CHB;
         f32x16 acc[2];
 #pragma unroll
@@ -1825,9 +1829,14 @@ static int dawn_ncu() {
     return ncu;
 }
 
+static bool gemm1x1_rowreg_ok(long M, int N, int C0, int C1) {
+    const int K = C0 + C1;
+    return (K == 64 || K == 128) && C0 % 16 == 0 && C1 % 16 == 0 && N % 64 == 0 && M % 256 == 0 && M >= 12800;
+}
+
 bool try_launch_gemm1x1_rowreg(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int K = d.C0 + d.C1;
-    if ((K != 64 && K != 128) || d.C0 % 16 != 0 || d.C1 % 16 != 0 || d.N % 64 != 0 || M % 256 != 0) return false;
+    if (!gemm1x1_rowreg_ok(M, d.N, d.C0, d.C1)) return false;
     if ((long)d.ld0 * 32 * 4 >= (1L << 31) || (long)d.ld1 * 32 * 4 >= (1L << 31)) return false;
     const long nunits = (M / 256) * (d.N / 64);
     const int ncu = dawn_ncu();
@@ -1897,7 +1906,7 @@ bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
         return false;
     const int plan = gemm1x1_split_plan(M, d.N, d.C0, d.C1);
     // short K: rows stationary in registers (policy bit 0x20000, A/B only: the tiled kernels)
-    if (plan != 0 && !(policy_of(d) & 0x20000) && try_launch_gemm1x1_rowreg(d, M, s)) return true;
+    if (!(policy_of(d) & 0x20000) && try_launch_gemm1x1_rowreg(d, M, s)) return true;
     // policy bit 0x8000: 128 x 64 tiles for every eligible shape; 0x10000 (A/B only): never (the round-1 tile policy)
     if (plan != 0 && ((policy_of(d) & 0x8000) || (plan == 3 && !(policy_of(d) & 0x10000)))) launch_gemm1x1_bf16_small(d, M, s);
     else if (plan == 3) {                            // 0x10000: the round-1 choice for these shapes
@@ -2001,7 +2010,9 @@ extern "C" int dawn_conv_set_debug(void* p) {
 /* 1 when a prologue-free 1x1 projection (M rows, N columns, C0 + C1 input channels, w_bf3 supplied, shipped policy) runs on
  * the split-operand GEMM, whose loader can apply LayerNorm row statistics; the host then skips materialising the
  * normalised rows (see unet_forward._ln_gemm / dawn_ctx.hip). */
-extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1) { return gemm1x1_split_plan(M, N, C0, C1) != 0; }
+extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1) {
+    return gemm1x1_split_plan(M, N, C0, C1) != 0 || gemm1x1_rowreg_ok(M, N, C0, C1);
+}
 
 extern "C" int dawn_conv_gemm_nblocks(long M, int N) {
     if (N <= 64) return dawn_cdiv(M, 128);   // upper bound (the 256-row tile variants launch fewer blocks; the

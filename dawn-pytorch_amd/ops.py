@@ -150,26 +150,19 @@ class HipOps:
             gn_part.dawn_rows = nrows.value      # rows the launch wrote (the rest of the buffer is unused)
         return out
 
-    @staticmethod
-    def _runs_split_kernel(w_bf3, KH, KW, stride, mode, rows, N, C0, C1, tr, gn_part) -> bool:
-        """Profiling label only: does this launch take a split-operand (bf16 pipe) kernel?  Mirrors the dispatch
-        conditions of dawn_conv_gemm for the shapes of the benchmark (3x3/s1 ResBlock convs; 1x1 GEMMs with
-        M >= 12800, M % 256 == 0, N % 64 == 0, 32-channel multiples per source, no GroupNorm sums)."""
+    def _runs_split_kernel(self, w_bf3, KH, KW, stride, mode, rows, N, C0, C1, tr, gn_part) -> bool:
+        """Profiling label only: does this launch take a split-operand (bf16 pipe) kernel?  3x3/s1 ResBlock convs always do;
+        for the 1x1 GEMMs the library's own dispatch predicate is asked (dawn_gemm1x1_split_ok)."""
         if w_bf3 is None or mode != 0 or stride != 1:
             return False
         if KH == 3 and KW == 3:
             return True
-        if not (KH == 1 and KW == 1 and rows >= 12800 and rows % 256 == 0 and N % 64 == 0 and N != 64 and C1 % 32 == 0
-                and C0 % 32 == 0 and gn_part is None):
-            return False
-        t2 = (rows // 256) * (N // 128)
-        return N % 128 != 0 or t2 >= 256 or t2 < 128 or rows >= 51200
+        return KH == 1 and KW == 1 and gn_part is None and self.split_gemm_ok(rows, N, C0, C1)
 
-    @classmethod
-    def split_gemm_ok(cls, rows: int, N: int, C0: int, C1: int = 0) -> bool:
-        """Will a 1x1 projection of this shape run on the split-operand GEMM (which can apply the LayerNorm row
-        statistics in its loader)?  Otherwise the caller materialises the normalised rows for the direct-to-LDS fp32 GEMM."""
-        return cls._runs_split_kernel(True, 1, 1, 1, 0, rows, N, C0, C1, None, None)
+    def split_gemm_ok(self, rows: int, N: int, C0: int, C1: int = 0) -> bool:
+        """Will a 1x1 projection of this shape run on a split-operand GEMM (which can apply the LayerNorm row statistics in
+        its loader)?  Otherwise the caller materialises the normalised rows for the direct-to-LDS fp32 GEMM."""
+        return bool(self.L.dawn_gemm1x1_split_ok(rows, N, C0, C1))
 
     # ------------------------------------------------------------------ GroupNorm / LayerNorm
     def conv_gn_part(self, rows_out: int, N: int, like: Tensor) -> Tensor:
