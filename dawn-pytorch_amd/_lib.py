@@ -38,6 +38,7 @@ class ConvDesc(C.Structure):
         ("w_bf3", c_f),
         ("gn_rows", C.POINTER(C.c_int)),
         ("policy", _i),
+        ("ln_eps", _f),
     ]
 
 
@@ -65,6 +66,7 @@ SIGNATURES = {
     "dawn_sla_apply": [c_f, c_f, _i, _i, c_f, c_f],
     "dawn_sla_ws_floats": [_i, _i, _i],
     "dawn_gemm1x1_split_ok": [_l, _i, _i, _i],
+    "dawn_gemm1x1_ln_inline_ok": [_l, _i, _i, _i],
     "dawn_sla_layer_c64": [c_f, _i, _i, c_f, c_f, c_f, c_f, _f, c_f, c_f, c_f],
     "dawn_frame_attn": [c_f, _i, _i, c_f, c_f],
     "dawn_init_conv_x": [c_f, c_f, c_f, _i, _i, _i, _i, c_f, c_f],

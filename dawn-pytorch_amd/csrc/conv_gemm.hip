@@ -1722,12 +1722,34 @@ __global__ __launch_bounds__(512) void gemm1x1_rowreg_kernel(const dawn_conv_des
         }
         float mu = 0.f, rs = 1.f;
         if (d.row_mean) { mu = d.row_mean[r0 + l31]; rs = d.row_rstd[r0 + l31]; }
+        if (d.ln_eps > 0.f) {
+            // LayerNorm statistics of the lane's row from the registers: this lane holds one half of the K channels, its
+            // xor-32 partner the other half (two-pass: mean, then biased variance of the centred values)
+            float sm = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) sm += (raw[kc][h2].x + raw[kc][h2].y) + (raw[kc][h2].z + raw[kc][h2].w);
+            sm += __shfl_xor(sm, 32, 64);
+            mu = sm * (1.0f / (16 * KS));
+            float sq = 0.f;
+#pragma unroll
+            for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x4 dl = raw[kc][h2] - mu;
+                    sq += (dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w);
+                }
+            sq += __shfl_xor(sq, 32, 64);
+            rs = 1.0f / sqrtf(sq * (1.0f / (16 * KS)) + d.ln_eps);
+        }
+        const bool nrm = d.row_mean != nullptr || d.ln_eps > 0.f;
 #pragma unroll
         for (int kc = 0; kc < KS; ++kc) {
             float v8[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v8[e] = raw[kc][0][e]; v8[4 + e] = raw[kc][1][e]; }
-            if (d.row_mean) {
+            if (nrm) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = (v8[e] - mu) * rs;      // == dawn_ln_rows
             }
@@ -2010,6 +2032,7 @@ extern "C" int dawn_conv_set_debug(void* p) {
 /* 1 when a prologue-free 1x1 projection (M rows, N columns, C0 + C1 input channels, w_bf3 supplied, shipped policy) runs on
  * the split-operand GEMM, whose loader can apply LayerNorm row statistics; the host then skips materialising the
  * normalised rows (see unet_forward._ln_gemm / dawn_ctx.hip). */
+extern "C" int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1) { return gemm1x1_rowreg_ok(M, N, C0, C1); }
 extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1) {
     return gemm1x1_split_plan(M, N, C0, C1) != 0 || gemm1x1_rowreg_ok(M, N, C0, C1);
 }
@@ -2034,6 +2057,14 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     const long M = (d.mode == 0) ? (long)d.F * d.Ho * d.Wo : (long)d.F * d.Hi * d.Wi;
     if (M <= 0 || d.N <= 0) return 0;
     hipStream_t s = (hipStream_t)stream;
+    if (d.ln_eps > 0.f) {                     // LayerNorm inside the GEMM: only the row-stationary kernel holds whole rows
+        if (!(d.w_bf3 && d.mode == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ch_a && !d.pro_act &&
+              !d.pro_add && !d.row_mean && !d.row_rstd && !d.gn_part && (d.C1 != 0) == (d.in1 != nullptr) &&
+              try_launch_gemm1x1_rowreg(d, M, s)))
+            return dawn_set_error_msg(-14, "dawn_conv_gemm: ln_eps needs a split 1x1 projection with dawn_gemm1x1_ln_inline_ok");
+        DAWN_LAUNCH_CHECK();
+        return 0;
+    }
     if ((policy_of(d) & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ch_a &&
         !d.pro_act && !d.pro_add && (d.row_mean == nullptr) == (d.row_rstd == nullptr) && try_launch_gemm1x1_bf16(d, M, s)) {
         DAWN_LAUNCH_CHECK();

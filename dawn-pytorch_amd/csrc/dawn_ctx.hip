@@ -22,6 +22,7 @@
 #include <vector>
 
 extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1);
+extern "C" int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1);
 
 namespace {
 
@@ -293,6 +294,7 @@ struct Eval {
         const float* w = nullptr; const void* w_bf3 = nullptr; const float* bias = nullptr; int N = 0;
         int Fr = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0, KH = 1, KW = 1, stride = 1, pad = 0, mode = 0;
         const float *row_mean = nullptr, *row_rstd = nullptr;
+        float ln_eps = 0.f;
         const float* res = nullptr; int ld_res = 0;
         const float *tr = nullptr, *tr_a = nullptr, *tr_b = nullptr; int ld_tr = 0;
         float* out = nullptr; int ld_out = 0;
@@ -304,7 +306,7 @@ struct Eval {
         d.in0 = a.in0; d.in1 = a.in1; d.C0 = a.C0; d.C1 = a.C1; d.ld0 = a.ld0; d.ld1 = a.ld1;
         d.F = a.Fr; d.Hi = a.Hi; d.Wi = a.Wi; d.Ho = a.Ho ? a.Ho : a.Hi; d.Wo = a.Wo ? a.Wo : a.Wi;
         d.KH = a.KH; d.KW = a.KW; d.stride = a.stride; d.pad = a.pad; d.mode = a.mode;
-        d.w = a.w; d.bias = a.bias; d.N = a.N; d.row_mean = a.row_mean; d.row_rstd = a.row_rstd;
+        d.w = a.w; d.bias = a.bias; d.N = a.N; d.row_mean = a.row_mean; d.row_rstd = a.row_rstd; d.ln_eps = a.ln_eps;
         d.res = a.res; d.ld_res = a.ld_res; d.tr = a.tr; d.ld_tr = a.ld_tr; d.tr_a = a.tr_a; d.tr_b = a.tr_b;
         d.out = a.out; d.ld_out = a.ld_out; d.gn_part = a.gn_part; d.w_bf3 = a.w_bf3; d.gn_rows = a.gn_rows;
         d.policy = c->conv_policy;
@@ -345,7 +347,11 @@ struct Eval {
         T2 o = t2(x.rows, N);
         ConvArgs a;
         a.w = w; a.w_bf3 = w_bf3; a.N = N; a.Fr = Fr; a.Hi = Hi; a.Wi = Wi; a.out = o.p; a.ld_out = N;
-        if (w_bf3 && dawn_gemm1x1_split_ok(x.rows, N, x.C, C1)) {
+        if (w_bf3 && dawn_gemm1x1_ln_inline_ok(x.rows, N, x.C, C1)) {
+            a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.in1 = x2 ? x2->p : nullptr; a.C1 = C1; a.ld1 = C1;
+            a.ln_eps = 1e-5f;
+            conv(a);
+        } else if (w_bf3 && dawn_gemm1x1_split_ok(x.rows, N, x.C, C1)) {
             float* mean = falloc(x.rows);
             float* rstd = falloc(x.rows);
             LAUNCH(dawn_ln_rowstats(x.p, x.C, x.C, x2 ? x2->p : nullptr, C1, C1, x.rows, 1e-5f, mean, rstd, cur));

@@ -100,7 +100,7 @@ class HipOps:
                   row_stats: Optional[Tuple[Tensor, Tensor]] = None, ch_ab: Optional[Tuple[Tensor, Tensor]] = None,
                   pro_act: int = 0, pro_add: Optional[Tensor] = None, res: Optional[Tensor] = None,
                   tr: Optional[Tuple[Tensor, Tensor, Tensor]] = None, out: Optional[Tensor] = None,
-                  gn_part: Optional[Tensor] = None, w_bf3: Optional[Tensor] = None) -> Tensor:
+                  gn_part: Optional[Tensor] = None, w_bf3: Optional[Tensor] = None, ln_eps: float = 0.0) -> Tensor:
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
         rows_out = F * Ho * Wo
@@ -127,6 +127,7 @@ class HipOps:
         d.gn_part = _p(gn_part)
         d.w_bf3 = _p(w_bf3)
         d.policy = self.conv_policy
+        d.ln_eps = ln_eps
         nrows = C.c_int(0)
         if gn_part is not None:
             d.gn_rows = C.pointer(nrows)
@@ -140,7 +141,7 @@ class HipOps:
             rows_gemm = rows_out if mode == 0 else F * Hi * Wi * 4
             self.prof.append((2.0 * rows_gemm * N * KH * KW * (d.C0 + d.C1), e0, e1,
                               f"M={rows_gemm} N={N} K={KH * KW * (d.C0 + d.C1)} k={KH}x{KW} s={stride} mode={mode} "
-                              f"pro={'r' if row_stats else ''}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}"
+                              f"pro={'r' if row_stats else ('n' if ln_eps else '')}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}"
                               + (" split-bf16" if self._runs_split_kernel(w_bf3, KH, KW, stride, mode, rows_out, N, d.C0, d.C1, tr,
                                                                           gn_part) else ""),
                               4.0 * (F * Hi * Wi * (d.C0 + d.C1) + rows_out * N + KH * KW * (d.C0 + d.C1) * N * (4 if mode else 1))))
@@ -158,6 +159,11 @@ class HipOps:
         if KH == 3 and KW == 3:
             return True
         return KH == 1 and KW == 1 and gn_part is None and self.split_gemm_ok(rows, N, C0, C1)
+
+    def ln_inline_ok(self, rows: int, N: int, C0: int, C1: int = 0) -> bool:
+        """May the projection compute the LayerNorm of its input rows itself (conv_gemm(ln_eps=...): the row-stationary
+        split GEMM holds whole rows in registers), so that no statistics pass reads them first?"""
+        return bool(self.L.dawn_gemm1x1_ln_inline_ok(rows, N, C0, C1))
 
     def split_gemm_ok(self, rows: int, N: int, C0: int, C1: int = 0) -> bool:
         """Will a 1x1 projection of this shape run on a split-operand GEMM (which can apply the LayerNorm row statistics in

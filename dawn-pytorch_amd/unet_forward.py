@@ -88,10 +88,12 @@ def time_film(ops, P: PackedUNet, t: float, like: Tensor) -> Tensor:
 
 
 def _ln_gemm(ops, x: Tensor, x2: Optional[Tensor], w: Tensor, N: int, w_bf3: Optional[Tensor], **g) -> Tensor:
-    """LayerNorm over the channels of [x | x2] (gain folded into w) followed by a projection.  On the split-operand GEMM
-    the normalisation rides in the loader (per-row mean / rstd from a read-only statistics pass): the normalised rows are
-    never written.  Otherwise they are materialised once so that the fp32 GEMM stays prologue-free (direct-to-LDS)."""
+    """LayerNorm over the channels of [x | x2] (gain folded into w) followed by a projection.  The row-stationary GEMM
+    (<= 128 channels) normalises the rows it holds itself; on the tiled split-operand GEMM the normalisation rides in the
+    loader (per-row mean / rstd from a read-only statistics pass): the normalised rows are never written.  Otherwise they are materialised once so that the fp32 GEMM stays prologue-free (direct-to-LDS)."""
     C1 = 0 if x2 is None else x2.shape[1]
+    if w_bf3 is not None and ops.ln_inline_ok(x.shape[0], N, x.shape[1], C1):
+        return ops.conv_gemm(x, w, N, in1=x2, ln_eps=1e-5, w_bf3=w_bf3, **g)       # rows normalised inside the GEMM
     if w_bf3 is not None and ops.split_gemm_ok(x.shape[0], N, x.shape[1], C1):
         return ops.conv_gemm(x, w, N, in1=x2, row_stats=ops.ln_rowstats(x, x2), w_bf3=w_bf3, **g)
     return ops.conv_gemm(ops.ln_rows(x, x2), w, N, w_bf3=w_bf3, **g)

@@ -58,6 +58,9 @@ typedef struct dawn_conv_desc {
     int* gn_rows;                                  /* optional HOST pointer: receives the number of gn_part rows this launch
                                                       writes (= its thread-block count; <= dawn_conv_gemm_nblocks) */
     int policy;                                    /* kernel-selection policy bits (see below); 0 = shipped default */
+    float ln_eps;                                  /* > 0: LayerNorm (no gain) over the C0+C1 channels of every input row, computed by the
+                                                      GEMM itself from the rows it holds -- no statistics pass (instead of row_mean /
+                                                      row_rstd; only shapes with dawn_gemm1x1_ln_inline_ok, error otherwise) */
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;
@@ -314,6 +317,7 @@ int dawn_ctx_profile_read(dawn_ctx* ctx, double* out4, int max_entries);
 int dawn_chw_to_hwc(const float* in, int C, long HW, float* out, void* stream);
 int dawn_rotary_tables(const float* freqs16, int n, int pos0, float* cos_out, float* sin_out, void* stream);
 int dawn_rel_pos_bucket(int rel);                                     /* MT:92-109, num_buckets = max_distance = 32 (host) */
+int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1);       /* host: may dawn_conv_desc.ln_eps be used for this projection? */
 int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1);             /* host: does a 1x1 projection take the split GEMM? */
 
 #ifdef __cplusplus

@@ -43,11 +43,14 @@ class RefOps:
     # ------------------------------------------------------------------ conv / linear
     def conv_gemm(self, in0, w, N, *, F, Hi, Wi, Ho=None, Wo=None, KH=1, KW=1, stride=1, pad=0, mode=0, in1=None,
                   bias=None, row_stats=None, ch_ab=None, pro_act=0, pro_add=None, res=None, tr=None, out=None, w_bf3=None,
-                  gn_part=None):
+                  gn_part=None, ln_eps=0.0):
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
         x = in0 if in1 is None else torch.cat((in0, in1), dim=1)
         Cin = x.shape[1]
+        if ln_eps:                                   # LayerNorm (no gain) inside the projection
+            mu = x.mean(dim=1, keepdim=True)
+            x = (x - mu) * torch.rsqrt(((x - mu) ** 2).mean(dim=1, keepdim=True) + ln_eps)
         if row_stats is not None:
             x = (x - row_stats[0][:, None]) * row_stats[1][:, None]
         if ch_ab is not None:
@@ -168,6 +171,10 @@ class RefOps:
     @staticmethod
     def can_fuse_xattn(Cin, Co, C0, HW=32):
         return Co == 64 and Cin in (64, 128) and C0 % 8 == 0
+
+    @staticmethod
+    def ln_inline_ok(rows, N, C0, C1=0):
+        return (C0 + C1) in (64, 128)    # exercise both LayerNorm + projection forms on CPU
 
     @staticmethod
     def split_gemm_ok(rows, N, C0, C1=0):

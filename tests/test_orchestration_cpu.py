@@ -52,6 +52,10 @@ class _NoFusionOps(RefOps):
         return False
 
     @staticmethod
+    def ln_inline_ok(rows, N, C0, C1=0):
+        return False
+
+    @staticmethod
     def can_fuse_xattn_out(Co, HW):
         return False
 
