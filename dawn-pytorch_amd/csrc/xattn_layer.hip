@@ -357,7 +357,10 @@ extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const flo
     long grid = (ntiles + 7) / 8;
     const bool split = wq_bf3 != nullptr && C0 % 16 == 0;
     // resident blocks: fp32 weights 2 per CU at 56 KB of LDS (Cin = 64), 1 at 105 KB; split planes 2 per CU at 79 KB, 1 at 151 KB
-    const long cap = (Cin == 64 && !split) ? 512 : 256;       // the split Cin = 64 kernel runs two 256-register waves per SIMD
+    // the split kernels run two 256-register waves per SIMD: a CU holding one of their persistent workgroups has no registers
+    // left for anybody else, and the one-block GroupNorm reduction of the OTHER stream (on the critical path of every ResBlock)
+    // waited for a whole cross-attention launch to drain (23 us average instead of 5).  Eight CUs stay out of the persistent grid.
+    const long cap = (Cin == 64 && !split) ? 512 : 248;
     if (grid > cap) grid = cap;
     int lds = ((split ? Cin * 1152 / 4 : (Cin / 4) * 192 * 4) + 192 + 8 * 192) * 4;
 #ifdef DAWN_XA_TIMING
