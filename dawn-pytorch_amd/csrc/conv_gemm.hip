@@ -1840,6 +1840,157 @@ __global__ __launch_bounds__(512) void gemm1x1_rowreg_kernel(const dawn_conv_des
 #endif
 }
 
+// Deep-K sibling of gemm1x1_rowreg_kernel for narrow outputs (N = 64 / 128 / 192: the cross-attention to_q projections of the
+// 256..1024-channel blocks, K a multiple of 128): the wave keeps the accumulators of ALL its N / 64 column chunks (96 VGPRs at
+// N = 192) and walks K in 128-channel blocks -- rows of the block fetched, normalised (row statistics supplied) and split once
+// into registers, then one weight chunk per (K block, column chunk) step through the same double-buffered LDS-DMA pipeline.
+// The tiled kernel re-split every row for each of its N / 64 column tiles and ran fetch | MFMA | store phases back to back.
+template <int NCH, int KS>
+__global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_desc d, const long M, const int panels_per_wg) {
+#if __HIP_DEVICE_COMPILE__
+    // KS k-steps (16 channels each) per K block: 8 with one column chunk, 4 with two or three (up to 96 accumulator registers)
+    constexpr int BM = 256, BNC = 64, KBC = 16 * KS;
+    constexpr int CHB = KS * 6 * BNC * 16;
+    constexpr int NDMA = KS * 6 / 8;
+    static_assert(KS * 6 % 8 == 0, "weight DMA split");
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int nKB = (d.C0 + d.C1) / KBC;
+    const long npanels = M / BM;
+    const long p0 = (long)blockIdx.x * panels_per_wg;
+    const long p1 = p0 + panels_per_wg < npanels ? p0 + panels_per_wg : npanels;
+    if (p0 >= p1) return;
+    const int ld1 = d.in1 ? d.ld1 : d.ld0;
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, (d.C0 + d.C1) / 16 * 6 * d.N * 16, 0x00020000);
+    auto issueB = [&](int kb, int c, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < NDMA; ++j) {
+            const int piece = kb * (KS * 6) + j * 8 + wave;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem_b + (size_t)buf * CHB + (j * 8 + wave) * 1024),
+                                                     16, (unsigned)(lane * 16), (piece * d.N + c * BNC) * 16, 0, 0);
+        }
+    };
+    bf16x8 xs[KS][3];
+    float mu = 0.f, rs = 1.f;
+    auto load_block = [&](long panel, int kb) __attribute__((always_inline)) {
+        const long r0 = panel * BM + wave * 32;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + r0 * d.ld0), 0, 32 * d.ld0 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((d.in1 ? d.in1 : d.in0) + r0 * ld1), 0, 32 * ld1 * 4, 0x00020000);
+        if (kb == 0 && d.row_mean) { mu = d.row_mean[r0 + l31]; rs = d.row_rstd[r0 + l31]; }
+        f32x4 raw[KS][2];
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc) {
+            const int cb = kb * KBC + 16 * kc;             // wave-uniform: C0 % 16 == 0
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+                raw[kc][h2] = __builtin_bit_cast(
+                    f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((l31 * d.ld0 + cb + 8 * half + 4 * h2) * 4), 0, 0)
+                                     : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((l31 * ld1 + cb - d.C0 + 8 * half + 4 * h2) * 4), 0, 0));
+        }
+#pragma unroll
+        for (int kc = 0; kc < KS; ++kc) {
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { v8[e] = raw[kc][0][e]; v8[4 + e] = raw[kc][1][e]; }
+            if (d.row_mean) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v8[e] = (v8[e] - mu) * rs;      // == dawn_ln_rows
+            }
+            split3_trunc8(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
+        }
+    };
+    f32x16 acc[NCH][2];
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
+    float* stg = reinterpret_cast<float*>(smem_b + 2 * CHB) + wave * (32 * 36);
+    int buf = 0;
+    issueB(0, 0, 0);
+    for (long panel = p0; panel < p1; ++panel) {
+        for (int kb = 0; kb < nKB; ++kb) {
+            load_block(panel, kb);                          // the only VMEM loads of the loop besides the weight requests
+            const bool last_kb = kb == nKB - 1;
+#pragma unroll
+            for (int c = 0; c < NCH; ++c) {
+                // weights of this step have landed (requested one step ago; VMEM completes in issue order: after an epilogue
+                // with no row fetch since, its 8 stores may stay in flight)
+                if (c > 0 && last_kb && !(d.bias || d.res || d.tr)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                {   // request the next step's chunk into the other buffer
+                    int nkb = kb, nc = c + 1;
+                    if (nc == NCH) { nc = 0; nkb = kb + 1; if (nkb == nKB) nkb = 0; }
+                    if (c + 1 < NCH || kb + 1 < nKB || panel + 1 < p1) issueB(nkb, nc, buf ^ 1);
+                }
+                const unsigned char* Bb = smem_b + (size_t)buf * CHB;
+                // weight fragments: double-buffered over the k-steps where the register budget allows (one column chunk)
+                constexpr int NFB = NCH == 1 ? 2 : 1;
+                bf16x8 fb[NFB][2][3];
+                auto read_frags = [&](int kc, int slot) __attribute__((always_inline)) {
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            fb[slot][j][pl] = *reinterpret_cast<const bf16x8*>(Bb + ((size_t)((kc * 3 + pl) * 2 + half) * BNC + j * 32 + l31) * 16);
+                };
+                if (NFB == 2) read_frags(0, 0);
+#pragma unroll
+                for (int kc = 0; kc < KS; ++kc) {
+                    if (NFB == 2) {
+                        if (kc + 1 < KS) read_frags(kc + 1, (kc + 1) & 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else {
+                        read_frags(kc, 0);
+                    }
+                    constexpr int PW[6] = {0, 2, 1, 0, 1, 0}, PX[6] = {2, 0, 1, 1, 0, 0};
+#pragma unroll
+                    for (int t = 0; t < 6; ++t)
+#pragma unroll
+                        for (int j = 0; j < 2; ++j)
+                            acc[c][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[NFB == 2 ? (kc & 1) : 0][j][PW[t]], xs[kc][PX[t]], acc[c][j], 0, 0, 0);
+                }
+                buf ^= 1;
+                if (last_kb) {
+                    const long m = panel * BM + wave * 32 + l31;
+                    const int n0 = c * BNC;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const int n = n0 + j * 32 + 8 * g + 4 * half;
+                            f32x4 v = {acc[c][j][4 * g], acc[c][j][4 * g + 1], acc[c][j][4 * g + 2], acc[c][j][4 * g + 3]};
+                            if (d.bias) v = v + *reinterpret_cast<const f32x4*>(d.bias + n);
+                            if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
+                            if (d.tr) {
+                                const f32x4 t4 = *reinterpret_cast<const f32x4*>(d.tr + m * d.ld_tr + n);
+                                const f32x4 ta = *reinterpret_cast<const f32x4*>(d.tr_a + n), tb = *reinterpret_cast<const f32x4*>(d.tr_b + n);
+#pragma unroll
+                                for (int e = 0; e < 4; ++e) v[e] += dawn_silu(t4[e] * ta[e] + tb[e]);
+                            }
+                            *reinterpret_cast<f32x4*>(stg + l31 * 36 + 8 * g + 4 * half) = v;
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) acc[c][j][4 * g + e] = 0.f;
+                        }
+                        float* orow = d.out + (panel * BM + wave * 32 + (lane >> 3)) * d.ld_out + n0 + j * 32 + 4 * (lane & 7);
+#pragma unroll
+                        for (int i = 0; i < 4; ++i)
+                            *reinterpret_cast<f32x4*>(orow + (long)(8 * i) * d.ld_out) =
+                                *reinterpret_cast<const f32x4*>(stg + ((lane >> 3) + 8 * i) * 36 + 4 * (lane & 7));
+                    }
+                }
+            }
+        }
+    }
+#endif
+}
+
 static int dawn_ncu() {
     static int ncu = 0;
     if (!ncu) {
@@ -1854,6 +2005,30 @@ static int dawn_ncu() {
 static bool gemm1x1_rowreg_ok(long M, int N, int C0, int C1) {
     const int K = C0 + C1;
     return (K == 64 || K == 128) && C0 % 16 == 0 && C1 % 16 == 0 && N % 64 == 0 && M % 256 == 0 && M >= 12800;
+}
+
+static bool gemm1x1_rowacc_ok(long M, int N, int C0, int C1) {
+    const int K = C0 + C1;
+    return K >= 256 && K % 128 == 0 && C0 % 16 == 0 && C1 % 16 == 0 && N % 64 == 0 && N <= 192 && M % 256 == 0 && M >= 12800;
+}
+
+bool try_launch_gemm1x1_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
+    if (!gemm1x1_rowacc_ok(M, d.N, d.C0, d.C1)) return false;
+    if ((long)d.ld0 * 32 * 4 >= (1L << 31) || (long)d.ld1 * 32 * 4 >= (1L << 31) || (long)(d.C0 + d.C1) / 16 * 6 * d.N * 16 >= (1L << 31)) return false;
+    const long npanels = M / 256;
+    const int ncu = dawn_ncu();
+    const int per = (int)((npanels + ncu - 1) / ncu);
+    const int nwg = (int)((npanels + per - 1) / per);
+    g_last_nwg = nwg;
+#define LAUNCH_RA(NCHV, KSV)                                                                                              \
+    do {                                                                                                                  \
+        const size_t lds = (size_t)2 * KSV * 6 * 64 * 16 + 8 * 32 * 36 * 4;                                               \
+        (void)hipFuncSetAttribute((const void*)gemm1x1_rowacc_kernel<NCHV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm1x1_rowacc_kernel<NCHV, KSV>), dim3(nwg), dim3(512), lds, s, d, M, per);                   \
+    } while (0)
+    if (d.N == 64) LAUNCH_RA(1, 8); else if (d.N == 128) LAUNCH_RA(2, 4); else LAUNCH_RA(3, 4);
+#undef LAUNCH_RA
+    return true;
 }
 
 bool try_launch_gemm1x1_rowreg(const dawn_conv_desc& d, long M, hipStream_t s) {
@@ -1929,6 +2104,7 @@ bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int plan = gemm1x1_split_plan(M, d.N, d.C0, d.C1);
     // short K: rows stationary in registers (policy bit 0x20000, A/B only: the tiled kernels)
     if (!(policy_of(d) & 0x20000) && try_launch_gemm1x1_rowreg(d, M, s)) return true;
+    if (!(policy_of(d) & 0x20000) && try_launch_gemm1x1_rowacc(d, M, s)) return true;
     // policy bit 0x8000: 128 x 64 tiles for every eligible shape; 0x10000 (A/B only): never (the round-1 tile policy)
     if (plan != 0 && ((policy_of(d) & 0x8000) || (plan == 3 && !(policy_of(d) & 0x10000)))) launch_gemm1x1_bf16_small(d, M, s);
     else if (plan == 3) {                            // 0x10000: the round-1 choice for these shapes
@@ -2034,7 +2210,7 @@ extern "C" int dawn_conv_set_debug(void* p) {
  * normalised rows (see unet_forward._ln_gemm / dawn_ctx.hip). */
 extern "C" int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1) { return gemm1x1_rowreg_ok(M, N, C0, C1); }
 extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1) {
-    return gemm1x1_split_plan(M, N, C0, C1) != 0 || gemm1x1_rowreg_ok(M, N, C0, C1);
+    return gemm1x1_split_plan(M, N, C0, C1) != 0 || gemm1x1_rowreg_ok(M, N, C0, C1) || gemm1x1_rowacc_ok(M, N, C0, C1);
 }
 
 extern "C" int dawn_conv_gemm_nblocks(long M, int N) {

@@ -13,6 +13,7 @@ SHAPES = [  # (M, N, K, row stats, residual)
     (204800, 128, 256, False, True), (51200, 256, 256, False, True), (204800, 192, 256, True, False),
     (204800, 192, 128, True, False), (51200, 768, 128, True, False), (51200, 128, 512, False, True),
     (819200, 64, 128, False, True), (204800, 128, 64, False, False),
+    (819200, 192, 256, True, False), (51200, 192, 512, True, False), (12800, 192, 1024, True, False), (12800, 192, 512, True, False),
 ]
 ap = argparse.ArgumentParser()
 ap.add_argument("--policy", default="0")
