@@ -301,7 +301,7 @@ def main():
                         "conv3x3_bf16_v2_kernel (3x3 ResBlock convs: fp32 operands split exactly into 3 bf16 pieces, 6 cross "
                         "terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate)"),
             "gemm1x1": ("hbm_bytes_per_launch_gemm1x1_bf16",
-                        "gemm1x1_bf16_kernel (1x1 projections: to_qkv / to_out / to_q / res_conv, same split-operand scheme)"),
+                        "gemm1x1_rowreg / gemm1x1_rowacc / gemm1x1_bf16 kernels (1x1 projections: to_qkv / to_out / to_q / res_conv, same split-operand scheme)"),
             "fp32": ("hbm_bytes_per_launch_fp32",
                      "conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA implicit GEMM: thin N=64 1x1, 4x4/s2, transposed 4x4)"),
         }
