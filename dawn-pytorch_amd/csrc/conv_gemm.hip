@@ -815,7 +815,7 @@ bool try_launch_halo(const dawn_conv_desc& d, long M, hipStream_t s) {
 // Structure = conv3x3_halo_kernel; the staged fp32 patch is split ONCE per channel chunk into three bf16 planes
 // in LDS ([plane][k-half][pos][8 ch], conflict-free ds_read_b128), the weights arrive pre-split from the host
 // ([chunk][plane][k-half][N][8]).
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef dawn_bf16x8 bf16x8;
 
 __device__ __forceinline__ void split3(const f32x4 v, uint2& p1, uint2& p2, uint2& p3) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -830,26 +830,6 @@ __device__ __forceinline__ void split3(const f32x4 v, uint2& p1, uint2& p2, uint
     p1 = *reinterpret_cast<uint2*>(&h1);
     p2 = *reinterpret_cast<uint2*>(&h2);
     p3 = *reinterpret_cast<uint2*>(&h3);
-}
-
-// exact truncation split of 8 values into three bf16x8 fragments (see temporal_layer.hip split3_oct): p1 + p2 + p3 == v
-__device__ __forceinline__ void split3_trunc8(const float (&v)[8], bf16x8& p1, bf16x8& p2, bf16x8& p3) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 q1, q2, q3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = v[2 * i], b = v[2 * i + 1];
-        const unsigned a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
-        const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
-        const unsigned a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
-        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
-        q1[i] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
-        q2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
-        q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-    }
-    p1 = __builtin_bit_cast(bf16x8, q1);
-    p2 = __builtin_bit_cast(bf16x8, q2);
-    p3 = __builtin_bit_cast(bf16x8, q3);
 }
 
 template <int BN, int WN, int NT>
@@ -1753,7 +1733,7 @@ __global__ __launch_bounds__(512) void gemm1x1_rowreg_kernel(const dawn_conv_des
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = (v8[e] - mu) * rs;      // == dawn_ln_rows
             }
-            split3_trunc8(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
+            dawn_split3_oct(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
         }
     };
 
@@ -1900,7 +1880,7 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = (v8[e] - mu) * rs;      // == dawn_ln_rows
             }
-            split3_trunc8(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
+            dawn_split3_oct(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
         }
     };
     f32x16 acc[NCH][2];

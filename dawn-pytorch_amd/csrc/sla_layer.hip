@@ -160,7 +160,6 @@ __global__ __launch_bounds__(512) void sla_c64_context_kernel(const float* __res
 //  * the softmax over pixels uses a running column max (flash-attention style rescale of ctx / den when it
 //    grows) instead of a first sweep that recomputes K only to find the max: softmax is shift-invariant, so
 //    the result differs from the two-sweep kernel by rounding only.
-typedef __bf16 bf16x8s __attribute__((ext_vector_type(8)));
 
 __device__ __forceinline__ void split3_quad(const f32x4 v, uint2& p1, uint2& p2, uint2& p3) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -320,27 +319,7 @@ __global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* __restr
 // (22.5 k pipe cycles) instead of 512 fp32 ones (32.8 k).
 // Work split: `tiles_per_block` consecutive (frame, 32-pixel tile) units per block, grid = number of CUs: every CU gets the
 // same number of tiles (the (frame, half) grid of the fp32 kernel was 400 one-per-CU blocks on 256 CUs = 1.56 rounds).
-typedef __bf16 bf16x8a __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3_oct(const float (&v)[8], bf16x8a& p1, bf16x8a& p2, bf16x8a& p3) {
-    // exact truncation split (see temporal_layer.hip): p1 + p2 + p3 == v bit for bit
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 q1, q2, q3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = v[2 * i], b = v[2 * i + 1];
-        const unsigned a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
-        const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
-        const unsigned a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
-        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
-        q1[i] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
-        q2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
-        q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-    }
-    p1 = __builtin_bit_cast(bf16x8a, q1);
-    p2 = __builtin_bit_cast(bf16x8a, q2);
-    p3 = __builtin_bit_cast(bf16x8a, q3);
-}
+typedef dawn_bf16x8 bf16x8a;
 
 __global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* __restrict__ x, int HW, int F,
                                                                  const unsigned short* __restrict__ wqkv_s,
@@ -411,7 +390,7 @@ __global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* __
                 float xn[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e) xn[e] = (xv[kc][e] - mu) * rs;
-                split3_oct(xn, xs[kc][0], xs[kc][1], xs[kc][2]);
+                dawn_split3_oct(xn, xs[kc][0], xs[kc][1], xs[kc][2]);
             }
 
             f32x16 oT[2];
@@ -545,8 +524,8 @@ __device__ __forceinline__ void sla_ctx_post(f32x16& kt, const f32x16& vt, int t
 #pragma unroll
         for (int i = 0; i < 8; ++i) { ek[i] = kt[8 * j + i]; vv[i] = vt[8 * j + i]; }
         bf16x8a e3[3], v3[3];
-        split3_oct(ek, e3[0], e3[1], e3[2]);
-        split3_oct(vv, v3[0], v3[1], v3[2]);
+        dawn_split3_oct(ek, e3[0], e3[1], e3[2]);
+        dawn_split3_oct(vv, v3[0], v3[1], v3[2]);
 #pragma unroll
         for (int u = 0; u < 6; ++u) ctx = __builtin_amdgcn_mfma_f32_32x32x16_bf16(e3[PA[u]], v3[PB[u]], ctx, 0, 0, 0);
     }

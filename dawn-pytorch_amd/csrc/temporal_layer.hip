@@ -59,7 +59,7 @@ __device__ __forceinline__ f32x16 proj_T(const float* wp, int Nw, int n, int hal
 // ([plane 3][chunk 4][k-half 2][row][8 channels], shared by all 8 heads x {q,k,v}), the pre-split weight fragments
 // (pack_bf3 image [4][3][2][768][8]) are read straight from L2 one chunk ahead: 24 bf16 MFMAs (768 cycles) replace
 // 32 fp32 MFMAs (2048 cycles) per 32x32 projection tile, and the per-head weight staging + its barrier disappear.
-typedef __bf16 bf16x8t __attribute__((ext_vector_type(8)));
+typedef dawn_bf16x8 bf16x8t;
 
 __device__ __forceinline__ void split3_quad_t(const f32x4 v, uint2& p1, uint2& p2, uint2& p3) {
     typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
@@ -508,24 +508,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
 // bits of r, r2 = r - p2 (exact, <= 8 significant bits left) = p3.  p1 + p2 + p3 == x bit for bit, every piece is a valid
 // bf16, and the instruction mix is the cheap one on gfx950 (tools/ubench/valu_rate.hip: v_and / v_sub issue at ~2.4 cycles
 // with two waves per SIMD, v_cvt_pk_bf16_f32 / v_lshlrev / v_perm at ~4.3): per pair 4 v_and + 4 v_sub + 3 v_perm.
-__device__ __forceinline__ void split3_oct(const float (&v)[8], bf16x8t& p1, bf16x8t& p2, bf16x8t& p3) {
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 q1, q2, q3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = v[2 * i], b = v[2 * i + 1];
-        const unsigned a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
-        const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
-        const unsigned a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
-        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
-        q1[i] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);          // [hi16(a) | hi16(b) << 16]
-        q2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
-        q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-    }
-    p1 = __builtin_bit_cast(bf16x8t, q1);
-    p2 = __builtin_bit_cast(bf16x8t, q2);
-    p3 = __builtin_bit_cast(bf16x8t, q3);
-}
+// (dawn_split3_oct, dawn_common.h)
 
 // Sum over the 16 lanes of a DPP row, result in every lane, as four v_add_f32_dpp (quad xor 1, quad xor 2, half-row mirror,
 // row mirror): same pairing tree as the xor butterfly (bit-identical), without its ds_bpermute round trips.
@@ -747,7 +730,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                         kr[4 * cc + 3] = kT[4 * c + 3] * cs.y + kT[4 * c + 2] * sn.y;
                     }
                     bf16x8t k1, k2, k3;
-                    split3_oct(kr, k1, k2, k3);
+                    dawn_split3_oct(kr, k1, k2, k3);
                     if (j < Fext) {
                         unsigned char* dst = Kp + ((size_t)(kc * 2 + half) * FA + j) * 16;
                         *reinterpret_cast<bf16x8t*>(dst) = k1;
@@ -772,7 +755,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                         }
                     }
                     bf16x8t v1, v2, v3;
-                    split3_oct(vr, v1, v2, v3);
+                    dawn_split3_oct(vr, v1, v2, v3);
                     unsigned char* dst = Vt + ((size_t)((2 * rt + g) * 2 + half) * 32 + l31) * 16;
                     *reinterpret_cast<bf16x8t*>(dst) = v1;
                     *reinterpret_cast<bf16x8t*>(dst + (size_t)NBV * 64 * 16) = v2;
@@ -809,7 +792,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                     kr[4 * cc + 3] = kT[4 * c + 3] * cs.y + kT[4 * c + 2] * sn.y;
                 }
                 bf16x8t k1, k2, k3;
-                split3_oct(kr, k1, k2, k3);
+                dawn_split3_oct(kr, k1, k2, k3);
                 if (j < Fext) {
                     unsigned char* dst = Kp + ((size_t)(kc * 2 + half) * FA + j) * 16;
                     *reinterpret_cast<bf16x8t*>(dst) = k1;
@@ -831,7 +814,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                     }
                 }
                 bf16x8t v1, v2, v3;
-                split3_oct(vr, v1, v2, v3);
+                dawn_split3_oct(vr, v1, v2, v3);
                 unsigned char* dst = Vt + ((size_t)((2 * rt + g) * 2 + half) * 32 + l31) * 16;
                 *reinterpret_cast<bf16x8t*>(dst) = v1;
                 *reinterpret_cast<bf16x8t*>(dst + (size_t)NBV * 64 * 16) = v2;
@@ -869,7 +852,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                         qr[4 * cc + 2] = a2 * cs.y - a3 * sn.y;
                         qr[4 * cc + 3] = a3 * cs.y + a2 * sn.y;
                     }
-                    split3_oct(qr, qp[0][kc], qp[1][kc], qp[2][kc]);
+                    dawn_split3_oct(qr, qp[0][kc], qp[1][kc], qp[2][kc]);
                 }
             }
             if (h < 2) TSTAMP();   // Q projected + rotated
@@ -943,7 +926,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
 #pragma unroll
                     for (int i = 0; i < 8; ++i) pr[i] = st[t][8 * g + i];
                     bf16x8t pp[3];
-                    split3_oct(pr, pp[0], pp[1], pp[2]);
+                    dawn_split3_oct(pr, pp[0], pp[1], pp[2]);
 #pragma unroll
                     for (int u = 0; u < 6; ++u) o = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[PA6[u]], pp[PB6[u]], o, 0, 0, 0);
                 }
@@ -1040,7 +1023,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                     float orr[8];
 #pragma unroll
                     for (int i = 0; i < 8; ++i) orr[i] = oT[8 * kc + i];
-                    split3_oct(orr, op[0][kc], op[1][kc], op[2][kc]);
+                    dawn_split3_oct(orr, op[0][kc], op[1][kc], op[2][kc]);
                 }
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt)

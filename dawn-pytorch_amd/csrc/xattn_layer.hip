@@ -42,27 +42,7 @@ __device__ __forceinline__ float x32(float v) { return v + __shfl_xor(v, 32, 64)
 // accumulate, see conv_gemm.hip): the pre-split weight planes (pack_bf3 image, [CIN/16][3][2][192][8]) take the place of the fp32
 // weights in LDS (72 / 144 KB), the lane's LayerNorm'ed channels (8 consecutive ones per k-step: B operand, lane = pixel) are
 // split once per tile in registers.  144 (288) bf16 MFMAs of 32 cycles instead of 192 (384) fp32 ones of 64 per tile.
-typedef __bf16 bf16x8x __attribute__((ext_vector_type(8)));
-
-__device__ __forceinline__ void split3_oct(const float (&v)[8], bf16x8x& p1, bf16x8x& p2, bf16x8x& p3) {
-    // exact truncation split (see temporal_layer.hip): p1 + p2 + p3 == v bit for bit
-    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 q1, q2, q3;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float a = v[2 * i], b = v[2 * i + 1];
-        const unsigned a1 = __float_as_uint(a) & 0xffff0000u, b1 = __float_as_uint(b) & 0xffff0000u;
-        const float ra = a - __uint_as_float(a1), rb = b - __uint_as_float(b1);
-        const unsigned a2 = __float_as_uint(ra) & 0xffff0000u, b2 = __float_as_uint(rb) & 0xffff0000u;
-        const float sa = ra - __uint_as_float(a2), sb = rb - __uint_as_float(b2);
-        q1[i] = __builtin_amdgcn_perm(b1, a1, 0x07060302u);
-        q2[i] = __builtin_amdgcn_perm(b2, a2, 0x07060302u);
-        q3[i] = __builtin_amdgcn_perm(__float_as_uint(sb), __float_as_uint(sa), 0x07060302u);
-    }
-    p1 = __builtin_bit_cast(bf16x8x, q1);
-    p2 = __builtin_bit_cast(bf16x8x, q2);
-    p3 = __builtin_bit_cast(bf16x8x, q3);
-}
+typedef dawn_bf16x8 bf16x8x;
 
 template <int CIN, bool SPLIT>
 __global__ __launch_bounds__(512, (CIN == 64 && !SPLIT) ? 4 : 2) void xattn_c64_kernel(const float* __restrict__ in0, int C0, int ld0,
@@ -155,7 +135,7 @@ __global__ __launch_bounds__(512, (CIN == 64 && !SPLIT) ? 4 : 2) void xattn_c64_
             for (int kc = 0; kc < CIN / 16; ++kc) {
                 const float v8[8] = {xn[2 * kc].x, xn[2 * kc].y, xn[2 * kc].z, xn[2 * kc].w,
                                      xn[2 * kc + 1].x, xn[2 * kc + 1].y, xn[2 * kc + 1].z, xn[2 * kc + 1].w};
-                split3_oct(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
+                dawn_split3_oct(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
             }
         }
         TSTAMP();   // x loaded + LayerNorm
