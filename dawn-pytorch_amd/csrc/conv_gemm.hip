@@ -1825,7 +1825,12 @@ __global__ __launch_bounds__(512) void gemm1x1_rowreg_kernel(const dawn_conv_des
 // N = 192) and walks K in 128-channel blocks -- rows of the block fetched, normalised (row statistics supplied) and split once
 // into registers, then one weight chunk per (K block, column chunk) step through the same double-buffered LDS-DMA pipeline.
 // The tiled kernel re-split every row for each of its N / 64 column tiles and ran fetch | MFMA | store phases back to back.
-template <int NCH, int KS>
+// MODE 0: plain rows (1x1 projection).  MODE 1 / 2: the same pipeline as an implicit GEMM -- the strided 4x4 / stride-2 / pad-1
+// convolution of Downsample (MT:176; a row = an output pixel, K block = 64 channels of one of the 16 taps) and the transposed 4x4
+// convolution of Upsample as four output phases of 2x2 taps (MT:167; a row = an input pixel of one phase): the lane gathers
+// its pixel's channels per tap through a per-frame buffer descriptor (padding = out-of-range offset = 0), everything else
+// is unchanged.  These launches were the last convolutions on the fp32 matrix pipe.
+template <int NCH, int KS, int MODE>
 __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_desc d, const long M, const int panels_per_wg) {
 #if __HIP_DEVICE_COMPILE__
     // KS k-steps (16 channels each) per K block: 8 with one column chunk, 4 with two or three (up to 96 accumulator registers)
@@ -1838,45 +1843,82 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int nKB = (d.C0 + d.C1) / KBC;
-    const long npanels = M / BM;
+    const int Ktot = (MODE == 0 ? 1 : (MODE == 1 ? 16 : 4)) * (d.C0 + d.C1);      // GEMM depth: taps x channels
+    const int nKB = Ktot / KBC;
+    const int cpb = d.C0 / KBC;                        // K blocks per tap (conv modes: single source)
+    const long ppp = M / BM;                           // panels per phase (MODE 2: 4 phases, each over the M input pixels)
+    const long npanels = (MODE == 2 ? 4 : 1) * ppp;
     const long p0 = (long)blockIdx.x * panels_per_wg;
     const long p1 = p0 + panels_per_wg < npanels ? p0 + panels_per_wg : npanels;
     if (p0 >= p1) return;
     const int ld1 = d.in1 ? d.ld1 : d.ld0;
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, (d.C0 + d.C1) / 16 * 6 * d.N * 16, 0x00020000);
-    auto issueB = [&](int kb, int c, int buf) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, (MODE == 2 ? 4 : 1) * (Ktot / 16) * 6 * d.N * 16, 0x00020000);
+    auto issueB = [&](long panel, int kb, int c, int buf) __attribute__((always_inline)) {
+        const int phase = MODE == 2 ? (int)(panel / ppp) : 0;
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
-            const int piece = kb * (KS * 6) + j * 8 + wave;
+            const int piece = phase * (Ktot / 16 * 6) + kb * (KS * 6) + j * 8 + wave;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem_b + (size_t)buf * CHB + (j * 8 + wave) * 1024),
                                                      16, (unsigned)(lane * 16), (piece * d.N + c * BNC) * 16, 0, 0);
         }
     };
     bf16x8 xs[KS][3];
     float mu = 0.f, rs = 1.f;
+    // conv modes: the lane's pixel of the current panel (set by locate())
+    int pf = 0, py_ = 0, px_ = 0;                          // frame; MODE 1: top-left input coordinate (2 oy - 1, 2 ox - 1); MODE 2: (a, b)
+    auto locate = [&](long panel) __attribute__((always_inline)) {
+        if (MODE == 0) return;
+        const long m = (MODE == 2 ? panel % ppp : panel) * BM + wave * 32 + l31;
+        const int hw = MODE == 1 ? d.Ho * d.Wo : d.Hi * d.Wi;
+        pf = (int)(m / hw);
+        const int rem = (int)(m - (long)pf * hw);
+        if (MODE == 1) { const int oy = rem / d.Wo; py_ = 2 * oy - 1; px_ = 2 * (rem - oy * d.Wo) - 1; }
+        else { py_ = rem / d.Wi; px_ = rem - py_ * d.Wi; }
+    };
     auto load_block = [&](long panel, int kb) __attribute__((always_inline)) {
-        const long r0 = panel * BM + wave * 32;
-        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + r0 * d.ld0), 0, 32 * d.ld0 * 4, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rb =
-            __builtin_amdgcn_make_buffer_rsrc((void*)((d.in1 ? d.in1 : d.in0) + r0 * ld1), 0, 32 * ld1 * 4, 0x00020000);
-        if (kb == 0 && d.row_mean) { mu = d.row_mean[r0 + l31]; rs = d.row_rstd[r0 + l31]; }
         f32x4 raw[KS][2];
+        if (MODE == 0) {
+            const long r0 = panel * BM + wave * 32;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + r0 * d.ld0), 0, 32 * d.ld0 * 4, 0x00020000);
+            const __amdgpu_buffer_rsrc_t rb =
+                __builtin_amdgcn_make_buffer_rsrc((void*)((d.in1 ? d.in1 : d.in0) + r0 * ld1), 0, 32 * ld1 * 4, 0x00020000);
+            if (kb == 0 && d.row_mean) { mu = d.row_mean[r0 + l31]; rs = d.row_rstd[r0 + l31]; }
 #pragma unroll
-        for (int kc = 0; kc < KS; ++kc) {
-            const int cb = kb * KBC + 16 * kc;             // wave-uniform: C0 % 16 == 0
+            for (int kc = 0; kc < KS; ++kc) {
+                const int cb = kb * KBC + 16 * kc;             // wave-uniform: C0 % 16 == 0
 #pragma unroll
-            for (int h2 = 0; h2 < 2; ++h2)
-                raw[kc][h2] = __builtin_bit_cast(
-                    f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((l31 * d.ld0 + cb + 8 * half + 4 * h2) * 4), 0, 0)
-                                     : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((l31 * ld1 + cb - d.C0 + 8 * half + 4 * h2) * 4), 0, 0));
+                for (int h2 = 0; h2 < 2; ++h2)
+                    raw[kc][h2] = __builtin_bit_cast(
+                        f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((l31 * d.ld0 + cb + 8 * half + 4 * h2) * 4), 0, 0)
+                                         : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((l31 * ld1 + cb - d.C0 + 8 * half + 4 * h2) * 4), 0, 0));
+            }
+        } else {
+            // a 32-pixel tile lies in one frame (host check): frame-sized descriptor, the lane's offset = its tap pixel
+            const int fr = __builtin_amdgcn_readfirstlane(pf);
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + (long)fr * d.Hi * d.Wi * d.ld0), 0,
+                                                                                d.Hi * d.Wi * d.ld0 * 4, 0x00020000);
+            const int tap = kb / cpb, c0 = (kb - tap * cpb) * KBC;
+            int iy, ix;
+            if (MODE == 1) { iy = py_ + (tap >> 2); ix = px_ + (tap & 3); }
+            else {
+                const int phase = (int)(panel / ppp), ppy = phase >> 1, ppx = phase & 1;
+                iy = py_ + ((tap >> 1) ? (ppy ? 1 : -1) : 0);
+                ix = px_ + ((tap & 1) ? (ppx ? 1 : -1) : 0);
+            }
+            const bool inb = iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi;
+            const unsigned off = inb ? (unsigned)(((iy * d.Wi + ix) * d.ld0 + c0 + 8 * half) * 4) : 0xffffff00u;   // padding reads 0
+#pragma unroll
+            for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+                    raw[kc][h2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, inb ? off + (unsigned)((16 * kc + 4 * h2) * 4) : off, 0, 0));
         }
 #pragma unroll
         for (int kc = 0; kc < KS; ++kc) {
             float v8[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v8[e] = raw[kc][0][e]; v8[4 + e] = raw[kc][1][e]; }
-            if (d.row_mean) {
+            if (MODE == 0 && d.row_mean) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = (v8[e] - mu) * rs;      // == dawn_ln_rows
             }
@@ -1892,8 +1934,9 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
             for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
     float* stg = reinterpret_cast<float*>(smem_b + 2 * CHB) + wave * (32 * 36);
     int buf = 0;
-    issueB(0, 0, 0);
+    issueB(p0, 0, 0, 0);
     for (long panel = p0; panel < p1; ++panel) {
+        locate(panel);
         for (int kb = 0; kb < nKB; ++kb) {
             load_block(panel, kb);                          // the only VMEM loads of the loop besides the weight requests
             const bool last_kb = kb == nKB - 1;
@@ -1906,8 +1949,9 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
                 __builtin_amdgcn_s_barrier();
                 {   // request the next step's chunk into the other buffer
                     int nkb = kb, nc = c + 1;
-                    if (nc == NCH) { nc = 0; nkb = kb + 1; if (nkb == nKB) nkb = 0; }
-                    if (c + 1 < NCH || kb + 1 < nKB || panel + 1 < p1) issueB(nkb, nc, buf ^ 1);
+                    long npan = panel;
+                    if (nc == NCH) { nc = 0; nkb = kb + 1; if (nkb == nKB) { nkb = 0; npan = panel + 1; } }
+                    if (c + 1 < NCH || kb + 1 < nKB || panel + 1 < p1) issueB(npan, nkb, nc, buf ^ 1);
                 }
                 const unsigned char* Bb = smem_b + (size_t)buf * CHB;
                 // weight fragments: double-buffered over the k-steps where the register budget allows (one column chunk)
@@ -1938,7 +1982,7 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
                 }
                 buf ^= 1;
                 if (last_kb) {
-                    const long m = panel * BM + wave * 32 + l31;
+                    const long m = (MODE == 2 ? panel % ppp : panel) * BM + wave * 32 + l31;      // GEMM row of the lane (residual / tr index)
                     const int n0 = c * BNC;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
@@ -1958,11 +2002,18 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
 #pragma unroll
                             for (int e = 0; e < 4; ++e) acc[c][j][4 * g + e] = 0.f;
                         }
-                        float* orow = d.out + (panel * BM + wave * 32 + (lane >> 3)) * d.ld_out + n0 + j * 32 + 4 * (lane & 7);
 #pragma unroll
-                        for (int i = 0; i < 4; ++i)
-                            *reinterpret_cast<f32x4*>(orow + (long)(8 * i) * d.ld_out) =
+                        for (int i = 0; i < 4; ++i) {
+                            long orow_i = (MODE == 2 ? panel % ppp : panel) * BM + wave * 32 + (lane >> 3) + 8 * i;
+                            if (MODE == 2) {           // input pixel (a, b) of phase (ppy, ppx) -> output pixel (2a + ppy, 2b + ppx)
+                                const int phase = (int)(panel / ppp), hw = d.Hi * d.Wi;
+                                const int f = (int)(orow_i / hw), rem = (int)(orow_i - (long)f * hw);
+                                const int a_ = rem / d.Wi, b_ = rem - a_ * d.Wi;
+                                orow_i = ((long)f * d.Ho + 2 * a_ + (phase >> 1)) * d.Wo + 2 * b_ + (phase & 1);
+                            }
+                            *reinterpret_cast<f32x4*>(d.out + orow_i * d.ld_out + n0 + j * 32 + 4 * (lane & 7)) =
                                 *reinterpret_cast<const f32x4*>(stg + ((lane >> 3) + 8 * i) * 36 + 4 * (lane & 7));
+                        }
                     }
                 }
             }
@@ -1992,10 +2043,9 @@ static bool gemm1x1_rowacc_ok(long M, int N, int C0, int C1) {
     return K >= 256 && K % 128 == 0 && C0 % 16 == 0 && C1 % 16 == 0 && N % 64 == 0 && N <= 192 && M % 256 == 0 && M >= 12800;
 }
 
-bool try_launch_gemm1x1_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
-    if (!gemm1x1_rowacc_ok(M, d.N, d.C0, d.C1)) return false;
-    if ((long)d.ld0 * 32 * 4 >= (1L << 31) || (long)d.ld1 * 32 * 4 >= (1L << 31) || (long)(d.C0 + d.C1) / 16 * 6 * d.N * 16 >= (1L << 31)) return false;
-    const long npanels = M / 256;
+template <int MODE>
+static void launch_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
+    const long npanels = (MODE == 2 ? 4 : 1) * (M / 256);
     const int ncu = dawn_ncu();
     const int per = (int)((npanels + ncu - 1) / ncu);
     const int nwg = (int)((npanels + per - 1) / per);
@@ -2003,12 +2053,32 @@ bool try_launch_gemm1x1_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
 #define LAUNCH_RA(NCHV, KSV)                                                                                              \
     do {                                                                                                                  \
         const size_t lds = (size_t)2 * KSV * 6 * 64 * 16 + 8 * 32 * 36 * 4;                                               \
-        (void)hipFuncSetAttribute((const void*)gemm1x1_rowacc_kernel<NCHV, KSV>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((gemm1x1_rowacc_kernel<NCHV, KSV>), dim3(nwg), dim3(512), lds, s, d, M, per);                   \
+        (void)hipFuncSetAttribute((const void*)gemm1x1_rowacc_kernel<NCHV, KSV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL((gemm1x1_rowacc_kernel<NCHV, KSV, MODE>), dim3(nwg), dim3(512), lds, s, d, M, per);             \
     } while (0)
-    if (d.N == 64) LAUNCH_RA(1, 8); else if (d.N == 128) LAUNCH_RA(2, 4); else LAUNCH_RA(3, 4);
+    if (d.N == 64) { if constexpr (MODE == 0) LAUNCH_RA(1, 8); else LAUNCH_RA(1, 4); }
+    else if (d.N == 128) LAUNCH_RA(2, 4);
+    else { if constexpr (MODE == 0) LAUNCH_RA(3, 4); }
 #undef LAUNCH_RA
+}
+
+bool try_launch_gemm1x1_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
+    if (!gemm1x1_rowacc_ok(M, d.N, d.C0, d.C1)) return false;
+    if ((long)d.ld0 * 32 * 4 >= (1L << 31) || (long)d.ld1 * 32 * 4 >= (1L << 31) || (long)(d.C0 + d.C1) / 16 * 6 * d.N * 16 >= (1L << 31)) return false;
+    launch_rowacc<0>(d, M, s);
     return true;
+}
+
+// Downsample (4x4 / stride 2 / pad 1) and Upsample (transposed 4x4 / stride 2 / pad 1 as 4 phases of 2x2 taps) on the split
+// pipeline: single source of 64-channel multiples, N = 64 / 128, bias-only epilogue, 32-pixel tiles inside one frame.
+static bool conv_resample_rowacc_ok(const dawn_conv_desc& d, long M) {
+    const bool down = d.mode == 0 && d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad == 1 && d.Hi == 2 * d.Ho && d.Wi == 2 * d.Wo;
+    const bool up = d.mode == 1;
+    if (!(down || up) || d.C1 != 0 || d.in1 || d.C0 % 64 != 0 || (d.N != 64 && d.N != 128) || M % 256 != 0 || M < 12800) return false;
+    if (d.row_mean || d.ch_a || d.pro_act || d.pro_add || d.res || d.tr || d.gn_part || d.ln_eps > 0.f) return false;
+    const long hw = down ? (long)d.Ho * d.Wo : (long)d.Hi * d.Wi;
+    if (hw % 32 != 0 || (long)d.Hi * d.Wi * d.ld0 * 4 >= (1L << 31) || (d.ld0 & 3) || (d.ld_out & 3)) return false;
+    return (long)(down ? 16 : 4) * d.C0 / 16 * 6 * d.N * 16 * (up ? 4 : 1) < (1L << 31);
 }
 
 bool try_launch_gemm1x1_rowreg(const dawn_conv_desc& d, long M, hipStream_t s) {
@@ -2218,6 +2288,11 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
               !d.pro_add && !d.row_mean && !d.row_rstd && !d.gn_part && (d.C1 != 0) == (d.in1 != nullptr) &&
               try_launch_gemm1x1_rowreg(d, M, s)))
             return dawn_set_error_msg(-14, "dawn_conv_gemm: ln_eps needs a split 1x1 projection with dawn_gemm1x1_ln_inline_ok");
+        DAWN_LAUNCH_CHECK();
+        return 0;
+    }
+    if ((policy_of(d) & 0x1000) && !(policy_of(d) & 0x20000) && d.w_bf3 && conv_resample_rowacc_ok(d, M)) {
+        if (d.mode == 0) launch_rowacc<1>(d, M, s); else launch_rowacc<2>(d, M, s);
         DAWN_LAUNCH_CHECK();
         return 0;
     }

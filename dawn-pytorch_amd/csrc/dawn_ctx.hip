@@ -58,6 +58,7 @@ struct Level {
     RB rb1, rb2;
     AT sla, tattn;
     const float *rs_w = nullptr, *rs_b = nullptr;   // down (4x4/s2) or up (transposed 4x4) conv
+    const void* rs_ws = nullptr;                    // its exact 3-way bf16 split (optional)
 };
 
 // Host-side sub-allocator over the caller's workspace.  First fit with coalescing; `dry` = measuring pass (no base
@@ -575,7 +576,7 @@ struct Eval {
             if (lv.rs_w) {
                 T2 dn = t2((long)F * (H / 2) * (W / 2), x.C);
                 ConvArgs a;
-                a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.w = lv.rs_w; a.bias = lv.rs_b; a.N = x.C; a.Fr = F; a.Hi = H; a.Wi = W;
+                a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.w = lv.rs_w; a.w_bf3 = lv.rs_ws; a.bias = lv.rs_b; a.N = x.C; a.Fr = F; a.Hi = H; a.Wi = W;
                 a.Ho = H / 2; a.Wo = W / 2; a.KH = 4; a.KW = 4; a.stride = 2; a.pad = 1; a.out = dn.p; a.ld_out = x.C;
                 conv(a);
                 x = dn;                         // (the skip keeps the level's output alive)
@@ -605,7 +606,7 @@ struct Eval {
             if (lv.rs_w) {
                 T2 up = t2((long)F * (2 * H) * (2 * W), x.C);
                 ConvArgs a;
-                a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.w = lv.rs_w; a.bias = lv.rs_b; a.N = x.C; a.Fr = F; a.Hi = H; a.Wi = W;
+                a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.w = lv.rs_w; a.w_bf3 = lv.rs_ws; a.bias = lv.rs_b; a.N = x.C; a.Fr = F; a.Hi = H; a.Wi = W;
                 a.Ho = 2 * H; a.Wo = 2 * W; a.KH = 2; a.KW = 2; a.mode = 1; a.out = up.p; a.ld_out = x.C;
                 conv(a);
                 rel(x); x = up;
@@ -639,6 +640,7 @@ int build_levels(dawn_ctx* c) {
         if (l + 1 < g.n_levels) {
             lv.rs_w = (const float*)getw(c, p + "down.w", true, &ok);
             lv.rs_b = (const float*)getw(c, p + "down.b", true, &ok);
+            lv.rs_ws = getw(c, p + "down.ws", false, &ok);
         }
     }
     const int dm = c->dims[g.n_levels];
@@ -658,6 +660,7 @@ int build_levels(dawn_ctx* c) {
         if (l + 1 < g.n_levels) {
             lv.rs_w = (const float*)getw(c, p + "up.w", true, &ok);
             lv.rs_b = (const float*)getw(c, p + "up.b", true, &ok);
+            lv.rs_ws = getw(c, p + "up.ws", false, &ok);
         }
     }
     int dummy = 0;

@@ -67,6 +67,8 @@ def named_weights(P: PackedUNet) -> Dict[str, Tensor]:
         attn(f"downs.{l}.sla.", lvl["sla"]); attn(f"downs.{l}.tattn.", lvl["tattn"])
         if lvl["down"] is not None:
             put(f"downs.{l}.down.w", lvl["down"][0]); put(f"downs.{l}.down.b", lvl["down"][1])
+            if lvl["down"][2] is not None:
+                put(f"downs.{l}.down.ws", lvl["down"][2])
     rb("mid.rb1.", P.mid["rb1"]); rb("mid.rb2.", P.mid["rb2"])
     attn("mid.sattn.", P.mid["sattn"]); attn("mid.tattn.", P.mid["tattn"])
     for l, lvl in enumerate(P.ups):
@@ -74,6 +76,8 @@ def named_weights(P: PackedUNet) -> Dict[str, Tensor]:
         attn(f"ups.{l}.sla.", lvl["sla"]); attn(f"ups.{l}.tattn.", lvl["tattn"])
         if lvl["up"] is not None:
             put(f"ups.{l}.up.w", lvl["up"][0]); put(f"ups.{l}.up.b", lvl["up"][1])
+            if lvl["up"][2] is not None:
+                put(f"ups.{l}.up.ws", lvl["up"][2])
     rb("head_g.", P.head_g); rb("head_o.", P.head_o)
     return out
 

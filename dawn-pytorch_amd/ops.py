@@ -154,7 +154,11 @@ class HipOps:
     def _runs_split_kernel(self, w_bf3, KH, KW, stride, mode, rows, N, C0, C1, tr, gn_part) -> bool:
         """Profiling label only: does this launch take a split-operand (bf16 pipe) kernel?  3x3/s1 ResBlock convs always do;
         for the 1x1 GEMMs the library's own dispatch predicate is asked (dawn_gemm1x1_split_ok)."""
-        if w_bf3 is None or mode != 0 or stride != 1:
+        if w_bf3 is None:
+            return False
+        if mode == 1 or (KH == 4 and KW == 4 and stride == 2):      # Downsample / Upsample on the row-accumulator kernel
+            return C1 == 0 and C0 % 64 == 0 and N in (64, 128) and gn_part is None and tr is None
+        if mode != 0 or stride != 1:
             return False
         if KH == 3 and KW == 3:
             return True

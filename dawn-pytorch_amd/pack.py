@@ -284,7 +284,8 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
         lvl = {"rb1": resblock(q + "0."), "rb2": resblock(q + "1."), "sla": attn(q + "2.", True),
                "tattn": attn(q + "3."), "down": None}
         if has(q + "4.weight"):
-            lvl["down"] = (dev(pack_kn(conv_w_kn(g(q + "4.weight")))), dev(g(q + "4.bias")))
+            wkn = conv_w_kn(g(q + "4.weight"))                 # (16 Ci, Co); split image for the bf16-pipe resampling kernel
+            lvl["down"] = (dev(pack_kn(wkn)), dev(g(q + "4.bias")), pack_bf3(wkn).to(device) if wkn.shape[0] % 1024 == 0 else None)
         P.downs.append(lvl)
     P.mid = {"rb1": resblock("mid_block1."), "sattn": attn("mid_spatial_attn."),
              "tattn": attn("mid_temporal_attn."), "rb2": resblock("mid_block2.")}
@@ -294,7 +295,8 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
                "tattn": attn(q + "3."), "up": None}
         if has(q + "4.weight"):
             ph = deconv_w_kn_phases(g(q + "4.weight"))
-            lvl["up"] = (dev(torch.stack([pack_kn(ph[i]) for i in range(4)], 0)), dev(g(q + "4.bias")))
+            lvl["up"] = (dev(torch.stack([pack_kn(ph[i]) for i in range(4)], 0)), dev(g(q + "4.bias")),
+                         torch.stack([pack_bf3(ph[i]) for i in range(4)], 0).to(device) if ph[0].shape[0] % 256 == 0 else None)
         P.ups.append(lvl)
     P.head_g = resblock("final_conv.0.")
     P.head_o = resblock("occlusion_map.0.")

@@ -237,9 +237,9 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
         x = _temporal(ops, lvl["tattn"], x, F, H, W, cs)
         skips.append((x, H, W))
         if lvl["down"] is not None:
-            wd, bd = lvl["down"]
+            wd, bd, wds = lvl["down"]
             x = ops.conv_gemm(x, wd, x.shape[1], F=F, Hi=H, Wi=W, Ho=H // 2, Wo=W // 2, KH=4, KW=4, stride=2, pad=1,
-                              bias=bd)
+                              bias=bd, w_bf3=wds)
             H, W = H // 2, W // 2
     x = _resblock(ops, P.mid["rb1"], x, None, F, H, W, film_all, cs)
     x = _mid_spatial(ops, P.mid["sattn"], x, F, H, W)
@@ -253,8 +253,8 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
         x = _spatial_linear(ops, lvl["sla"], x, F, H, W)
         x = _temporal(ops, lvl["tattn"], x, F, H, W, cs)
         if lvl["up"] is not None:
-            wu, bu = lvl["up"]
-            x = ops.conv_gemm(x, wu, x.shape[1], F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=bu)
+            wu, bu, wus = lvl["up"]
+            x = ops.conv_gemm(x, wu, x.shape[1], F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=bu, w_bf3=wus)
             H, W = 2 * H, 2 * W
     hg = _resblock(ops, P.head_g, x, r, F, H, W, film_all, cs)               # torch.cat((x, r)) MT:955
     ho = _resblock(ops, P.head_o, x, r, F, H, W, film_all, cs)

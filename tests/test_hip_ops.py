@@ -300,6 +300,35 @@ def test_conv_gemm_transposed(hip, ref):
     check("conv_gemm/transposed_up", got, want)
 
 
+@pytest.mark.parametrize("F,H,W,Cc", [(50, 32, 32, 64), (200, 16, 16, 128), (13, 64, 64, 64)])
+def test_conv_resample_on_split_pipeline(hip, ref, F, H, W, Cc):
+    """Downsample (4x4 / stride 2 / pad 1) and Upsample (transposed 4x4 / stride 2 / pad 1) with the exact bf16 split of their
+    weights supplied run as implicit GEMMs on the row-accumulator split kernel == torch's own convolutions (and == the fp32
+    implicit-GEMM kernel to its accuracy class)."""
+    from dawn_pytorch_amd.pack import pack_kn, pack_bf3, conv_w_kn, deconv_w_kn_phases
+    x, b = rnd(F * H * W, Cc, seed=2), rnd(Cc, seed=3)
+    img = x.reshape(F, H, W, Cc).permute(0, 3, 1, 2)
+    # down
+    w5 = rnd(Cc, Cc, 1, 4, 4, seed=1, scale=(Cc * 16) ** -0.5)
+    wkn = conv_w_kn(w5)
+    want = torch.nn.functional.conv2d(img, w5[:, :, 0], b, stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    kw = dict(F=F, Hi=H, Wi=W, Ho=H // 2, Wo=W // 2, KH=4, KW=4, stride=2, pad=1, bias=b.cuda())
+    got = hip.conv_gemm(x.cuda(), pack_kn(wkn).cuda(), Cc, w_bf3=pack_bf3(wkn).cuda(), **kw)
+    g32 = hip.conv_gemm(x.cuda(), pack_kn(wkn).cuda(), Cc, **kw)
+    check(f"conv_resample_split/down_F{F}_{H}x{W}_C{Cc}", got, want)
+    assert float((got.cpu() - want).abs().max()) <= 2.0 * float((g32.cpu() - want).abs().max()) + 1e-5
+    # up
+    w5t = rnd(Cc, Cc, 1, 4, 4, seed=4, scale=(Cc * 4) ** -0.5)
+    ph = deconv_w_kn_phases(w5t)
+    wantu = torch.nn.functional.conv_transpose2d(img, w5t[:, :, 0], b, stride=2, padding=1).permute(0, 2, 3, 1).reshape(-1, Cc)
+    kwu = dict(F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=b.cuda())
+    wp = torch.stack([pack_kn(ph[i]) for i in range(4)], 0).cuda()
+    gotu = hip.conv_gemm(x.cuda(), wp, Cc, w_bf3=torch.stack([pack_bf3(ph[i]) for i in range(4)], 0).cuda(), **kwu)
+    g32u = hip.conv_gemm(x.cuda(), wp, Cc, **kwu)
+    check(f"conv_resample_split/up_F{F}_{H}x{W}_C{Cc}", gotu, wantu)
+    assert float((gotu.cpu() - wantu).abs().max()) <= 2.0 * float((g32u.cpu() - wantu).abs().max()) + 1e-5
+
+
 def test_conv_gemm_strided_views(hip, ref):
     """channel slices as input (xattn to_out reads q[:, 64b:64b+64]) and output (y3[:, b*Co:(b+1)*Co])."""
     rows, Co = 200, 128
