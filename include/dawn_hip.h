@@ -283,7 +283,8 @@ typedef struct dawn_named_ptr { const char* name; const void* ptr; } dawn_named_
  * "t_w2" "t_b2" "film_w" "film_b" "wg" "bg" "wo" "bo"; attention layers "<init_tattn|downs.L.sla|downs.L.tattn|mid.sattn|
  * mid.tattn|ups.L.sla|ups.L.tattn>.<wqkv|wout|bout|wqkv_s|wout_s|wout_sp>"; ResBlocks "<downs.L.rb1|...|mid.rb1|mid.rb2|
  * head_g|head_o>.<w1|b1|g1|be1|w2|b2|g2|be2|wr|br|w1s|w2s|wrs|wq|wqs|q_scale|g3|wo.B|wos.B|mlp_w.B|mlp_b.B|kv_w.B|k_scale.B|
- * null_kv.B>" (B = 0..2: pose, aud, eye); "downs.L.down.<w|b>", "ups.L.up.<w|b>" (dawn_pytorch_amd/ctx.py builds the table). */
+ * null_kv.B>" (B = 0..2: pose, aud, eye); "downs.L.down.<w|b|ws>", "ups.L.up.<w|b|ws>" (ws optional: pack_bf3 image(s) of the
+ * resampling convolution for the split pipeline; dawn_pytorch_amd/ctx.py builds the table). */
 int dawn_ctx_create(const dawn_unet_cfg* cfg, const dawn_named_ptr* weights, int n_weights, dawn_ctx** out);
 void dawn_ctx_destroy(dawn_ctx* ctx);
 enum { DAWN_OPT_CONV_POLICY = 1, DAWN_OPT_TEMPORAL_FLAGS = 2, DAWN_OPT_OVERLAP = 3, DAWN_OPT_PROFILE = 4 };

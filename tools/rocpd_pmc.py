@@ -10,5 +10,8 @@ agg = collections.defaultdict(lambda: [0, 0.0])
 for r in rows:
     k = (str(r[ci[name_col]]).replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0][:60], r[ci["counter_name"]])
     agg[k][0] += 1; agg[k][1] += float(r[ci["value"]])
+flt = sys.argv[2] if len(sys.argv) > 2 else None       # optional kernel-name substring
 for (kn, cn), (n, v) in sorted(agg.items()):
+    if flt and flt not in kn:
+        continue
     print(f"{kn:62s} {cn:28s} n={n:4d} avg={v/n:16.1f}")

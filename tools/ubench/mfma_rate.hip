@@ -54,7 +54,12 @@ int main() {
     run<4, true>("bf16 32x32x16", 1, 20000);
     run<4, true>("bf16 32x32x16", 2, 20000);
     run<1, true>("bf16 32x32x16 dependent", 1, 20000);
+    run<1, true>("bf16 32x32x16 dependent", 2, 20000);
     run<2, true>("bf16 32x32x16", 1, 20000);
+    run<2, true>("bf16 32x32x16", 2, 20000);
+    run<1, false>("f32 32x32x2 dependent", 1, 10000);
+    run<1, false>("f32 32x32x2 dependent", 2, 10000);
+    run<2, false>("f32 32x32x2", 1, 10000);
     run<4, false>("f32 32x32x2", 1, 10000);
     run<4, false>("f32 32x32x2", 2, 10000);
     return 0;
