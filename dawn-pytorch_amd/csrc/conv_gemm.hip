@@ -1373,9 +1373,11 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
         constexpr int NP = NTHR / 32;
         if (tid < 16 * NP) {
             const int c = tid / NP, p = tid - c * NP;
+            // (start offset rotated per thread: consecutive threads read rows 128 B apart -- unrotated, all 64 lanes of a wave
+            //  hit one LDS bank in every one of the 32 steps)
             double a = 0.0;
 #pragma unroll 8
-            for (int e = 0; e < 32; ++e) a += (double)pf[c * NTHR + p * 32 + e];
+            for (int e = 0; e < 32; ++e) a += (double)pf[c * NTHR + p * 32 + ((e + tid) & 31)];
             pd[c * NP + p] = a;
         }
         __syncthreads();
