@@ -46,6 +46,11 @@ def main():
           f"evaluations + the once-per-clip work.  Total {tot_b / 1e9:.1f} GB = **{tot_b / nev / 1e9:.1f} GB per evaluation** "
           f"({tot_b / nev / 200 / 1e6:.0f} MB per frame-evaluation; SURVEY 8d fused lower bound: 118 MB), "
           f"kernel time {tot_t * 1e3:.1f} ms -> {tot_b / tot_t / 1e12:.2f} TB/s average while kernels run.\n")
+    once = sum(r[2] + r[3] for r in rows if r[0].startswith("at::native::"))
+    print(f"Of that, {once / 1e9:.1f} GB are the torch kernels of the once-per-clip work (`at::native::*`: frame-invariance check of "
+          f"fea, reference-layout conversions, cats), amortised here over {nev:.0f} evaluations instead of 50: the per-evaluation "
+          f"kernels alone move **{(tot_b - once) / nev / 1e9:.1f} GB per evaluation = {(tot_b - once) / nev / 200 / 1e6:.0f} MB per "
+          f"frame-evaluation**.\n")
     print("| kernel | launches | read GB | written GB | time ms | achieved TB/s | share of bytes |")
     print("|---|---|---|---|---|---|---|")
     for k, n, rd, wr, t in rows:
