@@ -559,6 +559,23 @@ def test_sla_layer_c64(hip, ref, F, HW):
     check(f"sla_layer_c64_split/F{F}_HW{HW}", got, want, 3e-5)
 
 
+def test_sla_softmax_reference_is_shift_safe(hip, ref):
+    """The single-sweep linear-attention kernels keep a lazily raised softmax reference (raised only when a tile exceeds it by
+    2^8) and merge slices by their references: logits with a large dynamic range and a strong trend along the pixel axis (every
+    tile raises the maximum; late pixels dwarf early ones) must still match the two-pass reference."""
+    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+    F, HW = 2, 2048
+    ramp = torch.linspace(-1.0, 1.0, HW).repeat(F)[:, None]
+    x = rnd(F * HW, 64, seed=1) * 2.0 + ramp * rnd(1, 64, seed=7) * 6.0
+    wqkv, wout, bias = packw(64, 768, seed=2) * 6.0, packw(256, 64, seed=3), rnd(64, seed=4)
+    want = ref.sla_layer_c64(x, F, HW, wqkv, wout, bias)
+    got = hip.sla_layer_c64(*gpu(x), F, HW, *gpu(wqkv, wout, bias), wqkv_bf3=pack_bf3(unpack_kn(wqkv)).cuda())
+    check("sla_layer_c64_split/wide_range", got, want, 1e-4)
+    qkv = rnd(F * HW, 768, seed=5) * 4.0
+    qkv[:, 256:512] += ramp * 25.0                                   # keys grow by ~50 over the frame
+    check("sla/wide_range", hip.sla(qkv.cuda(), F, HW), ref.sla(qkv, F, HW), 1e-4)
+
+
 @pytest.mark.parametrize("F,N", [(4, 16), (3, 64), (2, 100)])
 def test_frame_attn(hip, ref, F, N):
     qkv = rnd(F * N, 768, seed=1)
