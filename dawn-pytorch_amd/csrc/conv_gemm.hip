@@ -2312,7 +2312,11 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
             // N = 256: 100 tiles), 256 x 64 tiles put one 4-wave workgroup on twice as many CUs and the launch takes
             // 0.67x the time (measured 520 -> 349 us at K = 9216, 142 -> 97 us at K = 2304; with 129..256 tiles the same
             // CUs stay busy either way and nothing is gained)
-            const bool narrow = d.N <= 64 || (d.N % 64 == 0 && M % 256 == 0 && (M / 256) * ((d.N + 127) / 128) <= 128);
+            // ... and at N = 128 with many tiles (level 1: 1600 narrow tiles): two 4-wave workgroups per CU (76 KB of LDS each)
+            // overlap each other's prologue / epilogue, the 8-wave 128-column workgroup (108 KB) holds its CU alone:
+            // 356 -> 314 us at M = 204,800, K = 1152 (no difference at N = 256 / 512 with 800 / 400 narrow tiles)
+            const bool narrow = d.N <= 64 || (d.N % 64 == 0 && M % 256 == 0 && ((M / 256) * ((d.N + 127) / 128) <= 128 ||
+                                                                              (d.N == 128 && (M / 256) * 2 >= 1536)));
             ok = narrow ? try_launch_bf16_v2<1>(d, M, s, nine) : try_launch_bf16_v2<2>(d, M, s, nine);
             if (!ok && narrow && d.N > 64) ok = try_launch_bf16_v2<2>(d, M, s, nine);
         }
