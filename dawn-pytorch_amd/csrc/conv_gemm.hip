@@ -1849,19 +1849,24 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
     const int nKB = Ktot / KBC;
     const int cpb = d.C0 / KBC;                        // K blocks per tap (conv modes: single source)
     const long ppp = M / BM;                           // panels per phase (MODE 2: 4 phases, each over the M input pixels)
-    const long npanels = (MODE == 2 ? 4 : 1) * ppp;
+    // a unit = (row panel [x phase], group of NCH column chunks): N = ngrp * NCH * 64 (ngrp > 1 only for the resampling convs at
+    // N = 256: the rows of a panel are then fetched and split once per group)
+    const int ngrp = d.N / (NCH * BNC);
+    const long npanels = (MODE == 2 ? 4 : 1) * ppp * ngrp;
     const long p0 = (long)blockIdx.x * panels_per_wg;
     const long p1 = p0 + panels_per_wg < npanels ? p0 + panels_per_wg : npanels;
     if (p0 >= p1) return;
     const int ld1 = d.in1 ? d.ld1 : d.ld0;
     const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_bf3, 0, (MODE == 2 ? 4 : 1) * (Ktot / 16) * 6 * d.N * 16, 0x00020000);
-    auto issueB = [&](long panel, int kb, int c, int buf) __attribute__((always_inline)) {
+    auto issueB = [&](long unit, int kb, int c, int buf) __attribute__((always_inline)) {
+        const long panel = unit / ngrp;
+        const int cg = (int)(unit - panel * ngrp) * NCH;       // first column chunk of the unit's group
         const int phase = MODE == 2 ? (int)(panel / ppp) : 0;
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
             const int piece = phase * (Ktot / 16 * 6) + kb * (KS * 6) + j * 8 + wave;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (__attribute__((address_space(3))) void*)(smem_b + (size_t)buf * CHB + (j * 8 + wave) * 1024),
-                                                     16, (unsigned)(lane * 16), (piece * d.N + c * BNC) * 16, 0, 0);
+                                                     16, (unsigned)(lane * 16), (piece * d.N + (cg + c) * BNC) * 16, 0, 0);
         }
     };
     bf16x8 xs[KS][3];
@@ -1937,7 +1942,9 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
     float* stg = reinterpret_cast<float*>(smem_b + 2 * CHB) + wave * (32 * 36);
     int buf = 0;
     issueB(p0, 0, 0, 0);
-    for (long panel = p0; panel < p1; ++panel) {
+    for (long unit = p0; unit < p1; ++unit) {
+        const long panel = unit / ngrp;
+        const int cg = (int)(unit - panel * ngrp) * NCH;
         locate(panel);
         for (int kb = 0; kb < nKB; ++kb) {
             load_block(panel, kb);                          // the only VMEM loads of the loop besides the weight requests
@@ -1951,9 +1958,9 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
                 __builtin_amdgcn_s_barrier();
                 {   // request the next step's chunk into the other buffer
                     int nkb = kb, nc = c + 1;
-                    long npan = panel;
-                    if (nc == NCH) { nc = 0; nkb = kb + 1; if (nkb == nKB) { nkb = 0; npan = panel + 1; } }
-                    if (c + 1 < NCH || kb + 1 < nKB || panel + 1 < p1) issueB(npan, nkb, nc, buf ^ 1);
+                    long npan = unit;
+                    if (nc == NCH) { nc = 0; nkb = kb + 1; if (nkb == nKB) { nkb = 0; npan = unit + 1; } }
+                    if (c + 1 < NCH || kb + 1 < nKB || unit + 1 < p1) issueB(npan, nkb, nc, buf ^ 1);
                 }
                 const unsigned char* Bb = smem_b + (size_t)buf * CHB;
                 // weight fragments: double-buffered over the k-steps where the register budget allows (one column chunk)
@@ -1985,7 +1992,7 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
                 buf ^= 1;
                 if (last_kb) {
                     const long m = (MODE == 2 ? panel % ppp : panel) * BM + wave * 32 + l31;      // GEMM row of the lane (residual / tr index)
-                    const int n0 = c * BNC;
+                    const int n0 = (cg + c) * BNC;
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
 #pragma unroll
@@ -2047,7 +2054,8 @@ static bool gemm1x1_rowacc_ok(long M, int N, int C0, int C1) {
 
 template <int MODE>
 static void launch_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
-    const long npanels = (MODE == 2 ? 4 : 1) * (M / 256);
+    const int nch = d.N == 64 ? 1 : ((d.N == 128 || d.N == 256) ? 2 : 3);
+    const long npanels = (MODE == 2 ? 4 : 1) * (M / 256) * (d.N / (nch * 64));
     const int ncu = dawn_ncu();
     const int per = (int)((npanels + ncu - 1) / ncu);
     const int nwg = (int)((npanels + per - 1) / per);
@@ -2059,7 +2067,7 @@ static void launch_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
         hipLaunchKernelGGL((gemm1x1_rowacc_kernel<NCHV, KSV, MODE>), dim3(nwg), dim3(512), lds, s, d, M, per);             \
     } while (0)
     if (d.N == 64) { if constexpr (MODE == 0) LAUNCH_RA(1, 8); else LAUNCH_RA(1, 4); }
-    else if (d.N == 128) LAUNCH_RA(2, 4);
+    else if (d.N == 128 || d.N == 256) LAUNCH_RA(2, 4);
     else { if constexpr (MODE == 0) LAUNCH_RA(3, 4); }
 #undef LAUNCH_RA
 }
@@ -2072,11 +2080,12 @@ bool try_launch_gemm1x1_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
 }
 
 // Downsample (4x4 / stride 2 / pad 1) and Upsample (transposed 4x4 / stride 2 / pad 1 as 4 phases of 2x2 taps) on the split
-// pipeline: single source of 64-channel multiples, N = 64 / 128, bias-only epilogue, 32-pixel tiles inside one frame.
+// pipeline: single source of 64-channel multiples, N = 64 / 128 / 256 (256: two column groups per row panel), bias-only epilogue,
+// 32-pixel tiles inside one frame.
 static bool conv_resample_rowacc_ok(const dawn_conv_desc& d, long M) {
     const bool down = d.mode == 0 && d.KH == 4 && d.KW == 4 && d.stride == 2 && d.pad == 1 && d.Hi == 2 * d.Ho && d.Wi == 2 * d.Wo;
     const bool up = d.mode == 1;
-    if (!(down || up) || d.C1 != 0 || d.in1 || d.C0 % 64 != 0 || (d.N != 64 && d.N != 128) || M % 256 != 0 || M < 12800) return false;
+    if (!(down || up) || d.C1 != 0 || d.in1 || d.C0 % 64 != 0 || (d.N != 64 && d.N != 128 && d.N != 256) || M % 256 != 0 || M < 12800) return false;
     if (d.row_mean || d.ch_a || d.pro_act || d.pro_add || d.res || d.tr || d.gn_part || d.ln_eps > 0.f) return false;
     const long hw = down ? (long)d.Ho * d.Wo : (long)d.Hi * d.Wi;
     if (hw % 32 != 0 || (long)d.Hi * d.Wi * d.ld0 * 4 >= (1L << 31) || (d.ld0 & 3) || (d.ld_out & 3)) return false;

@@ -157,7 +157,7 @@ class HipOps:
         if w_bf3 is None:
             return False
         if mode == 1 or (KH == 4 and KW == 4 and stride == 2):      # Downsample / Upsample on the row-accumulator kernel
-            return C1 == 0 and C0 % 64 == 0 and N in (64, 128) and gn_part is None and tr is None
+            return C1 == 0 and C0 % 64 == 0 and N in (64, 128, 256) and gn_part is None and tr is None
         if mode != 0 or stride != 1:
             return False
         if KH == 3 and KW == 3:

@@ -300,7 +300,7 @@ def test_conv_gemm_transposed(hip, ref):
     check("conv_gemm/transposed_up", got, want)
 
 
-@pytest.mark.parametrize("F,H,W,Cc", [(50, 32, 32, 64), (200, 16, 16, 128), (13, 64, 64, 64)])
+@pytest.mark.parametrize("F,H,W,Cc", [(50, 32, 32, 64), (200, 16, 16, 128), (13, 64, 64, 64), (200, 16, 16, 256)])
 def test_conv_resample_on_split_pipeline(hip, ref, F, H, W, Cc):
     """Downsample (4x4 / stride 2 / pad 1) and Upsample (transposed 4x4 / stride 2 / pad 1) with the exact bf16 split of their
     weights supplied run as implicit GEMMs on the row-accumulator split kernel == torch's own convolutions (and == the fp32
@@ -316,7 +316,8 @@ def test_conv_resample_on_split_pipeline(hip, ref, F, H, W, Cc):
     got = hip.conv_gemm(x.cuda(), pack_kn(wkn).cuda(), Cc, w_bf3=pack_bf3(wkn).cuda(), **kw)
     g32 = hip.conv_gemm(x.cuda(), pack_kn(wkn).cuda(), Cc, **kw)
     check(f"conv_resample_split/down_F{F}_{H}x{W}_C{Cc}", got, want)
-    assert float((got.cpu() - want).abs().max()) <= 2.0 * float((g32.cpu() - want).abs().max()) + 1e-5
+    # (one accumulator chain over K = 16 Cin products: the rounding error grows with sqrt(K); allowance relative to the output scale)
+    assert float((got.cpu() - want).abs().max()) <= 2.0 * float((g32.cpu() - want).abs().max()) + 3e-6 * float(want.abs().max())
     # up
     w5t = rnd(Cc, Cc, 1, 4, 4, seed=4, scale=(Cc * 4) ** -0.5)
     ph = deconv_w_kn_phases(w5t)
@@ -326,7 +327,7 @@ def test_conv_resample_on_split_pipeline(hip, ref, F, H, W, Cc):
     gotu = hip.conv_gemm(x.cuda(), wp, Cc, w_bf3=torch.stack([pack_bf3(ph[i]) for i in range(4)], 0).cuda(), **kwu)
     g32u = hip.conv_gemm(x.cuda(), wp, Cc, **kwu)
     check(f"conv_resample_split/up_F{F}_{H}x{W}_C{Cc}", gotu, wantu)
-    assert float((gotu.cpu() - wantu).abs().max()) <= 2.0 * float((g32u.cpu() - wantu).abs().max()) + 1e-5
+    assert float((gotu.cpu() - wantu).abs().max()) <= 2.0 * float((g32u.cpu() - wantu).abs().max()) + 3e-6 * float(wantu.abs().max())
 
 
 def test_conv_gemm_strided_views(hip, ref):
