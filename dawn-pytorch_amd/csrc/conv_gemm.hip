@@ -1925,12 +1925,49 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
             float v8[8];
 #pragma unroll
             for (int e = 0; e < 4; ++e) { v8[e] = raw[kc][0][e]; v8[4 + e] = raw[kc][1][e]; }
-            if (MODE == 0 && d.row_mean) {
+            if (MODE == 0 && (d.row_mean || d.ln_eps > 0.f)) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v8[e] = (v8[e] - mu) * rs;      // == dawn_ln_rows
             }
             dawn_split3_oct(v8, xs[kc][0], xs[kc][1], xs[kc][2]);
         }
+    };
+    // LayerNorm inside the GEMM (dawn_conv_desc.ln_eps, MODE 0): one statistics sweep over the panel's rows before its K loop
+    // (the rows come back from L2 for the GEMM sweep: 32 KB per wave) -- shifted one-pass sums (shift = the row's first channel,
+    // so that E[d^2] - E[d]^2 does not cancel), both halves of a row combined by one xor-32 exchange
+    auto ln_stats = [&](long panel) __attribute__((always_inline)) {
+        const long r0 = panel * BM + wave * 32;
+        const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + r0 * d.ld0), 0, 32 * d.ld0 * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rb =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((d.in1 ? d.in1 : d.in0) + r0 * ld1), 0, 32 * ld1 * 4, 0x00020000);
+        const float shift = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ra, (unsigned)(l31 * d.ld0 * 4), 0, 0));
+        float s1 = 0.f, s2 = 0.f;
+        for (int kb = 0; kb < nKB; ++kb) {
+            f32x4 raw[KS][2];
+#pragma unroll
+            for (int kc = 0; kc < KS; ++kc) {
+                const int cb = kb * KBC + 16 * kc;
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2)
+                    raw[kc][h2] = __builtin_bit_cast(
+                        f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((l31 * d.ld0 + cb + 8 * half + 4 * h2) * 4), 0, 0)
+                                         : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((l31 * ld1 + cb - d.C0 + 8 * half + 4 * h2) * 4), 0, 0));
+            }
+#pragma unroll
+            for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const f32x4 dl = raw[kc][h2] - shift;
+                    s1 += (dl.x + dl.y) + (dl.z + dl.w);
+                    s2 += (dl.x * dl.x + dl.y * dl.y) + (dl.z * dl.z + dl.w * dl.w);
+                }
+        }
+        s1 += __shfl_xor(s1, 32, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float invk = 1.0f / (float)(d.C0 + d.C1);
+        const float md = s1 * invk;
+        mu = shift + md;
+        rs = 1.0f / sqrtf(fmaxf(s2 * invk - md * md, 0.f) + d.ln_eps);
     };
     f32x16 acc[NCH][2];
 #pragma unroll
@@ -1946,6 +1983,7 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
         const long panel = unit / ngrp;
         const int cg = (int)(unit - panel * ngrp) * NCH;
         locate(panel);
+        if (MODE == 0 && d.ln_eps > 0.f) ln_stats(panel);
         for (int kb = 0; kb < nKB; ++kb) {
             load_block(panel, kb);                          // the only VMEM loads of the loop besides the weight requests
             const bool last_kb = kb == nKB - 1;
@@ -2269,7 +2307,9 @@ extern "C" int dawn_conv_set_debug(void* p) {
 /* 1 when a prologue-free 1x1 projection (M rows, N columns, C0 + C1 input channels, w_bf3 supplied, shipped policy) runs on
  * the split-operand GEMM, whose loader can apply LayerNorm row statistics; the host then skips materialising the
  * normalised rows (see unet_forward._ln_gemm / dawn_ctx.hip). */
-extern "C" int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1) { return gemm1x1_rowreg_ok(M, N, C0, C1); }
+extern "C" int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1) {
+    return gemm1x1_rowreg_ok(M, N, C0, C1) || gemm1x1_rowacc_ok(M, N, C0, C1);
+}
 extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1) {
     return gemm1x1_split_plan(M, N, C0, C1) != 0 || gemm1x1_rowreg_ok(M, N, C0, C1) || gemm1x1_rowacc_ok(M, N, C0, C1);
 }
@@ -2297,7 +2337,7 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     if (d.ln_eps > 0.f) {                     // LayerNorm inside the GEMM: only the row-stationary kernel holds whole rows
         if (!(d.w_bf3 && d.mode == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ch_a && !d.pro_act &&
               !d.pro_add && !d.row_mean && !d.row_rstd && !d.gn_part && (d.C1 != 0) == (d.in1 != nullptr) &&
-              try_launch_gemm1x1_rowreg(d, M, s)))
+              (try_launch_gemm1x1_rowreg(d, M, s) || try_launch_gemm1x1_rowacc(d, M, s))))
             return dawn_set_error_msg(-14, "dawn_conv_gemm: ln_eps needs a split 1x1 projection with dawn_gemm1x1_ln_inline_ok");
         DAWN_LAUNCH_CHECK();
         return 0;

@@ -59,8 +59,9 @@ typedef struct dawn_conv_desc {
                                                       writes (= its thread-block count; <= dawn_conv_gemm_nblocks) */
     int policy;                                    /* kernel-selection policy bits (see below); 0 = shipped default */
     float ln_eps;                                  /* > 0: LayerNorm (no gain) over the C0+C1 channels of every input row, computed by the
-                                                      GEMM itself from the rows it holds -- no statistics pass (instead of row_mean /
-                                                      row_rstd; only shapes with dawn_gemm1x1_ln_inline_ok, error otherwise) */
+                                                      GEMM itself -- no statistics pass (instead of row_mean / row_rstd).  <= 128 channels: from the
+                                                      rows it holds in registers; deeper narrow projections: one shifted one-pass statistics sweep
+                                                      per row panel before its K loop.  Only shapes with dawn_gemm1x1_ln_inline_ok, error otherwise */
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;

@@ -174,7 +174,7 @@ class RefOps:
 
     @staticmethod
     def ln_inline_ok(rows, N, C0, C1=0):
-        return (C0 + C1) in (64, 128)    # exercise both LayerNorm + projection forms on CPU
+        return (C0 + C1) in (64, 128) or ((C0 + C1) % 128 == 0 and N <= 192)    # exercise both LayerNorm + projection forms on CPU
 
     @staticmethod
     def split_gemm_ok(rows, N, C0, C1=0):

@@ -201,10 +201,11 @@ def test_gemm1x1_split(hip, ref, M, K, N, res, bias):
     hip.conv_policy = 0
 
 
-@pytest.mark.parametrize("M,C0,C1,N", [(51200, 128, 0, 768), (25600, 64, 64, 192), (204800, 64, 0, 128), (12800, 32, 32, 64)])
+@pytest.mark.parametrize("M,C0,C1,N", [(51200, 128, 0, 768), (25600, 64, 64, 192), (204800, 64, 0, 128), (12800, 32, 32, 64),
+                                       (25600, 128, 128, 192), (12800, 512, 0, 128), (51200, 256, 0, 64), (12800, 512, 512, 192)])
 def test_gemm1x1_layernorm_inside(hip, ref, M, C0, C1, N):
-    """Row-stationary split GEMM with the LayerNorm of its input rows computed in the kernel (ln_eps) == LayerNorm statistics
-    pass + projection; shapes that kernel does not serve are refused, not silently computed otherwise."""
+    """Row-stationary / row-accumulator split GEMMs with the LayerNorm of their input rows computed in the kernel (ln_eps) ==
+    LayerNorm statistics pass + projection; shapes those kernels do not serve are refused, not silently computed otherwise."""
     from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
     from dawn_pytorch_amd._lib import DawnHipError
     w = packw(C0 + C1, N, seed=2)
@@ -216,10 +217,10 @@ def test_gemm1x1_layernorm_inside(hip, ref, M, C0, C1, N):
     got = hip.conv_gemm(x0.cuda(), w.cuda(), N, in1=None if x1 is None else x1.cuda(), ln_eps=1e-5,
                         w_bf3=pack_bf3(unpack_kn(w)).cuda(), **kw)
     check(f"gemm1x1_ln_inside/M{M}_C{C0}+{C1}_N{N}", got, want)
-    assert not hip.ln_inline_ok(M, N, 256, 0)
+    assert not hip.ln_inline_ok(M, N, 320, 0)            # neither <= 128 channels nor a multiple of 128
     with pytest.raises(DawnHipError):
-        w2 = packw(256, N, seed=3)
-        hip.conv_gemm(torch.zeros(M, 256, device="cuda"), w2.cuda(), N, ln_eps=1e-5, w_bf3=pack_bf3(unpack_kn(w2)).cuda(), **kw)
+        w2 = packw(320, N, seed=3)
+        hip.conv_gemm(torch.zeros(M, 320, device="cuda"), w2.cuda(), N, ln_eps=1e-5, w_bf3=pack_bf3(unpack_kn(w2)).cuda(), **kw)
 
 
 @pytest.mark.parametrize("M,C0,C1,N,extra", [(51200, 64, 64, 64, "tr"), (12800, 512, 512, 256, "tr"), (25600, 128, 0, 192, ""),
