@@ -38,3 +38,14 @@ def checksum(tensors) -> np.ndarray:
         s += float(t.sum())
         a += float(t.abs().sum())
     return np.asarray([s, a], dtype=np.float64)
+
+
+# multi-step DDIM trajectories (tools/gen_goldens_ddim.py): name -> (T, latent side, DDIM steps, steps whose INPUT
+# latent is kept in the fixture)
+DDIM_CASES = {"C1": (16, 32, 10, (1, 5, 9)), "T96S50": (96, 32, 50, (1, 10, 25, 49))}
+
+
+def ddim_noises(T: int, h: int, S: int, seed: int = 1234):
+    """The S-1 per-step noise tensors (MT:1201: none on the last step), from one seeded CPU generator."""
+    g = torch.Generator().manual_seed(seed)
+    return [torch.randn(1, 3, T, h, h, generator=g) for _ in range(S - 1)]

@@ -1,6 +1,7 @@
 """-m gpu: the product path (Unet3D / GaussianDiffusion on HipOps) against the reference goldens and the
-CPU oracle.  Tolerances (stated): predicted noise within 2e-4 abs of the reference golden on the tiny
-config (values O(1)); 1e-3 on the full DAWN_128 architecture (K up to 9216, ~300 chained ops, fp32)."""
+CPU oracle.  Tolerances (stated): predicted noise within 2e-5 abs of the reference golden on the tiny
+config (values O(1); measured 2.3e-6 .. 5.6e-6); 1e-4 on the full DAWN_128 architecture (K up to 9216, ~300 chained ops,
+fp32; measured 5.0e-6 .. 6.6e-6); trajectories 1e-5 (measured 1.2e-6)."""
 import json
 import os
 
@@ -43,13 +44,13 @@ def test_tiny_unet_golden(tiny):
     g, sd = tiny
     unet = tiny_unet(sd)
     y = unet.forward_with_cond_scale(T(g["x"]).cuda(), T(g["time"]).cuda(), cond=T(g["cond"]).cuda(), cond_scale=1.0)
-    assert log("tiny_unet", y, T(g["y"])) < 2e-4
+    assert log("tiny_unet", y, T(g["y"])) < 2e-5
     y2 = unet.forward_with_cond_scale(T(g["x"]).cuda(), T(g["time"]).cuda(), cond=T(g["cond"]).cuda(), cond_scale=2.5)
-    assert log("tiny_unet_cfg2.5", y2, T(g["y_cond_scale_2p5"])) < 5e-4
+    assert log("tiny_unet_cfg2.5", y2, T(g["y_cond_scale_2p5"])) < 5e-5
     h = load_golden("tiny_unet_T24.npz")
     unet.update_num_frames(24)
     y3 = unet.forward_with_cond_scale(T(h["x"]).cuda(), T(h["time"]).cuda(), cond=T(h["cond"]).cuda(), cond_scale=1.0)
-    assert log("tiny_unet_T24", y3, T(h["y"])) < 2e-4
+    assert log("tiny_unet_T24", y3, T(h["y"])) < 2e-5
 
 
 def test_tiny_ddim_golden(tiny):
@@ -63,8 +64,8 @@ def test_tiny_ddim_golden(tiny):
     out = diff.sample(T(d["fea"]).cuda(), T(d["bbox"]).cuda(), cond=T(d["cond"]).cuda(), cond_scale=1.0,
                       x_init=T(d["x_init"]).cuda(), noises=[n.cuda() for n in T(d["noises"])], trace=True)
     qs = torch.stack([tr["s"][1] for tr in diff.last_trace[0]]).cpu()
-    assert float((qs - T(d["quantiles"]).float()).abs().max()) < 1e-3
-    assert log("tiny_ddim", out, T(d["out"])) < 5e-4
+    assert float((qs - T(d["quantiles"]).float()).abs().max()) < 5e-5
+    assert log("tiny_ddim", out, T(d["out"])) < 1e-5
 
 
 @pytest.mark.parametrize("Tn", [8, 5])
@@ -86,7 +87,7 @@ def test_full_dawn128_forward_vs_oracle(Tn):
     want = O.unet_forward(sd, xin, torch.tensor([627]), cond, win=40)
     unet = unet.cuda()
     got = unet.forward_with_cond_scale(xin.cuda(), torch.tensor([627]).cuda(), cond=cond.cuda(), cond_scale=1.0)
-    assert log(f"dawn128_T{Tn}_forward", got, want) < 1e-3
+    assert log(f"dawn128_T{Tn}_forward", got, want) < 1e-4
 
 
 def test_sampler_properties_large():
@@ -140,7 +141,7 @@ def test_sharded_code_paths_world1(tiny):
                                         use_dynamic_thres=True, null_cond_prob=0.1, ddim_sampling_eta=1.0).cuda()
     out = diff.sample(T(d["fea"]).cuda(), T(d["bbox"]).cuda(), cond=T(d["cond"]).cuda(), cond_scale=1.0,
                       x_init=T(d["x_init"]).cuda(), noises=[n.cuda() for n in T(d["noises"])], comm=_LoopbackComm())
-    assert log("tiny_ddim_sharded_paths", out, T(d["out"])) < 5e-4
+    assert log("tiny_ddim_sharded_paths", out, T(d["out"])) < 1e-5
 
 
 def test_graph_replay_equals_eager():
@@ -169,7 +170,7 @@ def test_benchmark_size_kernel_families_agree(Tn, res):
     checked through a size-independent property: one denoiser evaluation computed with the shipped kernel policy
     (split-operand bf16-pipe convs / GEMMs, LayerNorm in the GEMM loader, 256x64 / 256x128 tile policy, XCD remap) must
     agree with the same evaluation on the exact-fp32-MFMA kernels (policy 0x80D: a different kernel family for every
-    conv and projection; both families are checked against the oracle at small sizes).  Tolerance: 2e-4 x max|y| --
+    conv and projection; both families are checked against the oracle at small sizes).  Tolerance: 3e-5 x max|y| (measured 3.9e-6) --
     ~300 chained fp32 ops whose summation orders differ."""
     import sys
     sys.path.insert(0, ROOT)
@@ -193,7 +194,7 @@ def test_benchmark_size_kernel_families_agree(Tn, res):
     assert torch.isfinite(y_split).all() and torch.isfinite(y_fp32).all()
     scale = float(y_fp32.abs().max())
     err = log(f"benchmark_size_T{Tn}_{res}px_split_vs_fp32_kernels", y_split, y_fp32)
-    assert err <= 2e-4 * max(1.0, scale), (err, scale)
+    assert err <= 3e-5 * max(1.0, scale), (err, scale)
     # determinism of the shipped path at this size (no atomics in any reduction)
     assert torch.equal(unet_forward(ops, P, cs, x, 500), y_split)
 

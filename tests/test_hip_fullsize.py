@@ -7,8 +7,10 @@
     C3  : T=200, h=64 = BASELINE configs[2] (256x256, 200 frames): the benchmark shape with the benchmark kernels
 
 Weights / inputs are rebuilt from seeds (fixture checksums prove they are the same tensors).
-Tolerance: 1e-3 * max(1, max|y|) on the predicted noise (fp32, ~300 chained ops, K up to 9216); measured errors are
-logged to gpurun_out/e2e_errors.jsonl and copied into profiles/r2_parity_errors.md."""
+Tolerance: 1e-4 * max(1, max|y|) on the predicted noise (fp32, ~300 chained ops, K up to 9216) = 6x the worst measured
+error (1.7e-5 at C3; 6e-6 / 9e-6 at T96 / C2); the 2-step trajectory 3e-5 (measured 4e-6).  Measured errors are logged to
+gpurun_out/e2e_errors.jsonl and copied into profiles/r3_parity_errors.md.  Whole 10 / 50-step trajectories:
+tests/test_hip_trajectory.py."""
 import numpy as np
 import pytest
 import torch
@@ -51,7 +53,7 @@ def test_full_architecture_forward_vs_reference(name, full_unet):
     want = torch.from_numpy(g["y"])
     err = log(f"full_{name}_T{T}_h{h}_forward_vs_reference", got[0].cpu()[:, fr], want)
     assert torch.isfinite(got).all()
-    assert err < 1e-3 * max(1.0, float(g["y_absmax"])), err
+    assert err < 1e-4 * max(1.0, float(g["y_absmax"])), err
     # the evaluation is deterministic (no atomics in any reduction)
     if name == "T96":
         xin = torch.cat((x3, fea272.unsqueeze(2).expand(-1, -1, T, -1, -1)), 1).cuda()
@@ -74,6 +76,6 @@ def test_full_architecture_ddim_vs_reference(full_unet):
                       x_init=x3.cuda(), noises=noises, trace=True)
     qs = torch.stack([tr["s"][1] for tr in diff.last_trace[0]]).cpu()
     qref = torch.from_numpy(g["ddim_quantiles"]).float()
-    assert float(((qs - qref).abs() / qref.abs()).max()) < 1e-4, (qs, qref)
+    assert float(((qs - qref).abs() / qref.abs()).max()) < 2e-5, (qs, qref)
     fr = torch.from_numpy(g["frames"]).long()
-    assert log("full_T96_ddim2_vs_reference", out[0].cpu()[:, fr], torch.from_numpy(g["ddim_out"])) < 1e-3
+    assert log("full_T96_ddim2_vs_reference", out[0].cpu()[:, fr], torch.from_numpy(g["ddim_out"])) < 3e-5

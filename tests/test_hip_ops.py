@@ -433,6 +433,37 @@ def test_xattn_layer_c64(hip, ref, C0, C1, Fn, HW):
     check(f"xattn_layer_c64_split/{C0}+{C1}_F{Fn}_HW{HW}", got, want, 3e-5)
 
 
+@pytest.mark.parametrize("Co", [64, 256])
+def test_xattn_trained_weight_like_range(hip, ref, Co):
+    """Cross-attention with trained-checkpoint-like scales: q_scale / k_scale of ~4 (logits up to 8*16*|cos| = +-128: the
+    two-key softmax saturates to exactly 0 / 1 for many heads -- the closed form 1/(1+2^z) must neither overflow to NaN nor
+    lose the small side), activations x30 with an offset (LayerNorm removes both) and a large null key."""
+    Fn, HW = 3, 64
+    rows = Fn * HW
+    qs = rnd(3, 8, seed=5) * 0.5 + 4.0
+    kvtab, nulltab = torch.zeros(Fn, 3, 128), torch.zeros(3, 16)
+    for b in range(3):
+        ref.xattn_prep(rnd(Fn, 128, seed=20 + b) * 5.0, rnd(8, seed=30 + b) * 0.5 + 4.0, rnd(2, 8, seed=40 + b) * 5.0, kvtab, b, nulltab)
+    wo = [packw(64, Co, seed=10 + b) for b in range(3)]
+    g3 = rnd(3, Co, seed=4) * 0.2 + 1
+    if Co == 64:
+        x = (rnd(rows, 64, seed=1) * 1.5 + 0.3) * 30.0
+        wq = packw(64, 192, seed=3) * 4.0
+        want = ref.xattn_layer_c64(x, None, HW, wq, wo, g3, qs, kvtab, nulltab)
+        from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+        for bf3 in (None, pack_bf3(unpack_kn(wq)).cuda()):
+            got = hip.xattn_layer_c64(x.cuda(), None, HW, wq.cuda(), [w.cuda() for w in wo], g3.cuda(), qs.cuda(), kvtab.cuda(),
+                                      nulltab.cuda(), wq_bf3=bf3)
+            check(f"xattn_layer_c64/wide_range_split{int(bf3 is not None)}", got, want, 1e-4)
+    else:
+        q = rnd(rows, 192, seed=1) * 40.0
+        o = ref.xattn_core(q.clone(), HW, kvtab, nulltab, qs)
+        y3 = torch.cat([ref.conv_gemm(o[:, 64 * b:64 * b + 64], wo[b], Co, F=rows, Hi=1, Wi=1) for b in range(3)], 1)
+        want = ref.xattn_ln_sum(y3, g3, Co)
+        xtab = hip.xattn_tables(kvtab.cuda(), nulltab.cuda(), qs.cuda(), [w.cuda() for w in wo], Co)
+        check(f"xattn_sigma_out/Co{Co}_wide_range", hip.xattn_sigma_out(q.cuda(), HW, xtab, g3.cuda(), Co), want, 1e-4)
+
+
 @pytest.mark.parametrize("Co,Fn,HW", [(128, 3, 1024), (256, 5, 64), (512, 7, 16), (32, 2, 4), (96, 3, 36), (64, 2, 64)])
 def test_xattn_sigma_out_equals_unfused_chain(hip, ref, Co, Fn, HW):
     """One-pass kernel (tables + sigmoid + K = 9 affine form + LN + sum) == xattn_core + 3 to_out GEMMs + xattn_ln_sum in
@@ -516,6 +547,36 @@ def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
             check(f"temporal_layer_c64_{name}/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 3e-5)
     finally:
         hip.temporal_flags = 0
+
+
+def test_temporal_attention_trained_weight_like_range(hip, ref):
+    """Trained-checkpoint-like statistics (all parity is on random-init weights, where logits are O(1)): activations x30 with
+    a trend along the frame axis, projection weights x6 -> logits of +-100s that grow towards late frames, so that every key
+    tile raises the running softmax maximum and most probabilities underflow; the relative-position band spans +-20.  The
+    fused layer (every kernel family) and the unfused attention core must still match the max-subtracted fp32 reference."""
+    from dawn_pytorch_amd.pack import pack_bf3, pack_bf3_temporal_out, unpack_kn
+    Fext, HW, q0, Fq, win = 200, 4, 0, 200, 40
+    ramp = torch.linspace(-1.0, 1.0, Fext).repeat_interleave(HW)[:, None]
+    x = (rnd(Fext * HW, 64, seed=1) * 1.3 + ramp * rnd(1, 64, seed=7) * 3.0) * 30.0
+    wqkv, wout = packw(64, 768, seed=2) * 6.0, packw(256, 64, seed=3)
+    ang = torch.arange(Fext).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
+    rc, rs = ang.cos().contiguous(), ang.sin().contiguous()
+    band = rnd(2 * win + 1, 8, seed=4) * 20.0
+    want = ref.temporal_layer_c64(x, Fext, HW, q0, Fq, win, wqkv, wout, rc, rs, band)
+    wsplit, wosp = pack_bf3(unpack_kn(wqkv)).cuda(), pack_bf3_temporal_out(unpack_kn(wout)).cuda()
+    try:
+        for flags, name in ((0, "default"), (1, "wmode0"), (3, "wmode2"), (4, "wmode3")):
+            hip.temporal_flags = flags
+            got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band), wqkv_bf3=wsplit,
+                                         wout_bf3p=wosp)
+            check(f"temporal_layer_c64_{name}/wide_range", got, want, 1e-4)
+    finally:
+        hip.temporal_flags = 0
+    qkv = rnd(Fext * HW, 768, seed=5) * 6.0
+    qkv[:, 256:512] += ramp * 12.0                                    # keys trend along the frame axis
+    want = ref.temporal_attn(qkv, Fext, HW, q0, Fq, win, rc, rs, band)
+    check("temporal_attn/wide_range", hip.temporal_attn(qkv.cuda(), Fext, HW, q0, Fq, win, rc.cuda(), rs.cuda(), band.cuda()),
+          want, 1e-4)
 
 
 @pytest.mark.parametrize("Fext,HW,q0,Fq", [(400, 8, 0, 400), (280, 8, 40, 200), (330, 4, 17, 301), (240, 8, 0, 200)])

@@ -132,3 +132,25 @@ def test_full_architecture_T96_vs_reference():
     xin = torch.cat((x3, fea272.unsqueeze(2).expand(-1, -1, Tn, -1, -1)), 1)
     y = O.unet_forward(sd, xin, torch.tensor([tval]), cond, win=40)
     close(y[0][:, T(g["frames"]).long()], g["y"], 2e-5)
+
+
+def test_ddim_C1_trajectory_vs_reference():
+    """BASELINE configs[0]'s exact workload (full architecture, T=16, h=32, S=10, eta=1) against the reference sampler's
+    own trajectory (tools/gen_goldens_ddim.py): every step's dynamic threshold, intermediate latents, final sample.
+    The 50-step T=96 trajectory is checked by tools/check_oracle_ddim.py in the build container (minutes of CPU)."""
+    import dawn_pytorch_amd as D
+    from fullsize_cases import DDIM_CASES, KW, build_inputs, checksum, ddim_noises
+    g = load_golden("ddim_C1.npz")
+    Tn, h, S, keep = DDIM_CASES["C1"]
+    unet = D.DynamicNfUnet3D(default_num_frames=Tn, **KW, init_seed=0)
+    sd = {"denoise_fn." + k: v for k, v in unet.state_dict().items()}
+    np.testing.assert_allclose(checksum(unet.state_dict().values()), g["weights_checksum"], rtol=1e-12)
+    fea272, cond, x3 = build_inputs(Tn, h)
+    np.testing.assert_allclose(checksum([fea272, cond, x3]), g["inputs_checksum"], rtol=1e-12)
+    noises = ddim_noises(Tn, h, S, int(g["ddim_noise_seed"])) + [torch.zeros(1, 3, Tn, h, h)]
+    trace = []
+    out = O.ddim_sample(sd, fea272, cond, x3, noises, S, win=40, trace=trace)
+    close(torch.stack([tr["s"][0] for tr in trace]).reshape(-1), np.maximum(g["quantiles"], 1.0), 2e-5)
+    for s in keep:
+        close(trace[s - 1]["img"][0], g[f"x_before_step_{s}"], 2e-5)
+    close(out[0], g["out"], 2e-5)
