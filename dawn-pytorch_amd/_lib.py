@@ -39,6 +39,7 @@ class ConvDesc(C.Structure):
         ("gn_rows", C.POINTER(C.c_int)),
         ("policy", _i),
         ("ln_eps", _f),
+        ("sk_ws", c_f), ("sk_ws_bytes", C.c_size_t),
     ]
 
 
@@ -46,6 +47,9 @@ class ConvDesc(C.Structure):
 SIGNATURES = {
     "dawn_conv_gemm": [C.POINTER(ConvDesc), c_f],
     "dawn_conv_gemm_nblocks": [_l, _i],
+    "dawn_conv_sk_workspace_bytes": [],
+    "dawn_conv_sk_workspace_init": [c_f, c_f],
+    "dawn_conv_sk_check": [c_f, c_f],
     "dawn_gn_partial": [c_f, _l, _i, _i, c_f, _i, c_f],
     "dawn_gn_reduce": [c_f, _i, c_f, c_f],
     "dawn_gn_finalize": [c_f, _d, c_f, c_f, c_f, c_f, _i, _f, c_f, c_f, c_f],
@@ -100,7 +104,7 @@ class DawnHipError(RuntimeError):
     pass
 
 
-LONG_RESULT = {"dawn_sla_ws_floats"}       # entry points that return a size (long), not a status
+LONG_RESULT = {"dawn_sla_ws_floats", "dawn_conv_sk_workspace_bytes"}       # entry points that return a size (long), not a status
 
 
 def lib() -> C.CDLL:

@@ -14,6 +14,8 @@
 // lanes 0-31 feed k = {0..3}, lanes 32-63 feed k = {4..7} of each 8-wide k group, so every lane reads ONE
 // float4 per operand tile for four MFMAs.  Workgroups are remapped so that each XCD (private L2) walks a
 // contiguous range of M tiles: the +-1 row halos of a 3x3 conv then hit in that XCD's L2.
+#include <algorithm>
+
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 
@@ -28,11 +30,13 @@ namespace {
 // 3x3/s1/p1 convs whose tile geometry fits (+5..19 %, profiles/r1_l_conv_halo.txt), 0x1000 split-operand bf16
 // MFMA version of that kernel when the caller supplies w_bf3 (6 cross terms; 0x2000: all 9), 0x4000 its second
 // generation (conv3x3_bf16_v2_kernel: +5..20 %, profiles/r1_n_conv_bf16.txt), 0x10/0x20 fp32-kernel perf ablations,
-// (8 << 16) the s_memtime build of the split kernel.
+// (8 << 16) the s_memtime build of the split kernel, 0x400 the persistent stream-K 3x3 kernel (conv3x3_sk.hip) when the caller
+// supplies dawn_conv_desc.sk_ws (0x200: without the half-tile offset between co-resident workgroups; bits 20..23 there: leave
+// n/16 of the resident slots to a concurrent stream).
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
 // split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
-constexpr int DAWN_CONV_POLICY_DEFAULT = 0x580D;
+constexpr int DAWN_CONV_POLICY_DEFAULT = 0x5C0D;
 #ifdef DAWN_ABLATION
 constexpr int DAWN_CONV_POLICY_MASK = 0x000FFFFF;
 #else
@@ -2298,6 +2302,8 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 
 }  // namespace
 
+int dawn_conv3x3_sk_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows);   // conv3x3_sk.hip
+
 #ifdef DAWN_ABLATION
 extern "C" int dawn_conv_set_debug(void* p) {
     return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_dbg), &p, sizeof(p));
@@ -2315,9 +2321,10 @@ extern "C" int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1) {
 }
 
 extern "C" int dawn_conv_gemm_nblocks(long M, int N) {
-    if (N <= 64) return dawn_cdiv(M, 128);   // upper bound (the 256-row tile variants launch fewer blocks; the
+    const int sk = 2 * dawn_ncu();             // the persistent 3x3 kernel writes one row per resident workgroup
+    if (N <= 64) return std::max(sk, dawn_cdiv(M, 128));   // upper bound (the 256-row tile variants launch fewer blocks; the
                                              // caller zero-fills the buffer)
-    return dawn_cdiv(M, 128) * dawn_cdiv(N, 128);
+    return std::max(sk, dawn_cdiv(M, 128) * dawn_cdiv(N, 128));
 }
 
 extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
@@ -2356,6 +2363,14 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         d.Ho == d.Hi && d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool nine = (policy_of(d) & 0x2000) != 0;
         bool ok = false;
+        if ((policy_of(d) & 0x400) && !nine && d.sk_ws) {   // persistent stream-K kernel (conv3x3_sk.hip)
+            int rows = 0;
+            if (dawn_conv3x3_sk_try(d, M, policy_of(d), s, &rows)) {
+                if (d.gn_rows) *d.gn_rows = rows;
+                DAWN_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         if (policy_of(d) & 0x4000) {           // v2 structure (row-of-taps weight stages, register-prefetched patch)
             // 256 x 128 tiles run one 8-wave workgroup per CU: when they occupy at most half of the 256 CUs (M = 12,800 rows,
             // N = 256: 100 tiles), 256 x 64 tiles put one 4-wave workgroup on twice as many CUs and the launch takes

@@ -269,6 +269,8 @@ struct Eval {
     const char* clip;
     ClipLayout L;
     int rc = 0;
+    void* sk_ws = nullptr;
+    size_t sk_bytes = 0;
 
     Eval(dawn_ctx* ctx, hipStream_t s, int F_, int h, int w, const void* clip_mem)
         : c(ctx), cur(s), main(s), A(ctx->arena), dry(ctx->arena.dry), F(F_), H0(h), W0(w), clip((const char*)clip_mem) {
@@ -311,6 +313,7 @@ struct Eval {
         d.res = a.res; d.ld_res = a.ld_res; d.tr = a.tr; d.ld_tr = a.ld_tr; d.tr_a = a.tr_a; d.tr_b = a.tr_b;
         d.out = a.out; d.ld_out = a.ld_out; d.gn_part = a.gn_part; d.w_bf3 = a.w_bf3; d.gn_rows = a.gn_rows;
         d.policy = c->conv_policy;
+        if (sk_ws && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1) { d.sk_ws = sk_ws; d.sk_ws_bytes = sk_bytes; }
         if (dry || rc) { if (a.gn_rows) *a.gn_rows = 1; return; }
         const bool prof = c->prof_on;
         ProfEntry pe;
@@ -550,6 +553,11 @@ struct Eval {
     // ---- one evaluation: x3 (3,F,h,w) latent, t -> eps (3,F,h,w)   (unet_forward.unet_forward)
     void forward(const float* x3, float t, float* eps_out) {
         const int dim = c->cfg.dim;
+        // scratch of the persistent stream-K 3x3 kernel (partial-tile hand-offs); its flag header must start zeroed
+        sk_bytes = dawn_conv_sk_workspace_bytes();
+        sk_ws = A.alloc(sk_bytes);
+        if (!sk_ws && rc == 0) rc = dawn_set_error_msg(-201, "dawn_ctx: activation workspace too small (dawn_workspace_bytes)");
+        if (sk_ws) LAUNCH(dawn_conv_sk_workspace_init(sk_ws, cur));
         // time_film: sinusoidal -> Linear -> GELU -> Linear -> [SiLU -> Linear] for every block in one GEMV
         float* e0 = falloc(dim);
         float* e1 = falloc(c->time_dim);
@@ -619,6 +627,7 @@ struct Eval {
         LAUNCH(dawn_head_out(hg.p, ho.p, c->wg, c->bg, c->wo, c->bo, (long)F * H * W, hg.C, eps_out, cur));
         rel(hg); rel(ho);
         A.free(film);
+        if (sk_ws) { A.free(sk_ws); sk_ws = nullptr; }
     }
 };
 

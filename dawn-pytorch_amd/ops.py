@@ -44,6 +44,24 @@ class HipOps:
         self.graph_error = None      # set when a HIP-graph capture failed and the sampler fell back to eager
         self.conv_policy = 0         # dawn_conv_desc.policy of every conv_gemm launch (0 = shipped kernel policy)
         self.temporal_flags = 0      # kernel-family selector of the fused temporal layer (0 = automatic; A/B and tests)
+        self.stream_k = True         # 3x3 convs on the persistent stream-K kernel (needs the scratch below)
+        self._sk_ws = {}             # device index -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
+
+    def sk_workspace(self, like: Tensor) -> Tensor:
+        """Scratch of the persistent stream-K 3x3 kernel (dawn_conv_desc.sk_ws): one per device, flag header zeroed once.
+        All 3x3 convs of an evaluation run on ONE stream (unet_forward), so one buffer serves them all."""
+        key = like.device.index
+        ws = self._sk_ws.get(key)
+        if ws is None:
+            ws = torch.empty(int(self.L.dawn_conv_sk_workspace_bytes()), device=like.device, dtype=torch.uint8)
+            check(self.L.dawn_conv_sk_workspace_init(_p(ws), self._stream()), "dawn_conv_sk_workspace_init")
+            self._sk_ws[key] = ws
+        return ws
+
+    def sk_check(self) -> None:
+        """Synchronising check of the stream-K kernel's error word (call once per clip, not per launch)."""
+        for ws in self._sk_ws.values():
+            check(self.L.dawn_conv_sk_check(_p(ws), self._stream()), "dawn_conv_sk_check")
 
     def with_comm(self, comm):
         o = HipOps(comm)
@@ -53,6 +71,8 @@ class HipOps:
         o.overlap = self.overlap
         o.conv_policy = self.conv_policy
         o.temporal_flags = self.temporal_flags
+        o.stream_k = self.stream_k
+        o._sk_ws = self._sk_ws
         return o
 
     # ------------------------------------------------------------------ helpers
@@ -128,6 +148,9 @@ class HipOps:
         d.w_bf3 = _p(w_bf3)
         d.policy = self.conv_policy
         d.ln_eps = ln_eps
+        if self.stream_k and w_bf3 is not None and KH == 3 and KW == 3 and stride == 1 and mode == 0:
+            ws = self.sk_workspace(in0)
+            d.sk_ws, d.sk_ws_bytes = _p(ws), ws.numel()
         nrows = C.c_int(0)
         if gn_part is not None:
             d.gn_rows = C.pointer(nrows)

@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(names) - {"dawn_last_error", "dawn_abi_version"} - CTX
     assert CTX <= set(names)
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.dawn_abi_version() == 3
+    assert L.dawn_abi_version() == 4
     # no process-global tuning hooks / ablation entry points in the shipped library (policy travels in dawn_conv_desc)
     for gone in ("dawn_conv_set_variant", "dawn_conv_set_debug"):
         assert not hasattr(L, gone), gone
@@ -43,9 +43,9 @@ def test_conv_desc_layout_matches_c():
         decl = decl.strip()
         if not decl:
             continue
-        is_ptr = "*" in decl
-        for name in re.sub(r"^(const\s+)?(float|int|double|void)\s*\*?", "", decl).split(","):
-            fields.append((name.strip().lstrip("*").strip(), 8 if is_ptr else 4))
+        is_wide = "*" in decl or decl.startswith("size_t")
+        for name in re.sub(r"^(const\s+)?(float|int|double|void|size_t)\s*\*?", "", decl).split(","):
+            fields.append((name.strip().lstrip("*").strip(), 8 if is_wide else 4))
     off, expect = 0, {}
     for name, size in fields:
         off = (off + size - 1) // size * size

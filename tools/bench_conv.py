@@ -27,11 +27,12 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default=",".join(CASES))
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--variants", default="7")
+ap.add_argument("--gn", action="store_true", help="emit GroupNorm partial sums from the conv epilogue (as the ResBlock convs do)")
 a = ap.parse_args()
 ops = HipOps()
 dev = "cuda"
 import itertools
-for variant, name in itertools.product([int(v) for v in a.variants.split(",")], a.cases.split(",")):
+for variant, name in itertools.product([int(v, 0) for v in a.variants.split(",")], a.cases.split(",")):
     ops.conv_policy = variant
     F, H, W, C0, C1, N, k, st, pad, rs = CASES[name]
     rows = F * H * W
@@ -49,6 +50,8 @@ for variant, name in itertools.product([int(v) for v in a.variants.split(",")], 
     if rs:
         kw["row_stats"] = (torch.randn(rows, device=dev) * 0.1, torch.rand(rows, device=dev) + 0.5)
     out = torch.empty(rows, N, device=dev)
+    if a.gn and k == 3:
+        kw["gn_part"] = ops.conv_gn_part(rows, N, x0)
     ops.conv_gemm(x0, w, N, out=out, **kw)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
