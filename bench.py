@@ -186,6 +186,8 @@ def main():
                     help="record the per-launch HIP events of the roofline measurement on every n-th DDIM step of the timed "
                          "region (every step costs ~2.5 %% of the run: two marker packets per conv launch)")
     ap.add_argument("--no-overlap", action="store_true", help="disable the two-stream overlap inside ResBlocks")
+    ap.add_argument("--conv-policy", type=lambda v: int(v, 0), default=0,
+                    help="A/B only: dawn_conv_desc.policy of every conv launch (0 = the shipped kernel policy)")
     ap.add_argument("--host", choices=["python", "ctx"], default="python",
                     help="who issues the launches of the DDIM loop: the Python orchestration (unet_forward.py / sampler.py) or "
                          "the C-side evaluator (dawn_sampler_run, csrc/dawn_ctx.hip; single-GPU / replica modes); same kernels, "
@@ -226,6 +228,7 @@ def main():
                                        Ttotal=Ttotal)
     ops = unet._ops()
     ops.overlap = not args.no_overlap
+    ops.conv_policy = args.conv_policy
     diff.use_ctx = args.host == "ctx" and mode != "tshard"
     if diff.use_ctx:
         from dawn_pytorch_amd import ctx as _ctx

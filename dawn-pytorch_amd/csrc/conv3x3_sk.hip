@@ -30,9 +30,11 @@ struct sk_args {
     int nC, nNt, ncx, G;         // 16-channel chunks per tile, 64*WN-column tiles, column tiles per row band, grid
     int U;                       // ntiles * nC work units
     int pair_xor;                // de-phasing of the two co-resident workgroups (see the launcher)
+    int prio_alt;                // alternate the issue priority of the two co-resident workgroups per unit
     float* part;                 // [G][256 * BN] fp32 partial tiles
     unsigned* flag;              // [G]   1 = partial published (reset by its consumer)
     unsigned* err;               // [1]   set when a spin timed out (results invalid)
+    unsigned long long* dbg;     // instrumented build only: [G][64] s_memtime stamps
 };
 
 // exact truncation split of 4 fp32 values into three bf16 quads (dawn_split3_oct's scheme, see dawn_common.h)
@@ -54,14 +56,15 @@ __device__ __forceinline__ void split3q(const f32x4 v, uint2& p1, uint2& p2, uin
     p3 = make_uint2(q3[0], q3[1]);
 }
 
-// sum over the 64 lanes of a wave, result in every lane: four DPP adds inside each row of 16, two xor shuffles across rows
+// sum over the 64 lanes of a wave, result in lanes 48..63 (only): four DPP adds inside each row of 16 (quad xor 1, quad xor 2,
+// half-row mirror, row mirror), then row_bcast15 into rows 1 / 3 and row_bcast31 into rows 2 / 3 -- no LDS round trips
 __device__ __forceinline__ float wave_sum64_dpp(float v) {
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
     v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
-    v += __shfl_xor(v, 16, 64);
-    v += __shfl_xor(v, 32, 64);
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x143, 0xC, 0xF, false));
     return v;
 }
 
@@ -69,7 +72,7 @@ struct sk_tile {                 // position of a tile in the (row band, column 
     int nt, xq, y0, f0;
 };
 
-template <int TR, int WT, int NF, int WN>
+template <int TR, int WT, int NF, int WN, int DBG = 0>
 __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn_conv_desc d, const sk_args a) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; buffer-resource builtins are device-only)
     constexpr int NTHR = 256 * WN, BN = 64 * WN, TM = 2, TN = 2;
@@ -88,6 +91,15 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
     unsigned char* const planes = smem_b;                      // [3 planes][2 k-halves][HPS]
     unsigned char* const Bs = smem_b + (size_t)6 * HPS;        // [2][3 taps][3 planes][2 halves][BN][16 B]
     float* const wsum = reinterpret_cast<float*>(smem_b + (size_t)6 * HPS + 2 * SB);   // [NW][16] GroupNorm wave sums
+    unsigned long long* const stamps = reinterpret_cast<unsigned long long*>(smem_b + (size_t)6 * HPS + 2 * SB + NW * 64);   // DBG: [64]
+    int tix = 0;
+    bool stamp_on = false;
+    unsigned long long t_start = 0;
+    if (DBG) t_start = __builtin_amdgcn_s_memtime();
+#define TSTAMP()                                                                              \
+    do {                                                                                      \
+        if (DBG && threadIdx.x == 0 && stamp_on && tix < 62) stamps[tix++] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -198,7 +210,6 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
     };
 
     f32x4 araw[MAXQ];
-    uint2 ap[MAXQ][3];
     auto loadA = [&](int i) {
         const int cbase = Lcc * 16;
         const bool src1 = cbase >= d.C0;
@@ -209,15 +220,21 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
                              : __builtin_amdgcn_raw_buffer_load_b128(rs0, voff, soff, 0);
         araw[i] = __builtin_bit_cast(f32x4, x);
     };
-    auto convA = [&](int i) { split3q(araw[i], ap[i][0], ap[i][1], ap[i][2]); };
+    // The fp32 quads stay in registers until the planes are free (after the last tap of the unit) and are split + written
+    // in one burst there: holding the three split images of all quads next to the 12 MFMA fragments of a tap (as the v2
+    // kernel does) exceeds the 256-register budget of two waves per SIMD -- the fragment reads then serialise behind the
+    // MFMAs that free their registers.  The burst (~150 VALU + 21 LDS writes per unit) runs while the co-resident
+    // workgroup's waves own the matrix pipe.
     auto writeA = [&]() {
 #pragma unroll
         for (int i = 0; i < MAXQ; ++i) {
             if (tid + NTHR * i < NQ) {
+                uint2 p1, p2, p3;
+                split3q(araw[i], p1, p2, p3);
                 unsigned char* dst = planes + dbase + i * (NTHR * 4);
-                *reinterpret_cast<uint2*>(dst) = ap[i][0];
-                *reinterpret_cast<uint2*>(dst + 2 * HPS) = ap[i][1];
-                *reinterpret_cast<uint2*>(dst + 4 * HPS) = ap[i][2];
+                *reinterpret_cast<uint2*>(dst) = p1;
+                *reinterpret_cast<uint2*>(dst + 2 * HPS) = p2;
+                *reinterpret_cast<uint2*>(dst + 4 * HPS) = p3;
             }
         }
     };
@@ -250,8 +267,6 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
         issueB(L.nt * BN, Lcc, 0, 0);
 #pragma unroll
         for (int i = 0; i < MAXQ; ++i) loadA(i);
-#pragma unroll
-        for (int i = 0; i < MAXQ; ++i) convA(i);
         writeA();
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 
@@ -262,8 +277,21 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
         for (int u = u0;; ++u) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                   // planes(u) written, weight stage (u, 0) landed: visible to all
+            if (DBG) stamp_on = (u - u0 >= 2 && u - u0 < 6);
+            TSTAMP();   // unit top (barrier passed)
             const bool has_next = u + 1 < u1;
             const int Cn0 = Ct.nt * BN;
+            // issue priority alternates between the two co-resident workgroups from unit to unit: with equal priority the
+            // older workgroup of a CU wins every arbitration and finishes its (equal) range ~30 % earlier than the younger
+            // one, which then runs alone (measured spread of workgroup durations 410 k .. 581 k cycles)
+            if (a.prio_alt) {
+                // mode 1: by unit parity; modes 2..4: time slices of 2^12 / 2^14 / 2^16 cycles of the XCD's clock, which both
+                // workgroups of a CU read -- their priorities are complementary at every instant
+                const unsigned phase = a.prio_alt == 1 ? (unsigned)(u - u0)
+                                                       : (unsigned)(__builtin_amdgcn_s_memtime() >> (8 + 2 * a.prio_alt));
+                if ((phase + (blockIdx.x >= (unsigned)(G >> 1) ? 1u : 0u)) & 1u) __builtin_amdgcn_s_setprio(1);
+                else __builtin_amdgcn_s_setprio(0);
+            }
             if (has_next) {
                 if (++Lcc == nC) { Lcc = 0; advance(L); make_window(); }
             }
@@ -277,6 +305,7 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
                     for (int i = 0; i < MAXQ; ++i)
                         if ((ky == 0 && i < L0) || (ky == 1 && i >= L0)) loadA(i);
                 }
+                TSTAMP();   // stage: DMA / patch requests issued
                 const unsigned char* Bb = Bs + bb0 + (size_t)bufB * SB;
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
@@ -302,42 +331,33 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
 #pragma unroll
                             for (int j = 0; j < TN; ++j)
                                 acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB6[t]], fa[i][PA6[t]], acc[i][j], 0, 0, 0);
-                    // split the quads that landed during the previous stage, in the shadow of the MFMAs above
-                    if (has_next && ky > 0) {
-#pragma unroll
-                        for (int i = 0; i < MAXQ; ++i) {
-                            const bool mine = ky == 1 ? i < L0 : i >= L0;
-                            const int ord = ky == 1 ? i : i - L0;
-                            if (mine && ord % 3 == kx) convA(i);
-                        }
-                    }
-                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);           // the 12 fragment reads first
-#pragma unroll
-                    for (int t = 0; t < 24; ++t) {
-                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);        // then MFMA, 2 VALU (split), MFMA, ...
-                        __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
-                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);           // the 12 fragment reads first,
+                    __builtin_amdgcn_sched_group_barrier(0x008, 24, 0);           // then the 24 MFMAs
                 }
+                TSTAMP();   // stage: MFMAs issued
                 // the next weight stage and this stage's patch quads have landed (the register operands pin the split of
-                // the quads behind the wait); after the barrier this stage's weight buffer -- and, for ky == 2, the planes --
-                // may be overwritten
+                // the quads behind the wait: the compiler must not start it -- and wait for the loads -- earlier); after the
+                // barrier this stage's weight buffer -- and, for ky == 2, the planes -- may be overwritten
+                // (lgkmcnt(0): this wave's fragment reads are complete, not merely issued, before it signals the barrier; the
+                //  accumulator operands keep the stage's MFMAs in front of the barrier, so that the next stage opens with its
+                //  DMA / patch requests)
+#define SK_STAGE_WAIT(...)                                                                                              \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"                                                                        \
+                 : "+v"(acc[0][0]), "+v"(acc[0][1]), "+v"(acc[1][0]), "+v"(acc[1][1]), __VA_ARGS__ :: "memory")
                 if (MAXQ == 7)
-                    asm volatile("s_waitcnt vmcnt(0)"
-                                 : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]), "+v"(araw[4]), "+v"(araw[5]),
-                                   "+v"(araw[MAXQ - 1])
-                                 :: "memory");
+                    SK_STAGE_WAIT("+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]), "+v"(araw[4]), "+v"(araw[5]), "+v"(araw[MAXQ - 1]));
                 else if (MAXQ == 6)
-                    asm volatile("s_waitcnt vmcnt(0)"
-                                 : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]), "+v"(araw[4]), "+v"(araw[MAXQ - 1])
-                                 :: "memory");
+                    SK_STAGE_WAIT("+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]), "+v"(araw[4]), "+v"(araw[MAXQ - 1]));
                 else
-                    asm volatile("s_waitcnt vmcnt(0)"
-                                 : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[MAXQ - 1])
-                                 :: "memory");
+                    SK_STAGE_WAIT("+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[MAXQ - 1]));
+#undef SK_STAGE_WAIT
+                TSTAMP();   // stage: loads landed
                 __builtin_amdgcn_s_barrier();
+                TSTAMP();   // stage: barrier passed
                 bufB ^= 1;
             }
             if (has_next) writeA();                         // planes(u + 1)
+            TSTAMP();   // planes written
 
             if (Ccc == nC - 1 || !has_next) {
                 // ================= end of this workgroup's part of tile Ct =================
@@ -424,6 +444,7 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
                             }
                         }
                     }
+                    TSTAMP();   // (tile end) stores issued
                     if (d.gn_part) {
                         // wave sums (fp32 over the wave's 64 pixels x 8 channels of a group), fp64 from there on
 #pragma unroll
@@ -431,7 +452,7 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
 #pragma unroll
                             for (int g = 0; g < 4; ++g) {
                                 const float s1 = wave_sum64_dpp(gs[j][g]), s2 = wave_sum64_dpp(gss[j][g]);
-                                if (lane == 0) {
+                                if (lane == 63) {
                                     wsum[wave * 16 + (j * 4 + g) * 2] = s1;
                                     wsum[wave * 16 + (j * 4 + g) * 2 + 1] = s2;
                                 }
@@ -439,19 +460,25 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
                         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                         __builtin_amdgcn_s_barrier();
                         if (tid < 16) {
-                            const int grp = tid >> 1, which = tid & 1;
+                            // (8-channel column block jg of wave w covers channels Cn0 + (w % WN)*64 + 8*jg ..+7: it belongs to
+                            //  this thread's group when that start lies in [grp*cpg, (grp+1)*cpg) -- compares, no division)
+                            const int which = tid & 1;
                             const int cpg = d.N >> 3;
+                            const int lo = (tid >> 1) * cpg - Cn0, hi = lo + cpg;
                             double s = 0.0;
+#pragma unroll
                             for (int w = 0; w < NW; ++w)
 #pragma unroll
-                                for (int jg = 0; jg < 8; ++jg)
-                                    if ((Cn0 + (w % WN) * 64 + (jg >> 2) * 32 + 8 * (jg & 3)) / cpg == grp)
-                                        s += (double)wsum[w * 16 + jg * 2 + which];
+                                for (int jg = 0; jg < 8; ++jg) {
+                                    const int c = (w % WN) * 64 + 8 * jg;
+                                    if (c >= lo && c < hi) s += (double)wsum[w * 16 + jg * 2 + which];
+                                }
                             gn64 += s;
                         }
                         // (wsum is rewritten at the next finished tile, several barriers from here)
                     }
                 }
+                TSTAMP();   // (tile end) GroupNorm sums done
                 zero_acc();
                 part_cc0 = 0;
             }
@@ -461,6 +488,10 @@ __global__ __launch_bounds__(256 * WN, 2 / WN) void conv3x3_sk_kernel(const dawn
         }
     }
     if (d.gn_part && tid < 16) d.gn_part[(long)blockIdx.x * 16 + tid] = gn64;
+    if (DBG && tid == 0 && a.dbg)
+        for (int i = 0; i < 64; ++i)
+            a.dbg[(size_t)blockIdx.x * 64 + i] = i == 62 ? t_start : (i == 63 ? (unsigned long long)__builtin_amdgcn_s_memtime() : (i < tix ? stamps[i] : 0ull));
+#undef TSTAMP
 #endif
 }
 
@@ -475,26 +506,31 @@ static int sk_ncu() {
     return n;
 }
 
-template <int TR, int WT, int NF, int WN>
+template <int TR, int WT, int NF, int WN, int DBG = 0>
 bool launch_sk(const dawn_conv_desc& d, const sk_args& a, hipStream_t s) {
     constexpr int BN = 64 * WN;
     constexpr int PW = WT + 2, P = NF * (TR + 2) * PW, P16 = (P + 15) / 16 * 16;
-    constexpr size_t lds = (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 18 * BN * 16 + (size_t)4 * WN * 16 * 4;
+    constexpr size_t lds = (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 18 * BN * 16 + (size_t)4 * WN * 16 * 4 + (DBG ? 512 : 0);
     static int occ = -1;                                    // resident workgroups per CU of this instantiation (queried once)
     if (occ < 0) {
-        (void)hipFuncSetAttribute((const void*)conv3x3_sk_kernel<TR, WT, NF, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipFuncSetAttribute((const void*)conv3x3_sk_kernel<TR, WT, NF, WN, DBG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         int o = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)conv3x3_sk_kernel<TR, WT, NF, WN>, 256 * WN, lds) != hipSuccess) o = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&o, (const void*)conv3x3_sk_kernel<TR, WT, NF, WN, DBG>, 256 * WN, lds) != hipSuccess) o = 0;
         occ = o;
     }
     // the owner of a cut tile waits for partials of HIGHER-numbered workgroups: every workgroup of the grid must be able to
     // become resident without another one of this grid exiting first
     if (occ < 1 || a.G > occ * sk_ncu()) return false;
-    hipLaunchKernelGGL((conv3x3_sk_kernel<TR, WT, NF, WN>), dim3(a.G), dim3(256 * WN), lds, s, d, a);
+    hipLaunchKernelGGL((conv3x3_sk_kernel<TR, WT, NF, WN, DBG>), dim3(a.G), dim3(256 * WN), lds, s, d, a);
     return true;
 }
 
 }  // namespace
+
+#ifdef DAWN_ABLATION
+static unsigned long long* g_sk_dbg = nullptr;
+extern "C" int dawn_conv_sk_set_debug(void* p) { g_sk_dbg = static_cast<unsigned long long*>(p); return 0; }
+#endif
 
 extern "C" size_t dawn_conv_sk_workspace_bytes(void) {
     // header (flags + error word) + one 256 x 64 fp32 partial tile per resident workgroup (2 per CU)
@@ -548,12 +584,22 @@ int dawn_conv3x3_sk_try(const dawn_conv_desc& d, long M, int policy, hipStream_t
     if (G > a.U) G = a.U;
     if (G <= 0) return 0;
     a.G = G;
-    a.pair_xor = ((policy & 0x200) || (G % 64)) ? 0 : 2;   // (idx ^ 2 is a permutation of [G/16, G/8) only then)
+    a.pair_xor = ((policy & 0x200) || (G % 64)) ? 0 : 2;
+    a.prio_alt = (policy & 0x40) ? 1 + ((policy >> 16) & 3) : 0;   // (idx ^ 2 is a permutation of [G/16, G/8) only then)
     unsigned char* ws = static_cast<unsigned char*>(d.sk_ws);
     a.flag = reinterpret_cast<unsigned*>(ws);
     a.err = reinterpret_cast<unsigned*>(ws + 4096);
     a.part = reinterpret_cast<float*>(ws + 8192);
+    a.dbg = nullptr;
     bool ok = false;
+#ifdef DAWN_ABLATION
+    if (cls == 0 && g_sk_dbg) {             // s_memtime-instrumented build (tools/conv_sk_phase_timing.py)
+        a.dbg = g_sk_dbg;
+        ok = launch_sk<4, 64, 1, 1, 1>(d, a, s);
+        if (ok && nrows) *nrows = G;
+        return ok ? 1 : 0;
+    }
+#endif
     switch (cls) {
         case 0: ok = launch_sk<4, 64, 1, 1>(d, a, s); break;
         case 1: ok = launch_sk<8, 32, 1, 1>(d, a, s); break;

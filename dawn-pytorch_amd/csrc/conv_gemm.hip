@@ -31,12 +31,15 @@ namespace {
 // MFMA version of that kernel when the caller supplies w_bf3 (6 cross terms; 0x2000: all 9), 0x4000 its second
 // generation (conv3x3_bf16_v2_kernel: +5..20 %, profiles/r1_n_conv_bf16.txt), 0x10/0x20 fp32-kernel perf ablations,
 // (8 << 16) the s_memtime build of the split kernel, 0x400 the persistent stream-K 3x3 kernel (conv3x3_sk.hip) when the caller
-// supplies dawn_conv_desc.sk_ws (0x200: without the half-tile offset between co-resident workgroups; bits 20..23 there: leave
-// n/16 of the resident slots to a concurrent stream).
+// supplies dawn_conv_desc.sk_ws (0x200: without the half-tile offset between co-resident workgroups; 0x40 + bits 16..17: issue-priority
+// alternation between them; bits 20..23 there: leave n/16 of the resident slots to a concurrent stream).  NOT in the shipped
+// default: in isolation it takes 6..16 % off the 128..512-channel levels, inside the benchmark it is 3..5 % slower end to end --
+// the chip is power-limited in these kernels (profiles/r3_conv_power_by_data.txt, r3_mfma_power_ubench.txt), so cycles saved by
+// the schedule come back as a lower clock for everything that follows.
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
 // split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
-constexpr int DAWN_CONV_POLICY_DEFAULT = 0x5C0D;
+constexpr int DAWN_CONV_POLICY_DEFAULT = 0x580D;
 #ifdef DAWN_ABLATION
 constexpr int DAWN_CONV_POLICY_MASK = 0x000FFFFF;
 #else

@@ -554,10 +554,12 @@ struct Eval {
     void forward(const float* x3, float t, float* eps_out) {
         const int dim = c->cfg.dim;
         // scratch of the persistent stream-K 3x3 kernel (partial-tile hand-offs); its flag header must start zeroed
-        sk_bytes = dawn_conv_sk_workspace_bytes();
-        sk_ws = A.alloc(sk_bytes);
-        if (!sk_ws && rc == 0) rc = dawn_set_error_msg(-201, "dawn_ctx: activation workspace too small (dawn_workspace_bytes)");
-        if (sk_ws) LAUNCH(dawn_conv_sk_workspace_init(sk_ws, cur));
+        if (c->conv_policy & 0x400) {           // (opt-in kernel: policy bit 0x400)
+            sk_bytes = dawn_conv_sk_workspace_bytes();
+            sk_ws = A.alloc(sk_bytes);
+            if (!sk_ws && rc == 0) rc = dawn_set_error_msg(-201, "dawn_ctx: activation workspace too small (dawn_workspace_bytes)");
+            if (sk_ws) LAUNCH(dawn_conv_sk_workspace_init(sk_ws, cur));
+        }
         // time_film: sinusoidal -> Linear -> GELU -> Linear -> [SiLU -> Linear] for every block in one GEMV
         float* e0 = falloc(dim);
         float* e1 = falloc(c->time_dim);

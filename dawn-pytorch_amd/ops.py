@@ -44,7 +44,7 @@ class HipOps:
         self.graph_error = None      # set when a HIP-graph capture failed and the sampler fell back to eager
         self.conv_policy = 0         # dawn_conv_desc.policy of every conv_gemm launch (0 = shipped kernel policy)
         self.temporal_flags = 0      # kernel-family selector of the fused temporal layer (0 = automatic; A/B and tests)
-        self.stream_k = True         # 3x3 convs on the persistent stream-K kernel (needs the scratch below)
+        self.stream_k = True         # supply the stream-K scratch when conv_policy selects that kernel (bit 0x400; opt-in)
         self._sk_ws = {}             # device index -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
 
     def sk_workspace(self, like: Tensor) -> Tensor:
@@ -148,7 +148,7 @@ class HipOps:
         d.w_bf3 = _p(w_bf3)
         d.policy = self.conv_policy
         d.ln_eps = ln_eps
-        if self.stream_k and w_bf3 is not None and KH == 3 and KW == 3 and stride == 1 and mode == 0:
+        if self.stream_k and (self.conv_policy & 0x400) and w_bf3 is not None and KH == 3 and KW == 3 and stride == 1 and mode == 0:
             ws = self.sk_workspace(in0)
             d.sk_ws, d.sk_ws_bytes = _p(ws), ws.numel()
         nrows = C.c_int(0)

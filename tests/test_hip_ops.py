@@ -135,7 +135,8 @@ SK_CASES = [
     ("L0_64x64_18units", 9, 64, 64, 64, 0, 64, {"bias": True, "gn": True}, 15),           # 4.5 tiles per workgroup
     ("L0_cat_N128_cut_tiles", 3, 64, 64, 64, 64, 128, {"bias": True}, 14),                # two sources, 2 n-tiles, 1.5 tiles each
     ("L1_32x32_res", 5, 32, 32, 32, 0, 64, {"res": True}, 15),                            # 1.25 units each
-    ("L2_16x16_N192_tr", 7, 16, 16, 128, 0, 192, {"tr": True, "bias": True, "gn": True}, 15),
+    ("L2_16x16_N192_tr", 7, 16, 16, 128, 0, 192, {"tr": True, "bias": True}, 15),
+    ("L2_16x16_N256_gn", 7, 16, 16, 64, 0, 256, {"bias": True, "gn": True}, 15),
     ("L3_8x8_deepK_many_parts", 12, 8, 8, 256, 256, 64, {"bias": True, "gn": True}, 15),  # a tile spans ~10 workgroups
     ("decoder_W128_column_tiles", 2, 16, 128, 48, 0, 64, {"res": True, "gn": True}, 15),
     ("L0_full_grid_2units", 16, 64, 64, 64, 0, 64, {"bias": True, "gn": True}, 0),        # 512 workgroups, every tile cut

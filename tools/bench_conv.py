@@ -27,6 +27,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cases", default=",".join(CASES))
 ap.add_argument("--iters", type=int, default=10)
 ap.add_argument("--variants", default="7")
+ap.add_argument("--data", default="randn", choices=["randn", "zero", "const"], help="operand values (the chip clocks to its power budget: zeros run faster than random data)")
 ap.add_argument("--gn", action="store_true", help="emit GroupNorm partial sums from the conv epilogue (as the ResBlock convs do)")
 a = ap.parse_args()
 ops = HipOps()
@@ -42,6 +43,12 @@ for variant, name in itertools.product([int(v, 0) for v in a.variants.split(",")
     K = k * k * (C0 + C1)
     torch.manual_seed(0)
     w_kn = torch.randn(K, N) * K ** -0.5
+    if a.data != "randn":
+        fill = 0.0 if a.data == "zero" else 0.37
+        x0.fill_(fill)
+        if x1 is not None:
+            x1.fill_(fill)
+        w_kn.fill_(fill)
     w = pack_kn(w_kn).to(dev)
     b = torch.randn(N, device=dev)
     kw = dict(F=F, Hi=H, Wi=W, KH=k, KW=k, stride=st, pad=pad, in1=x1, bias=b)
