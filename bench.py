@@ -101,10 +101,82 @@ def cpu_baseline(h, S, sample_frames, unet_cpu_sd):
                       f"{warm:.1f} s), extrapolated to {S} DDIM steps"}
 
 
+def power_ceiling(ops, device, iters=20000):
+    """Sustained executed TFLOP/s of an MFMA-only bf16 loop on this box under its power budget (dawn_ubench_mfma_bf16): operands =
+    the three split planes of N(0,1) values, from registers and re-read from LDS at the conv kernels' ratio; zeros for contrast."""
+    import ctypes
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(16, 256, 8, generator=g)
+    h1 = x.bfloat16()
+    r1 = x - h1.float()
+    h2 = r1.bfloat16()
+    h3 = (r1 - h2.float()).bfloat16()
+    planes = torch.stack([(h1, h2, h3)[i % 3][i] for i in range(16)]).contiguous().to(device)
+    zeros = torch.zeros_like(planes)
+    scratch = torch.empty(2 * torch.cuda.get_device_properties(device).multi_processor_count * 256, device=device)
+    out = {}
+    v = ctypes.c_float(0.0)
+    for key, mode, src in (("mfma_lds_tflops", 2, planes), ("mfma_regs_tflops", 1, planes), ("mfma_regs_zero_operands_tflops", 1, zeros)):
+        rc = ops.L.dawn_ubench_mfma_bf16(mode, iters, src.data_ptr(), scratch.data_ptr(), ctypes.byref(v), torch.cuda.current_stream().cuda_stream)
+        if rc != 0:
+            raise RuntimeError(f"dawn_ubench_mfma_bf16 failed: {rc}")
+        out[key] = float(v.value)
+    out["what"] = ("executed TFLOP/s of a loop of nothing but v_mfma_f32_32x32x16_bf16 (two waves per SIMD, every SIMD), measured right "
+                   "after the timed region on this GPU: operands = bf16 split planes of N(0,1) values re-read from LDS at the conv "
+                   "kernels' ratio / held in registers / zeros.  The chip clocks to its power budget, so the first figure -- not the "
+                   "nominal 2500 -- is what the split-operand kernels could reach with a perfect schedule and no other work")
+    return out
+
+
+def shard_sim(unet, diff, T, h, device, single_ms, world=8, rank=3, rccl=False):
+    """OUTSIDE the timed region, one GPU: the workload of ONE interior rank of a T-sharded clip (BASELINE configs[3]:
+    8 x 200 frames) -- 200 own frames, 2 x 40 halo frames at every temporal attention (filled locally), GroupNorm statistics on the
+    reduce -> all-reduce -> finalize path, histogram all-reduces of the threshold selection (world-size-1 RCCL communicator when it
+    can be created) -- against the unsharded 200-frame clip timed above.  shard_overhead = compute-side price of the sharded shape
+    (segmentation, halo-row projections, extra small kernels); xGMI link time is not in it (no second GPU here)."""
+    from dawn_pytorch_amd.tshard import SimulatedInteriorShard
+    pg, dist_mod = None, None
+    try:
+        if not rccl:
+            raise RuntimeError("RCCL not requested")
+        import tempfile
+        import torch.distributed as dist_mod
+        if not dist_mod.is_initialized():
+            f = tempfile.NamedTemporaryFile(prefix="dawn_pg_", delete=True)
+            name = f.name
+            f.close()
+            dist_mod.init_process_group("nccl", init_method=f"file://{name}", rank=0, world_size=1, device_id=device)
+            pg = True
+    except Exception:                                         # noqa: BLE001
+        dist_mod = None
+    try:
+        comm = SimulatedInteriorShard(T, world=world, rank=rank, dist=dist_mod)
+        fea, bbox, cond = synthetic_inputs(T, h, device, seed=123, f0=rank * T, Ttotal=world * T)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)          # warm-up (buffers, RCCL)
+        ev[0].record()
+        for i in range(2):
+            out = diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)
+            ev[i + 1].record()
+        torch.cuda.synchronize()
+        assert torch.isfinite(out).all()
+        ms = min(ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]))
+        st = comm.stats()
+    finally:
+        if pg:
+            dist_mod.destroy_process_group()
+    return {"ms_per_clip": ms, "single_gpu_ms_per_clip": single_ms, "shard_overhead": ms / single_ms,
+            "rank": f"{rank} of {world} (interior: a neighbour on both sides)", "frames_per_rank": T,
+            "all_reduces": "world-size-1 RCCL" if dist_mod is not None else "skipped (no communicator)",
+            "halo_exchanges_per_clip": st["halo_exchanges"] // 3, "all_reduces_per_clip": st["all_reduces"] // 3,
+            "what": "one interior rank's compute of a T-sharded clip on one GPU (halos filled locally; link time not included) vs "
+                    "the unsharded clip of the same length"}
+
+
 def max_clip_frames(unet, diff, h, device, world, win=40, probes=(320, 480)):
     """Second half of BASELINE's metric ("max clip length in HBM"): peak allocator bytes of one full DDIM step (UNet
-    evaluation + dynamic threshold + update) at two probe lengths on the long-clip kernel path (> 288 frames: the
-    unfused 64-channel temporal layers), a linear fit of bytes/frame, and the largest T with fixed + T * per_frame
+    evaluation + dynamic threshold + update) at two probe lengths on the long-clip kernel path (> 200 frames: the fused
+    64-channel temporal layers run as 120-query segments on overlapping row windows), a linear fit of bytes/frame, and the largest T with fixed + T * per_frame
     <= 97 % of this GPU's HBM.  T-sharded over N GPUs every rank holds its T/N frames plus 2*win halo frames at the
     attention inputs, so the clip limit grows as N * (per_gpu - 2*win).  (tools/max_clip_length.py additionally
     PROVES a length by running it: profiles/r1_max_clip_length.log, 12,070 frames.)"""
@@ -134,7 +206,8 @@ def max_clip_frames(unet, diff, h, device, world, win=40, probes=(320, 480)):
     return {"per_gpu": per_gpu, "total": per_gpu if world == 1 else world * (per_gpu - 2 * win), "n_gpus": world,
             "bytes_per_frame": per_frame, "fixed_bytes": fixed, "hbm_bytes": total,
             "probes": [{"frames": T, "peak_bytes": p} for T, p in pts],
-            "method": "linear fit of the peak allocator bytes of one DDIM step at the two probe lengths; largest T with "
+            "method": "linear fit of the peak allocator bytes of one DDIM step at the two probe lengths (long-clip kernel path: segmented "
+                      "fused temporal layers); largest T with "
                       "fixed + T*bytes_per_frame <= 0.97*HBM; T-sharded total = n_gpus*(per_gpu - 2*win halo frames)"}
 
 
@@ -182,6 +255,11 @@ def main():
     ap.add_argument("--no-max-clip", action="store_true", help="skip the max-clip-length probes")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) flow-decode report")
+    ap.add_argument("--shard-sim-rccl", action="store_true",
+                    help="shard_sim: run its all-reduces on a world-size-1 RCCL communicator (RCCL prints a banner on stdout at "
+                         "init, so this is opt-in; default: the all-reduces are skipped)")
+    ap.add_argument("--no-shard-sim", action="store_true",
+                    help="skip the (untimed) single-GPU measurement of one interior T-shard rank's workload")
     ap.add_argument("--event-every", type=int, default=5,
                     help="record the per-launch HIP events of the roofline measurement on every n-th DDIM step of the timed "
                          "region (every step costs ~2.5 %% of the run: two marker packets per conv launch)")
@@ -250,11 +328,15 @@ def main():
         ops.prof = []
         ops.prof_every = max(1, args.event_every)
     barrier()
+    clip_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    clip_ev[0].record()
+    for i in range(args.steps):
         out = one_clip()
+        clip_ev[i + 1].record()             # (an event, not a synchronisation: the clips stay back to back in the queue)
     barrier()
     dt = time.perf_counter() - t0
+    clip_ms = sorted(clip_ev[i].elapsed_time(clip_ev[i + 1]) for i in range(args.steps))
     prof, ops.prof = getattr(ops, "prof", None), None
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
@@ -275,7 +357,10 @@ def main():
         "metric": "generated frames/sec at 256x256, 50 DDIM steps" if (args.res, S) == (256, 50)
         else f"generated frames/sec at {args.res}x{args.res}, {S} DDIM steps",
         "value": value, "unit": "frames/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3,
+        "ms_per_step_spread": {"min": clip_ms[0], "median": clip_ms[len(clip_ms) // 2], "max": clip_ms[-1],
+                               "what": "per-clip GPU time of this rank from HIP events between the timed clips"},
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic (random-init DAWN weights, N(0,1) fea/bbox/cond, Philox noise)",
         "config": {"workload": f"{args.res}x{args.res}, {T}-frame clip per GPU, {S} DDIM steps, window 40, eta 1.0, "
                                f"cond_scale 1.0" + {(256, 200, 50): " (BASELINE configs[2])", (128, 400, 50): " (BASELINE configs[1])",
@@ -329,6 +414,7 @@ def main():
                           "frac_executed": 6.0 * alg / PEAK_BF16_MFMA_TFLOPS,
                           "frac_algorithmic": alg / PEAK_BF16_MFMA_TFLOPS,
                           "frac_algorithmic_vs_fp32_mfma_peak": alg / PEAK_FP32_MFMA_TFLOPS,
+                          "frac_of_split_ceiling": alg / (PEAK_BF16_MFMA_TFLOPS / 6.0),
                           "executed_flops_per_algorithmic_flop": 6,
                           "note": "achieved / frac_executed = bf16 MFMA flops actually issued (6 exact cross terms per fp32 "
                                   "product) over the bf16 dense peak = matrix-pipe utilisation; frac_algorithmic = 2*M*N*K / "
@@ -356,6 +442,19 @@ def main():
         result["roofline"] = roofs[order[0]][0]                     # the dominant kernel
         if len(order) > 1:
             result["roofline_other"] = [roofs[k][0] for k in order[1:]]
+        # the split kernels are POWER-limited (same instruction stream, zero-filled tensors: 28-38 % faster; profiles/
+        # r3_conv_power_by_data.txt): price the dominant kernel against what an MFMA-only loop sustains on THIS box right now
+        try:
+            pc = power_ceiling(ops, device)
+            result["roofline"]["power_ceiling"] = pc
+            for r in [result["roofline"]] + result.get("roofline_other", []):
+                if r.get("frac_is") == "frac_executed":
+                    r["frac_of_power_ceiling"] = r["achieved"] / pc["mfma_lds_tflops"]
+        except Exception as e:                                # noqa: BLE001  (a report, never the metric)
+            result["roofline"]["power_ceiling"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    elif diff.use_ctx:
+        result["roofline"] = {"skipped": "--host ctx: per-launch HIP events are recorded by the Python host only (run without --host ctx, "
+                                          "or read dawn_ctx_profile_read under DAWN_OPT_PROFILE)"}
     alg = algorithmic_flops_per_forward(Ttotal if mode == "tshard" else T, h) * S * args.steps * \
         (n_gpus if mode == "replica" else 1)
     result["whole_path"] = {"algorithmic_tflop": alg / 1e12, "achieved_tflops": alg / dt / 1e12,
@@ -388,6 +487,11 @@ def main():
         result["flow_decode"] = {"what": "LFG forward_with_flow for the whole clip (FlowDecoder.decode_clip), outside the timed region",
                                  "ms_per_clip": td * 1e3, "frames_per_s": T / td, "algorithmic_tflops": dfl / td / 1e12,
                                  "sampler_plus_decode_frames_per_s": T / (dt / args.steps + td)}
+    if n_gpus == 1 and mode == "single" and not args.no_shard_sim and not diff.use_ctx:
+        try:
+            result["shard_sim"] = shard_sim(unet, diff, T, h, device, clip_ms[len(clip_ms) // 2], rccl=args.shard_sim_rccl)
+        except Exception as e:                                # noqa: BLE001  (a report, never the metric)
+            result["shard_sim"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     if not args.no_max_clip:
         try:
             result["max_clip_frames"] = max_clip_frames(unet, diff, h, device, n_gpus)
@@ -398,9 +502,10 @@ def main():
     if not args.no_cpu_baseline and n_gpus == 1:
         sd = {"denoise_fn." + k: v.detach().cpu() for k, v in unet.state_dict().items()}
         result["cpu_baseline"] = cpu_baseline(h, S, args.cpu_sample_frames, sd)
-    print(json.dumps(result))
     if dist is not None:
         dist.destroy_process_group()
+    sys.stdout.flush()
+    print(json.dumps(result), flush=True)
 
 
 if __name__ == "__main__":

@@ -46,7 +46,6 @@ constexpr int DAWN_CONV_POLICY_MASK = 0x000FFFFF;
 constexpr int DAWN_CONV_POLICY_MASK = 0x00F3FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
-static thread_local int g_last_nwg = 0;   // gridDim.x of the calling thread's last launch (= rows of gn_part it writes)
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
 
 struct RowInfo {
@@ -806,7 +805,7 @@ bool try_launch_halo(const dawn_conv_desc& d, long M, hipStream_t s) {
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_kernel<BN, WN>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
-    g_last_nwg = nwg;
+    if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     hipLaunchKernelGGL((conv3x3_halo_kernel<BN, WN>), dim3(nwg), dim3(256), lds, s, d, remap, TR, nf, P16);
     return true;
 }
@@ -1441,7 +1440,7 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
         hipLaunchKernelGGL((conv3x3_bf16_v2_kernel<WN, NTV, ABLV>), dim3(nwg), dim3(256 * WN), lds, s, d, remap, TR, nf, \
                            P16, WT, stagger);                                                                         \
     } while (0)
-    g_last_nwg = nwg;
+    if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     if (nine) LAUNCH_V2(9, 0);
 #ifdef DAWN_ABLATION
     else if (timing) LAUNCH_V2(6, 8);
@@ -2104,7 +2103,7 @@ static void launch_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int ncu = dawn_ncu();
     const int per = (int)((npanels + ncu - 1) / ncu);
     const int nwg = (int)((npanels + per - 1) / per);
-    g_last_nwg = nwg;
+    if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
 #define LAUNCH_RA(NCHV, KSV)                                                                                              \
     do {                                                                                                                  \
         const size_t lds = (size_t)2 * KSV * 6 * 64 * 16 + 8 * 32 * 36 * 4;                                               \
@@ -2145,7 +2144,7 @@ bool try_launch_gemm1x1_rowreg(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int ncu = dawn_ncu();
     const int per = (int)((nunits + ncu - 1) / ncu);
     const int nwg = (int)((nunits + per - 1) / per);
-    g_last_nwg = nwg;
+    if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     const size_t lds = (size_t)2 * (K / 16) * 6 * 64 * 16 + 8 * 32 * 36 * 4;      // two weight chunks + the waves' staging tiles
     if (K == 128) {
         (void)hipFuncSetAttribute((const void*)gemm1x1_rowreg_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -2162,7 +2161,7 @@ void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
     constexpr int BN = 64 * WN;
     const size_t lds = (size_t)2 * 2 * 6 * (256 * 16 + 128) + (size_t)2 * 2 * 6 * BN * 16;
     const int nwg = (int)(M / 256) * (d.N / BN);
-    g_last_nwg = nwg;
+    if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     if (policy_of(d) & 0x2000) {
         (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<9, WN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         hipLaunchKernelGGL((gemm1x1_bf16_kernel<9, WN>), dim3(nwg), dim3(256 * WN), lds, s, d, M);
@@ -2175,7 +2174,7 @@ void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
 void launch_gemm1x1_bf16_small(const dawn_conv_desc& d, long M, hipStream_t s) {
     const size_t lds = (size_t)2 * 2 * 6 * (128 * 16 + 128) + (size_t)2 * 2 * 6 * 64 * 16;      // 76.8 KB: two per CU
     const int nwg = (int)(M / 128) * (d.N / 64);
-    g_last_nwg = nwg;
+    if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<6, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     hipLaunchKernelGGL((gemm1x1_bf16_kernel<6, 1, 1>), dim3(nwg), dim3(256), lds, s, d, M);
 }
@@ -2202,11 +2201,18 @@ int gemm1x1_split_plan(long M, int N, int C0, int C1) {
     return plan;
 }
 
-bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
+// operand layout every split 1x1 kernel (tiled, row-stationary, row-accumulator) relies on: 16-byte aligned row strides of the
+// sources, the output and the epilogue tensors (f32x4 loads / stores), offsets inside 31 bits
+static bool gemm1x1_split_layout_ok(const dawn_conv_desc& d) {
     if ((d.C1 != 0) != (d.in1 != nullptr) || d.gn_part) return false;
     if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) || (d.tr && (d.ld_tr & 3)) ||
         (long)d.ld0 * 256 * 4 >= (1L << 31) || (long)d.ld1 * 256 * 4 >= (1L << 31))
         return false;
+    return true;
+}
+
+bool try_launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
+    if (!gemm1x1_split_layout_ok(d)) return false;
     const int plan = gemm1x1_split_plan(M, d.N, d.C0, d.C1);
     // short K: rows stationary in registers (policy bit 0x20000, A/B only: the tiled kernels)
     if (!(policy_of(d) & 0x20000) && try_launch_gemm1x1_rowreg(d, M, s)) return true;
@@ -2238,7 +2244,7 @@ bool try_launch_halo_bf16(const dawn_conv_desc& d, long M, hipStream_t s, bool n
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * dawn_cdiv(d.N, BN);
     const int remap = ((policy_of(d) & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
-    g_last_nwg = nwg;
+    if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     if (nine) {
         (void)hipFuncSetAttribute((const void*)conv3x3_halo_bf16_kernel<BN, WN, 9>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
@@ -2257,7 +2263,7 @@ void launch_pro(const dawn_conv_desc& d, long M, hipStream_t s) {
     const int z = d.mode == 1 ? 4 : 1;
     const int nwg = nMt * nNt;
     const int remap = ((policy_of(d) & 4) && nwg >= 64 && d.KH * d.KW > 1 && d.Hi * d.Wi >= 1024) ? 1 : 0;
-    g_last_nwg = nwg;
+    if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, PRO>), dim3(nwg, 1, z), dim3(256), 0, s, d, remap);
 }
 
@@ -2267,7 +2273,7 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
     if (policy_of(d) & 0x30) {   // perf ablations only (wrong results): 0x10 no re-staging, 0x20 also no barrier
         const int nMt = dawn_cdiv(M, BM), nNt = dawn_cdiv(d.N, BN);
         const int nwg = nMt * nNt;
-        g_last_nwg = nwg;
+        if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
         if (policy_of(d) & 0x20)
             hipLaunchKernelGGL((conv_gemm_kernel<BM, BN, BK, WM, WN, 0, 2>), dim3(nwg, 1, 1), dim3(256), 0, s, d, 0);
         else
@@ -2284,12 +2290,12 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
         if (BN == 64 && M >= 65536 && ((policy_of(d) & 0x200) || (d.KH * d.KW > 1 && d.C0 + d.C1 <= 64 && !(policy_of(d) & 0x400)))) {
             // 256 x 64 tile (weights amortised over 2x the rows): +7 % on the K=576 3x3 convs, not on 1x1 / K>=1152
             const int nwg2 = dawn_cdiv(M, 256);
-            g_last_nwg = nwg2;
+            if (d.gn_rows) *d.gn_rows = nwg2;   // rows of gn_part this launch writes
             hipLaunchKernelGGL((conv_gemm_glds_kernel<64, 2, 16, 1>), dim3(nwg2, 1, d.mode == 1 ? 4 : 1), dim3(256), 0, s, d,
                                remap);
             return;
         }
-        g_last_nwg = nwg;
+        if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
         if (((policy_of(d) & 0x80) || deep) && d.C0 % 32 == 0 && d.C1 % 32 == 0)
             hipLaunchKernelGGL((conv_gemm_glds_kernel<BN, 2, 32>), grid, dim3(256), 0, s, d, remap);
         else if (policy_of(d) & 0x100)
@@ -2313,9 +2319,10 @@ extern "C" int dawn_conv_set_debug(void* p) {
 }
 #endif
 
-/* 1 when a prologue-free 1x1 projection (M rows, N columns, C0 + C1 input channels, w_bf3 supplied, shipped policy) runs on
- * the split-operand GEMM, whose loader can apply LayerNorm row statistics; the host then skips materialising the
- * normalised rows (see unet_forward._ln_gemm / dawn_ctx.hip). */
+/* 1 when a 1x1 projection (M rows, N columns, C0 + C1 input channels, w_bf3 supplied, shipped policy, 16-byte aligned row strides)
+ * runs on a row-stationary / row-accumulator split GEMM, which can compute the LayerNorm of its input rows itself
+ * (dawn_conv_desc.ln_eps): the host then launches no statistics pass (see unet_forward._ln_gemm / dawn_ctx.hip).  dawn_conv_gemm
+ * re-checks the layout and policy conditions per call and answers -14 when they fail. */
 extern "C" int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1) {
     return gemm1x1_rowreg_ok(M, N, C0, C1) || gemm1x1_rowacc_ok(M, N, C0, C1);
 }
@@ -2346,9 +2353,10 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (d.ln_eps > 0.f) {                     // LayerNorm inside the GEMM: only the row-stationary kernel holds whole rows
         if (!(d.w_bf3 && d.mode == 0 && d.KH == 1 && d.KW == 1 && d.stride == 1 && d.pad == 0 && !d.ch_a && !d.pro_act &&
-              !d.pro_add && !d.row_mean && !d.row_rstd && !d.gn_part && (d.C1 != 0) == (d.in1 != nullptr) &&
-              (try_launch_gemm1x1_rowreg(d, M, s) || try_launch_gemm1x1_rowacc(d, M, s))))
-            return dawn_set_error_msg(-14, "dawn_conv_gemm: ln_eps needs a split 1x1 projection with dawn_gemm1x1_ln_inline_ok");
+              !d.pro_add && !d.row_mean && !d.row_rstd && gemm1x1_split_layout_ok(d) && (policy_of(d) & 0x1000) &&
+              !(policy_of(d) & 0x20000) && (try_launch_gemm1x1_rowreg(d, M, s) || try_launch_gemm1x1_rowacc(d, M, s))))
+            return dawn_set_error_msg(-14, "dawn_conv_gemm: ln_eps needs a split 1x1 projection with dawn_gemm1x1_ln_inline_ok, 16-byte aligned "
+                                           "row strides and the split-kernel policy bits (0x1000 set, 0x20000 clear)");
         DAWN_LAUNCH_CHECK();
         return 0;
     }
@@ -2389,7 +2397,6 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         }
         if (!ok) ok = d.N <= 64 ? try_launch_halo_bf16<64, 1>(d, M, s, nine) : try_launch_halo_bf16<128, 2>(d, M, s, nine);
         if (ok) {
-            if (d.gn_rows) *d.gn_rows = g_last_nwg;
             DAWN_LAUNCH_CHECK();
             return 0;
         }
@@ -2398,7 +2405,6 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool ok = d.N <= 64 ? try_launch_halo<64, 1>(d, M, s) : try_launch_halo<128, 2>(d, M, s);
         if (ok) {
-            if (d.gn_rows) *d.gn_rows = g_last_nwg;
             DAWN_LAUNCH_CHECK();
             return 0;
         }
@@ -2411,7 +2417,6 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         if (k32) launch<128, 128, 32, 2, 2>(d, M, s);
         else launch<128, 128, 16, 2, 2>(d, M, s);
     }
-    if (d.gn_rows) *d.gn_rows = g_last_nwg;
     DAWN_LAUNCH_CHECK();
     return 0;
 }

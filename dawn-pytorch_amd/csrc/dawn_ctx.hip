@@ -351,7 +351,8 @@ struct Eval {
         T2 o = t2(x.rows, N);
         ConvArgs a;
         a.w = w; a.w_bf3 = w_bf3; a.N = N; a.Fr = Fr; a.Hi = Hi; a.Wi = Wi; a.out = o.p; a.ld_out = N;
-        if (w_bf3 && dawn_gemm1x1_ln_inline_ok(x.rows, N, x.C, C1)) {
+        const int pol = c->conv_policy;     // (A/B policies without the row-stationary split kernels take the statistics pass)
+        if (w_bf3 && !(pol && (!(pol & 0x1000) || (pol & 0x20000))) && dawn_gemm1x1_ln_inline_ok(x.rows, N, x.C, C1)) {
             a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.in1 = x2 ? x2->p : nullptr; a.C1 = C1; a.ld1 = C1;
             a.ln_eps = 1e-5f;
             conv(a);
@@ -816,12 +817,21 @@ extern "C" int dawn_clip_prepare(dawn_ctx* c, int F, int h, int w, const float* 
 
 extern "C" size_t dawn_workspace_bytes(dawn_ctx* c, int F, int h, int w) {
     if (!c || F <= 0 || h <= 0 || w <= 0) return 0;
-    c->arena.reset(nullptr, 0, true);
-    {
-        Eval ev(c, nullptr, F, h, w, nullptr);
-        ev.forward((const float*)4096, 0.f, (float*)4096);
+    // sized for BOTH schedules (two-stream: frees inside a side-stream region are deferred to the join; one-stream: immediate --
+    // with a first-fit arena neither high-water mark bounds the other), so that toggling DAWN_OPT_OVERLAP after sizing cannot make a
+    // later call run out of workspace
+    const int overlap_saved = c->overlap;
+    size_t fwd = 0;
+    for (int ov = 0; ov < 2; ++ov) {
+        c->overlap = ov;
+        c->arena.reset(nullptr, 0, true);
+        {
+            Eval ev(c, nullptr, F, h, w, nullptr);
+            ev.forward((const float*)4096, 0.f, (float*)4096);
+        }
+        if (c->arena.high > fwd) fwd = c->arena.high;
     }
-    size_t fwd = c->arena.high;
+    c->overlap = overlap_saved;
     c->arena.reset(nullptr, 0, false);
     // sampler state on top of one evaluation: x, eps, x0, noise (3*F*h*w floats each) + histograms / scalars
     const size_t lat = al256((size_t)3 * F * h * w * 4);

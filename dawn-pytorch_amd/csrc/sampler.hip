@@ -189,6 +189,15 @@ extern "C" int dawn_ddim_x0(const float* x, const float* eps, float recip, float
     DAWN_LAUNCH_CHECK();
     return 0;
 }
+/* scratch of one threshold selection, laid out [hist1 2048 | hist2 1024 | hist3 1024 | state 4 | hmin 4] (4104 words): zero the
+ * histograms / state and set hmin to INT_MAX.  Two runtime fills on the stream -- the host keeps ONE buffer per device instead of
+ * allocating + zero-filling five tensors per DDIM step. */
+extern "C" int dawn_select_ws_reset(unsigned* ws, void* stream) {
+    hipError_t e = hipMemsetAsync(ws, 0, (size_t)(2048 + 1024 + 1024 + 4) * 4, (hipStream_t)stream);
+    if (e == hipSuccess) e = hipMemsetD32Async((hipDeviceptr_t)(ws + 2048 + 1024 + 1024 + 4), 0x7fffffff, 4, (hipStream_t)stream);
+    if (e != hipSuccess) return dawn_set_error(e, __FILE__, __LINE__);
+    return 0;
+}
 extern "C" int dawn_select_scan(const unsigned* hist, int nbins, unsigned long long rank, unsigned* state, int pass,
                                 void* stream) {
     if (nbins % 256 != 0) return dawn_set_error_msg(-70, "dawn_select_scan: nbins must be a multiple of 256");

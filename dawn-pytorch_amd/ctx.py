@@ -126,6 +126,8 @@ class CtxEvaluator:
             check(L.dawn_ctx_create(C.byref(cfg), arr, len(self.weights), C.byref(h)), "dawn_ctx_create")
         self.h = h
         self._ws: Optional[Tensor] = None
+        self._need = {}              # (F, h, w, conv policy) -> dawn_workspace_bytes (a dry evaluation on the host: cached)
+        self._policy = 0
 
     def __del__(self):
         h, self.h = getattr(self, "h", None), None
@@ -134,13 +136,20 @@ class CtxEvaluator:
 
     def set_option(self, option: int, value: int) -> None:
         check(self.L.dawn_ctx_set_option(self.h, option, int(value)), "dawn_ctx_set_option")
+        if option == OPT_CONV_POLICY:
+            self._policy = int(value)
+        if option != OPT_PROFILE:
+            self._need.clear()              # kernel-family options change the launch sequence, hence the requirement
 
     @staticmethod
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
     def workspace(self, F: int, h: int, w: int) -> Tensor:
-        need = int(self.L.dawn_workspace_bytes(self.h, F, h, w))
+        key = (F, h, w, self._policy)
+        need = self._need.get(key)
+        if need is None:                    # sized in C for the two-stream (overlap) case, the larger of the two
+            need = self._need[key] = int(self.L.dawn_workspace_bytes(self.h, F, h, w))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -149,7 +158,9 @@ class CtxEvaluator:
         """fea272 (fea_ch, h, w), cond (F, cond_dim) -> the per-clip table memory (a dict holding the buffer + shape)."""
         Cf, h, w = fea272.shape
         F = cond.shape[0]
-        assert fea272.is_cuda and fea272.is_contiguous() and cond.is_cuda and cond.stride(1) == 1
+        if not (fea272.is_cuda and fea272.is_contiguous() and cond.is_cuda and cond.stride(1) == 1 and fea272.dtype == torch.float32
+                and cond.dtype == torch.float32):
+            raise _lib.DawnHipError("prepare_clip: fea272 must be a contiguous fp32 GPU tensor, cond an fp32 GPU tensor with unit column stride")
         mem = torch.empty(int(self.L.dawn_clip_bytes(self.h, F, h, w)), dtype=torch.uint8, device=self.device)
         ws = self.workspace(F, h, w)
         check(self.L.dawn_clip_prepare(self.h, F, h, w, fea272.data_ptr(), cond.data_ptr(), cond.stride(0),
@@ -159,7 +170,8 @@ class CtxEvaluator:
 
     def forward(self, clip: dict, x3: Tensor, t: float) -> Tensor:
         F, h, w = clip["F"], clip["h"], clip["w"]
-        assert x3.is_cuda and x3.is_contiguous() and x3.shape == (3, F, h, w) and x3.dtype == torch.float32
+        if not (x3.is_cuda and x3.is_contiguous() and tuple(x3.shape) == (3, F, h, w) and x3.dtype == torch.float32):
+            raise _lib.DawnHipError(f"forward: x3 must be a contiguous fp32 GPU tensor of shape (3, {F}, {h}, {w})")
         out = torch.empty_like(x3)
         ws = self.workspace(F, h, w)
         check(self.L.dawn_unet_forward(self.h, F, h, w, clip["mem"].data_ptr(), x3.data_ptr(), float(t), out.data_ptr(),
@@ -179,7 +191,8 @@ class CtxEvaluator:
         if noises is not None:
             nz = (C.c_void_p * S)()
             for i, t in enumerate(noises):
-                assert t is None or (t.is_cuda and t.is_contiguous() and t.numel() == 3 * F * h * w)
+                if t is not None and not (t.is_cuda and t.is_contiguous() and t.numel() == 3 * F * h * w and t.dtype == torch.float32):
+                    raise _lib.DawnHipError(f"sample: noises[{i}] must be a contiguous fp32 GPU tensor of {3 * F * h * w} elements")
                 nz[i] = None if t is None else t.data_ptr()
         x_init = x_init.contiguous().float()
         out = torch.empty_like(x_init)

@@ -98,9 +98,12 @@ class GaussianDiffusion(nn.Module):
                 nz = None
                 if noises is not None:
                     nz = [noises[i][b].contiguous() if st["t_next"] > 0 else None for i, st in enumerate(steps)]
-                elif seed is None:
-                    nz = [torch.randn(3, T, h, w, device=device) if st["t_next"] > 0 else None for st in steps]   # MT:1201
-                outs.append(ev.sample(clip, x0, steps, seed=(seed or 0) + b, noises=nz))
+                run_seed = (seed + b) if seed is not None else None
+                if nz is None and run_seed is None:
+                    # unseeded (MT:1201 draws from the global generator): ONE draw from it seeds the evaluator's counter-based
+                    # generator -- S x 3 x T x h x w floats of pre-drawn noise would be GBs for the long clips the path supports
+                    run_seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                outs.append(ev.sample(clip, x0, steps, seed=run_seed or 0, noises=nz))
             self.last_trace = None
             return torch.stack(outs, 0)
         for b in range(B):

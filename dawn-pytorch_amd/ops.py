@@ -46,6 +46,7 @@ class HipOps:
         self.temporal_flags = 0      # kernel-family selector of the fused temporal layer (0 = automatic; A/B and tests)
         self.stream_k = True         # supply the stream-K scratch when conv_policy selects that kernel (bit 0x400; opt-in)
         self._sk_ws = {}             # device index -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
+        self._sel_ws = {}            # device index -> scratch of the threshold selection (histograms, state)
 
     def sk_workspace(self, like: Tensor) -> Tensor:
         """Scratch of the persistent stream-K 3x3 kernel (dawn_conv_desc.sk_ws): one per device, flag header zeroed once.
@@ -73,6 +74,7 @@ class HipOps:
         o.temporal_flags = self.temporal_flags
         o.stream_k = self.stream_k
         o._sk_ws = self._sk_ws
+        o._sel_ws = self._sel_ws
         return o
 
     # ------------------------------------------------------------------ helpers
@@ -190,6 +192,9 @@ class HipOps:
     def ln_inline_ok(self, rows: int, N: int, C0: int, C1: int = 0) -> bool:
         """May the projection compute the LayerNorm of its input rows itself (conv_gemm(ln_eps=...): the row-stationary
         split GEMM holds whole rows in registers), so that no statistics pass reads them first?"""
+        pol = self.conv_policy          # 0 = shipped policy; A/B policies without the split kernels (0x1000 clear) or with the
+        if pol and (not (pol & 0x1000) or (pol & 0x20000)):          # row-stationary ones disabled (0x20000) take the statistics pass
+            return False
         return bool(self.L.dawn_gemm1x1_ln_inline_ok(rows, N, C0, C1))
 
     def split_gemm_ok(self, rows: int, N: int, C0: int, C1: int = 0) -> bool:
@@ -393,12 +398,14 @@ class HipOps:
         return out
 
     def sla_layer_c64(self, x: Tensor, F: int, HW: int, wqkv: Tensor, wout: Tensor, bias: Tensor,
-                      eps: float = 1e-5, wqkv_bf3: Optional[Tensor] = None) -> Tensor:
+                      eps: float = 1e-5, wqkv_bf3: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
         """out = x + to_out(linear_attention(LayerNorm(x))) for 64-channel levels (two kernels, no qkv tensor)."""
         assert x.is_contiguous() and x.shape == (F * HW, 64)
         self._require(x, wqkv, wout, bias)
         ws = self.empty(self.L.dawn_sla_ws_floats(F, HW, int(wqkv_bf3 is not None)), like=x)
-        out = self.empty(F * HW, 64, like=x)
+        if out is None:
+            out = self.empty(F * HW, 64, like=x)
+        assert out.is_contiguous() and out.shape == (F * HW, 64)
         check(self.L.dawn_sla_layer_c64(_p(x), F, HW, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(bias), eps, _p(ws), _p(out),
                                         self._stream()), "dawn_sla_layer_c64")
         return out
@@ -449,7 +456,13 @@ class HipOps:
         n = x.numel()
         assert x.is_contiguous() and eps.is_contiguous()
         x0 = torch.empty_like(x)
-        hist = torch.zeros(2048, device=x.device, dtype=torch.int32)
+        # selection scratch [hist1 2048 | hist2 1024 | hist3 1024 | state 4 | hmin 4]: ONE buffer per device, reset by two
+        # stream-ordered fills per step (no allocation, no torch fill kernels inside the DDIM loop)
+        ws = self._sel_ws.get(x.device.index)
+        if ws is None:
+            ws = self._sel_ws[x.device.index] = torch.empty(2048 + 1024 + 1024 + 8, device=x.device, dtype=torch.int32)
+        check(self.L.dawn_select_ws_reset(_p(ws), self._stream()), "dawn_select_ws_reset")
+        hist = ws[:2048]
         check(self.L.dawn_ddim_x0(_p(x), _p(eps), recip, recipm1, n, _p(x0), _p(hist), self._stream()), "dawn_ddim_x0")
         return x0, hist
 
@@ -475,17 +488,21 @@ class HipOps:
         lo, weight = self.quantile_rank(n_total, q)
         s = self._stream()
         n = x0.numel()
-        state = torch.zeros(4, device=x0.device, dtype=torch.int32)
+        ws = self._sel_ws.get(x0.device.index)
+        if ws is None or hist1.data_ptr() != ws.data_ptr():          # histogram from elsewhere (tests): private scratch
+            ws = torch.empty(2048 + 1024 + 1024 + 8, device=x0.device, dtype=torch.int32)
+            check(self.L.dawn_select_ws_reset(_p(ws), s), "dawn_select_ws_reset")
+        state = ws[4096:4100]
         if self.comm is not None:
             self.comm.all_reduce_sum(hist1)
         check(self.L.dawn_select_scan(_p(hist1), 2048, lo, _p(state), 1, s), "dawn_select_scan")
         for p in (2, 3):
-            h = torch.zeros(1024, device=x0.device, dtype=torch.int32)
+            h = ws[2048 + (p - 2) * 1024:2048 + (p - 1) * 1024]
             check(self.L.dawn_select_hist(_p(x0), n, _p(state), p, _p(h), s), "dawn_select_hist")
             if self.comm is not None:
                 self.comm.all_reduce_sum(h)
             check(self.L.dawn_select_scan(_p(h), 1024, 0, _p(state), p, s), "dawn_select_scan")
-        hmin = torch.full((4,), 0x7fffffff, device=x0.device, dtype=torch.int32)
+        hmin = ws[4100:4104]
         check(self.L.dawn_select_hist(_p(x0), n, _p(state), 4, _p(hmin), s), "dawn_select_hist")
         if self.comm is not None:
             self.comm.all_reduce_min(hmin)

@@ -83,8 +83,23 @@ class TShardComm:
             b = self._bufs[key] = torch.empty(rows, C, device=like.device, dtype=like.dtype)
         return b
 
+    def own_buffer(self, F: int, HW: int, C: int, win: int, like: Tensor) -> Tensor:
+        """The cached extended buffer [lower halo | own | upper halo] for an (F*HW, C) layer input."""
+        lo_g, hi_g = max(0, self.f0 - win), min(self.Ttotal, self.f0 + F + win)
+        return self._buffer((hi_g - lo_g) * HW, C, like)
+
+    def own_view(self, F: int, HW: int, C: int, win: int, like: Tensor) -> Tensor:
+        """The own-rows slice of that buffer: a PRODUCER that writes the temporal layer's input straight into it (out=...)
+        saves halo_begin's copy of the own rows (210 MB per level-0 layer at 256 x 256).  Valid until the next exchange of the
+        same shape (the buffer is cached per shape), i.e. for a tensor whose only consumer is that temporal layer."""
+        hl = self.f0 - max(0, self.f0 - win)
+        return self.own_buffer(F, HW, C, win, like)[hl * HW:(hl + F) * HW]
+
     def halo_begin(self, x: Tensor, HW: int, win: int) -> HaloExchange:
         """x (F*HW, C) own frames.  Copies them into the middle of the (cached) extended buffer and posts the point-to-point
+        sends / receives.  NOTE the returned buffer is CACHED per (rows, C): it stays valid only until the next exchange of the
+        same shape on this communicator (the three 64-channel level-0 layers share one); callers consume it before the next
+        exchange (stream order).  `release_buffers()` drops the cache between clips.
         sends / receives of the halo frames: the lower halo = global frames [f0 - win, f0), the upper = [f0 + F, f0 + F +
         win), clipped to the clip, each piece from the rank that owns it."""
         F = x.shape[0] // HW
@@ -93,7 +108,8 @@ class TShardComm:
         lo_g, hi_g = max(0, self.f0 - win), min(self.Ttotal, self.f0 + F + win)     # global frame range of the buffer
         hl, hh = self.f0 - lo_g, hi_g - (self.f0 + F)
         xe = self._buffer((hl + F + hh) * HW, C, x)
-        xe[hl * HW:(hl + F) * HW].copy_(x)
+        if x.data_ptr() != xe[hl * HW:].data_ptr():          # (already in place when the producer wrote into own_view())
+            xe[hl * HW:(hl + F) * HW].copy_(x)
         d = self.dist
         ops = []
         for r in range(self.world):
@@ -114,13 +130,63 @@ class TShardComm:
         self.n_halo += 1
         return HaloExchange(xe, hl, hh, F, works)
 
+    def release_buffers(self) -> None:
+        """Drop the cached extended buffers (they pin (Fext*HW, C) per level for the lifetime of the communicator)."""
+        self._bufs.clear()
+
     def halo_end(self, hx: HaloExchange) -> None:
         for w in hx.works:
             w.wait()          # NCCL/RCCL: the current stream waits for the transfer; gloo: the host does
         hx.works = []
 
     def halo_exchange(self, x: Tensor, HW: int, win: int) -> Tuple[Tensor, int]:
-        """Blocking form: (xe, first own frame index in xe)."""
+        """Blocking form: (xe, first own frame index in xe).  xe is a private copy (safe to keep), unlike halo_begin's."""
         hx = self.halo_begin(x, HW, win)
         self.halo_end(hx)
-        return hx.xe, hx.hl
+        return hx.xe.clone(), hx.hl
+
+
+class SimulatedInteriorShard(TShardComm):
+    """ONE interior rank's workload of a T-sharded clip, on one GPU (bench.py `shard_sim`): the rank owns frames
+    [f0, f0 + F) of a clip of Ttotal = world * F frames with a neighbour on each side, so every temporal attention runs on
+    [lower halo | own | upper halo] rows, the GroupNorm statistics take the separate reduce -> all-reduce -> finalize path and the
+    threshold selection the histogram all-reduces.  The halo rows are FILLED LOCALLY (copies of this rank's own edge frames: the
+    values are irrelevant to the cost, the bytes moved on the device are not the link's) and the all-reduces run on a
+    world-size-1 communicator when `dist` is given (their launch + latency is real, their payload trivial) or are skipped.
+    What it measures: the compute-side price of the sharded shape -- segmentation, halo-row projections, own-row placement,
+    extra small kernels -- against the unsharded clip of the same F frames.  Link time is NOT in it."""
+
+    def __init__(self, F: int, world: int = 8, rank: int = 3, dist=None):
+        super().__init__(dist, rank, world, world * F, rank * F, F)
+        self.simulated = True
+
+    def all_reduce_sum(self, t: Tensor) -> None:
+        self.n_allreduce += 1
+        self.allreduce_bytes += t.numel() * t.element_size()
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+
+    def all_reduce_min(self, t: Tensor) -> None:
+        self.n_allreduce += 1
+        self.allreduce_bytes += t.numel() * t.element_size()
+        if self.dist is not None:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+
+    def halo_begin(self, x: Tensor, HW: int, win: int) -> HaloExchange:
+        F = x.shape[0] // HW
+        C = x.shape[1]
+        lo_g, hi_g = max(0, self.f0 - win), min(self.Ttotal, self.f0 + F + win)
+        hl, hh = self.f0 - lo_g, hi_g - (self.f0 + F)
+        xe = self.own_buffer(F, HW, C, win, x)
+        if x.data_ptr() != xe[hl * HW:].data_ptr():
+            xe[hl * HW:(hl + F) * HW].copy_(x)
+        n = min(hl, F)
+        if n:
+            xe[(hl - n) * HW:hl * HW].copy_(x[(F - n) * HW:])        # "received" lower halo: the own last frames
+        n = min(hh, F)
+        if n:
+            xe[(hl + F) * HW:(hl + F + n) * HW].copy_(x[:n * HW])    # "received" upper halo: the own first frames
+        self.halo_bytes_recv += (hl + hh) * HW * C * x.element_size()
+        self.halo_bytes_sent += (min(win, F) * 2) * HW * C * x.element_size()
+        self.n_halo += 1
+        return HaloExchange(xe, hl, hh, F, [])

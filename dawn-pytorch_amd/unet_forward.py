@@ -205,18 +205,27 @@ def _temporal_sharded(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs:
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 
-def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
+def _temporal_input_buffer(cs: ClipState, F: int, H: int, W: int, C: int, like: Tensor) -> Optional[Tensor]:
+    """T-sharded: the own-rows slice of the extended [halo | own | halo] buffer of the temporal layer that consumes a producer's
+    output next -- the producer writes there (out=...) and the halo exchange finds the own rows in place (no 210 MB copy per
+    level-0 layer).  Only for tensors whose sole consumer is that temporal layer (the buffer is cached per shape)."""
+    if cs.comm is None or not hasattr(cs.comm, "own_view"):
+        return None
+    return cs.comm.own_view(F, H * W, C, cs.win, like)
+
+
+def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, out: Optional[Tensor] = None) -> Tensor:
     if a.C == 64:
-        return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout, wqkv_bf3=a.wqkv_s)
+        return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout, wqkv_bf3=a.wqkv_s, out=out)
     qkv = _ln_gemm(ops, x, None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W)
     o = ops.sla(qkv, F, H * W)
-    return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
+    return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s, out=out)
 
 
-def _mid_spatial(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int) -> Tensor:
+def _mid_spatial(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, out: Optional[Tensor] = None) -> Tensor:
     qkv = _ln_gemm(ops, x, None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W)
     o = ops.frame_attn(qkv, F, H * W)
-    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
+    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s, out=out)
 
 
 def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_all: Optional[Tensor] = None) -> Tensor:
@@ -233,7 +242,7 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
     for lvl in P.downs:
         x = _resblock(ops, lvl["rb1"], x, None, F, H, W, film_all, cs)
         x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)
-        x = _spatial_linear(ops, lvl["sla"], x, F, H, W)
+        x = _spatial_linear(ops, lvl["sla"], x, F, H, W, out=_temporal_input_buffer(cs, F, H, W, x.shape[1], x))
         x = _temporal(ops, lvl["tattn"], x, F, H, W, cs)
         skips.append((x, H, W))
         if lvl["down"] is not None:
@@ -242,7 +251,7 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
                               bias=bd, w_bf3=wds)
             H, W = H // 2, W // 2
     x = _resblock(ops, P.mid["rb1"], x, None, F, H, W, film_all, cs)
-    x = _mid_spatial(ops, P.mid["sattn"], x, F, H, W)
+    x = _mid_spatial(ops, P.mid["sattn"], x, F, H, W, out=_temporal_input_buffer(cs, F, H, W, x.shape[1], x))
     x = _temporal(ops, P.mid["tattn"], x, F, H, W, cs)
     x = _resblock(ops, P.mid["rb2"], x, None, F, H, W, film_all, cs)
     for lvl in P.ups:
@@ -250,7 +259,7 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
         assert (sh, sw) == (H, W)
         x = _resblock(ops, lvl["rb1"], x, skip, F, H, W, film_all, cs)       # torch.cat((x, h.pop())) MT:948
         x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)
-        x = _spatial_linear(ops, lvl["sla"], x, F, H, W)
+        x = _spatial_linear(ops, lvl["sla"], x, F, H, W, out=_temporal_input_buffer(cs, F, H, W, x.shape[1], x))
         x = _temporal(ops, lvl["tattn"], x, F, H, W, cs)
         if lvl["up"] is not None:
             wu, bu, wus = lvl["up"]

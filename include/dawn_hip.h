@@ -209,6 +209,9 @@ int dawn_select_scan(const unsigned* hist, int nbins, unsigned long long rank, u
                      void* stream);
 int dawn_select_hist(const float* x0, long n, const unsigned* state, int pass, unsigned* hist, void* stream);
 int dawn_select_finalize(const unsigned* state, const unsigned* hist3, float weight, float* s_out, void* stream);
+/* scratch of one selection [hist1 2048 | hist2 1024 | hist3 1024 | state 4 | hmin 4] = 4104 words: zero histograms and state,
+ * hmin = INT_MAX (two stream-ordered fills; the host reuses one buffer per device for every DDIM step) */
+int dawn_select_ws_reset(unsigned* ws, void* stream);
 /* x = clamp(x0,-s,s)/s*sqrt_alpha_next + c*eps + sigma*noise   (noise may be NULL) */
 int dawn_ddim_update(const float* x0, const float* eps, const float* s, const float* noise,
                      float sqrt_alpha_next, float c, float sigma, long n, float* x, void* stream);
@@ -331,6 +334,11 @@ int dawn_rotary_tables(const float* freqs16, int n, int pos0, float* cos_out, fl
 int dawn_rel_pos_bucket(int rel);                                     /* MT:92-109, num_buckets = max_distance = 32 (host) */
 int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1);       /* host: may dawn_conv_desc.ln_eps be used for this projection? */
 int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1);             /* host: does a 1x1 projection take the split GEMM? */
+
+/* ---- measurement helper (bench.py; not on the product path): sustained executed TFLOP/s of an MFMA-only bf16 loop on this
+ * box under its power budget.  mode 0 = zero operands, 1 = operands from registers, 2 = re-read from LDS at the conv kernels'
+ * ratio; operands = 16 x 256 x 8 bf16 (64 KB), scratch >= 2 * CUs * 256 floats.  Synchronises. */
+int dawn_ubench_mfma_bf16(int mode, int iters, const void* operands, float* scratch, float* tflops_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -294,11 +294,11 @@ class RefOps:
         o = torch.einsum("fhde,fhdn->fhen", ctx, q)                          # (F, 8, 32, HW)
         return o.permute(0, 3, 1, 2).reshape(F * HW, 256).contiguous()
 
-    def sla_layer_c64(self, x, F, HW, wqkv, wout, bias, eps=1e-5, wqkv_bf3=None):
+    def sla_layer_c64(self, x, F, HW, wqkv, wout, bias, eps=1e-5, wqkv_bf3=None, out=None):
         stats = self.ln_rowstats(x, None, eps)
         qkv = self.conv_gemm(x, wqkv, 768, row_stats=stats, F=F, Hi=1, Wi=HW)
         o = self.sla(qkv, F, HW)
-        return self.conv_gemm(o, wout, 64, bias=bias, res=x, F=F, Hi=1, Wi=HW)
+        return self.conv_gemm(o, wout, 64, bias=bias, res=x, F=F, Hi=1, Wi=HW, out=out)
 
     def frame_attn(self, qkv, F, N):
         x = qkv.reshape(F, N, 3, 8, 32)

@@ -21,7 +21,10 @@ def pytest_configure(config):
         import shutil
         import subprocess
         if shutil.which("hipcc"):
-            subprocess.run(["bash", os.path.join(ROOT, "build_lib.sh")], check=False, stdout=subprocess.DEVNULL)
+            print("conftest: libdawn_hip.so missing -- building it with build_lib.sh (hipcc, a few minutes) ...", file=sys.stderr)
+            r = subprocess.run(["bash", os.path.join(ROOT, "build_lib.sh")], check=False, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+            if r.returncode != 0:
+                print(f"conftest: build_lib.sh FAILED (exit {r.returncode}):\n{r.stderr[-2000:]}", file=sys.stderr)
 
 
 def pytest_collection_modifyitems(config, items):
