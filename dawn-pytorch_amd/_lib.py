@@ -74,6 +74,7 @@ SIGNATURES = {
     "dawn_sla_layer_c64": [c_f, _i, _i, c_f, c_f, c_f, c_f, _f, c_f, c_f, c_f],
     "dawn_frame_attn": [c_f, _i, _i, c_f, c_f],
     "dawn_init_conv_x": [c_f, c_f, c_f, _i, _i, _i, _i, c_f, c_f],
+    "dawn_init_conv_x_ex": [c_f, _l, c_f, c_f, _i, _i, _i, _i, c_f, c_f],
     "dawn_head_out": [c_f, c_f, c_f, c_f, c_f, c_f, _l, _i, c_f, c_f],
     "dawn_linear": [c_f, _i, _i, _i, c_f, c_f, _i, _i, c_f, _i, c_f],
     "dawn_sinusoidal": [_f, _i, c_f, c_f, c_f],

@@ -10,14 +10,13 @@ namespace {
 // 16 threads per pixel, each 4 output channels (Co = 64) -- generic: Co/4 threads per pixel.
 __global__ __launch_bounds__(256) void init_conv_x_kernel(const float* __restrict__ x, const float* __restrict__ w3,
                                                           const float* __restrict__ fea_pre, int F, int h, int w,
-                                                          int Co, float* __restrict__ out) {
+                                                          int Co, float* __restrict__ out, const long plane) {
     extern __shared__ __attribute__((aligned(16))) float ws[];  // [147][Co]
     for (int i = threadIdx.x; i < 147 * Co; i += 256) ws[i] = w3[i];
     __syncthreads();
     const int tpp = Co >> 2;
     const long npix = (long)F * h * w;
     const long total = npix * tpp;
-    const long plane = (long)F * h * w;
     for (long t = (long)blockIdx.x * 256 + threadIdx.x; t < total; t += (long)gridDim.x * 256) {
         const long pix = t / tpp;
         const int cq = (int)(t - pix * tpp);
@@ -50,14 +49,13 @@ __global__ __launch_bounds__(256) void init_conv_x_kernel(const float* __restric
 // (TR image rows); the 3-channel (TR+6) x (w+6) zero-padded patch and the 148 x 64 weights live in LDS.
 __global__ __launch_bounds__(256) void init_conv_x_mfma_kernel(const float* __restrict__ x, const float* __restrict__ w3,
                                                                const float* __restrict__ fea_pre, int F, int h, int w,
-                                                               float* __restrict__ out) {
+                                                               float* __restrict__ out, const long plane) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int Co = 64, KP = 148;
     const int TR = 256 / w, PW = w + 6, PS = (TR + 6) * PW;
     float* Ws = sm;                 // [148][64]
     float* Ps = sm + KP * Co;       // [3][TR+6][w+6]
     const int tid = threadIdx.x;
-    const long plane = (long)F * h * w;
     const int tiles_per_frame = h / TR;
     const int f = blockIdx.x / tiles_per_frame;
     const int y0 = (blockIdx.x - f * tiles_per_frame) * TR;
@@ -177,14 +175,17 @@ __global__ void sinusoidal_kernel(float t, int dim, const float* __restrict__ fr
 
 }  // namespace
 
-extern "C" int dawn_init_conv_x(const float* x, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
-                                float* out, void* stream) {
+/* plane_stride = floats between the channel planes of x: F*h*w for a whole (3, F, h, w) latent; larger when x points at a frame
+ * sub-range of a longer latent (the T-shard path convolves the edge frames first) */
+extern "C" int dawn_init_conv_x_ex(const float* x, long plane_stride, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
+                                   float* out, void* stream) {
+    if (plane_stride < (long)F * h * w) return dawn_set_error_msg(-61, "dawn_init_conv_x: plane stride smaller than a plane");
     if (Co % 4 != 0 || 147 * Co * 4 > 60000) return dawn_set_error_msg(-60, "dawn_init_conv_x: bad Co");
     if (Co == 64 && w <= 256 && 256 % w == 0 && h % (256 / w) == 0 && (256 / w) <= h) {
         const int TR = 256 / w;
         const int lds = (148 * 64 + 3 * (TR + 6) * (w + 6)) * (int)sizeof(float);
         hipLaunchKernelGGL(init_conv_x_mfma_kernel, dim3(F * (h / TR)), dim3(256), lds, (hipStream_t)stream, x, w3, fea_pre,
-                           F, h, w, out);
+                           F, h, w, out, plane_stride);
         DAWN_LAUNCH_CHECK();
         return 0;
     }
@@ -192,9 +193,13 @@ extern "C" int dawn_init_conv_x(const float* x, const float* w3, const float* fe
     int grid = (int)((total + 255) / 256);
     if (grid > 4096) grid = 4096;
     hipLaunchKernelGGL(init_conv_x_kernel, dim3(grid), dim3(256), 147 * Co * sizeof(float), (hipStream_t)stream, x, w3,
-                       fea_pre, F, h, w, Co, out);
+                       fea_pre, F, h, w, Co, out, plane_stride);
     DAWN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int dawn_init_conv_x(const float* x, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
+                                float* out, void* stream) {
+    return dawn_init_conv_x_ex(x, (long)F * h * w, w3, fea_pre, F, h, w, Co, out, stream);
 }
 extern "C" int dawn_head_out(const float* hg, const float* ho, const float* wg, const float* bg, const float* wo,
                              const float* bo, long rows, int Co, float* eps_out, void* stream) {

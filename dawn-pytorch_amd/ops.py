@@ -417,12 +417,17 @@ class HipOps:
         return out
 
     # ------------------------------------------------------------------ boundary ops
-    def init_conv_x(self, x: Tensor, w3: Tensor, fea_pre: Tensor, F: int, h: int, w: int, Co: int) -> Tensor:
+    def init_conv_x(self, x: Tensor, w3: Tensor, fea_pre: Tensor, F: int, h: int, w: int, Co: int,
+                    frames: Optional[Tuple[int, int]] = None, out: Optional[Tensor] = None) -> Tensor:
+        """frames = (fa, fb): only that frame range of the (3, F, h, w) latent -> ((fb - fa)*h*w, Co) rows (T-shard: edge frames first)."""
         assert x.is_contiguous() and x.shape == (3, F, h, w)
-        self._require(x, w3, fea_pre)
-        out = self.empty(F * h * w, Co, like=x)
-        check(self.L.dawn_init_conv_x(_p(x), _p(w3), _p(fea_pre), F, h, w, Co, _p(out), self._stream()),
-              "dawn_init_conv_x")
+        self._require(x, w3, fea_pre, out)
+        fa, fb = frames if frames is not None else (0, F)
+        if out is None:
+            out = self.empty((fb - fa) * h * w, Co, like=x)
+        assert out.is_contiguous() and out.shape == ((fb - fa) * h * w, Co)
+        check(self.L.dawn_init_conv_x_ex(x.data_ptr() + fa * h * w * 4, F * h * w, _p(w3), _p(fea_pre), fb - fa, h, w, Co, _p(out),
+                                         self._stream()), "dawn_init_conv_x")
         return out
 
     def head_out(self, hg: Tensor, ho: Tensor, wg: Tensor, bg: Tensor, wo: Tensor, bo: Tensor) -> Tensor:

@@ -151,10 +151,10 @@ def _chunks(a: int, b: int, n: int):
     return [(i, min(i + n, b)) for i in range(a, b, n)]
 
 
-def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState) -> Tensor:
+def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState, hx=None) -> Tensor:
     HW = H * W
     if cs.comm is not None:
-        return _temporal_sharded(ops, a, x, F, H, W, cs)
+        return _temporal_sharded(ops, a, x, F, H, W, cs, hx)
     xe, q0, Fext = x, 0, F
     if ops.can_fuse_temporal(a.C, Fext, F, cs.win) and (Fext <= 200 or not ops.can_fuse_temporal_segmented(a.C, cs.win)):
         return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
@@ -168,13 +168,32 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 
-def _temporal_sharded(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState) -> Tensor:
-    """T-sharded form: the halo exchange is posted first, everything that only needs this rank's own
-    frames is launched while it is in flight, and only the work that reads halo rows waits for it."""
+def _balanced_chunks(a: int, b: int, n: int):
+    """[a, b) in the fewest pieces of at most n, equal to within one (a launch of the fused layer costs about the same for 40
+    queries as for 120: its eight waves take one 32-query tile each)."""
+    k = max(1, -(-(b - a) // n))
+    step = -(-(b - a) // k)
+    return [(i, min(i + step, b)) for i in range(a, b, step)]
+
+
+def _temporal_sharded(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState, hx=None) -> Tensor:
+    """T-sharded form.  Two ways of hiding the halo transfer:
+    * `hx` given -- the PRODUCER of x already posted the exchange after writing the edge frames and computed the interior frames
+      while it ran (`_edge_first`): the layer waits for the halo, then runs on the whole extended buffer in the fewest launches;
+    * otherwise the exchange is posted here, everything that only needs this rank's own frames is launched while it is in flight,
+      and only the work that reads halo rows waits for it."""
     HW, win, comm = H * W, cs.win, cs.comm
-    hx = comm.halo_begin(x, HW, win)                      # xe = [lower halo | own | upper halo], transfers in flight
+    posted_early = hx is not None
+    if hx is None:
+        hx = comm.halo_begin(x, HW, win)                  # xe = [lower halo | own | upper halo], transfers in flight
     xe, q0, Fext = hx.xe, hx.hl, hx.Fext
-    if ops.can_fuse_temporal_segmented(a.C, win):
+    if posted_early and ops.can_fuse_temporal_segmented(a.C, win) and (Fext > 200 or not ops.can_fuse_temporal(a.C, Fext, F, win)):
+        # (more than 200 rows do not fit the all-bf16-pipe kernel's LDS image in one launch: balanced segments, not its fp32 fallback)
+        comm.halo_end(hx)
+        return ops.temporal_layer_c64_segmented(xe, Fext, HW, q0, F, win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
+                                                segments=_balanced_chunks(q0, q0 + F, ops.SEG_QUERIES), wqkv_bf3=a.wqkv_s,
+                                                wout_bf3p=a.wout_sp)
+    if not posted_early and ops.can_fuse_temporal_segmented(a.C, win):
         # queries whose +-win window stays inside the own rows need no halo: those segments run first
         ia, ib = q0 + (win if hx.hl else 0), q0 + F - (win if hx.hh else 0)
         ia, ib = min(ia, q0 + F), max(ib, min(ia, q0 + F))
@@ -205,13 +224,34 @@ def _temporal_sharded(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs:
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 
-def _temporal_input_buffer(cs: ClipState, F: int, H: int, W: int, C: int, like: Tensor) -> Optional[Tensor]:
-    """T-sharded: the own-rows slice of the extended [halo | own | halo] buffer of the temporal layer that consumes a producer's
-    output next -- the producer writes there (out=...) and the halo exchange finds the own rows in place (no 210 MB copy per
-    level-0 layer).  Only for tensors whose sole consumer is that temporal layer (the buffer is cached per shape)."""
+def _edge_first(ops, cs: ClipState, F: int, H: int, W: int, C: int, like: Tensor, produce):
+    """T-sharded: run a FRAME-LOCAL producer of a temporal layer's input so that the halo transfer hides behind it:
+    produce(fa, fb, out_rows) computes frames [fa, fb) into out_rows.  The `win` edge frames on each side -- all the neighbours
+    need -- are produced first, straight into the own-rows slice of the extended buffer, the exchange is posted, and the
+    interior frames are produced while it runs.  Returns (own rows, the exchange in flight or None)."""
+    comm, HW, win = cs.comm, H * W, cs.win
+    own = comm.own_view(F, HW, C, win, like)
+    # only where the halo is large (64-channel levels at >= 32 x 32: 10..42 MB per direction and layer at 256 x 256).  On the deep
+    # levels the transfer is 0.6..2.6 MB -- hidden behind the own-rows qkv projection anyway -- and three small producer launches
+    # (below the split kernels' row minimum: fp32 GEMMs) cost more than they hide (measured: +1.4 ms per evaluation)
+    if F <= 2 * win or not getattr(comm, "edge_first", True) or C != 64 or HW < 1024:
+        produce(0, F, own)
+        return own, None
+    produce(0, win, own[:win * HW])
+    produce(F - win, F, own[(F - win) * HW:])
+    hx = comm.halo_begin(own, HW, win)
+    produce(win, F - win, own[win * HW:(F - win) * HW])
+    return own, hx
+
+
+def _spatial_then_temporal(ops, sp, tattn: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState, spatial) -> Tensor:
+    """x -> temporal(spatial(x)); spatial = _spatial_linear or _mid_spatial (per-frame attention: frame-local)."""
     if cs.comm is None or not hasattr(cs.comm, "own_view"):
-        return None
-    return cs.comm.own_view(F, H * W, C, cs.win, like)
+        return _temporal(ops, tattn, spatial(ops, sp, x, F, H, W), F, H, W, cs)
+    HW = H * W
+    own, hx = _edge_first(ops, cs, F, H, W, x.shape[1], x,
+                          lambda fa, fb, o: spatial(ops, sp, x[fa * HW:fb * HW], fb - fa, H, W, out=o))
+    return _temporal(ops, tattn, own, F, H, W, cs, hx)
 
 
 def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, out: Optional[Tensor] = None) -> Tensor:
@@ -236,14 +276,25 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
     F, H, W = cs.F, cs.h, cs.w
     if film_all is None:
         film_all = time_film(ops, P, t, cs.fea_pre)
-    r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
-    x = _temporal(ops, P.init_tattn, r, F, H, W, cs)
+    if cs.comm is not None and hasattr(cs.comm, "own_view"):
+        # T-sharded: `r` stays a tensor of its own (it is the skip of the heads, MT:911 / 955); its frames are convolved edge frames
+        # first and copied into the temporal layer's extended buffer, so that the halo transfer runs behind the interior frames
+        HW = H * W
+        r = ops.empty(F * HW, P.dim, like=x3)
+
+        def produce(fa, fb, o):
+            ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim, frames=(fa, fb), out=r[fa * HW:fb * HW])
+            o.copy_(r[fa * HW:fb * HW])
+        own, hx = _edge_first(ops, cs, F, H, W, P.dim, r, produce)
+        x = _temporal(ops, P.init_tattn, own, F, H, W, cs, hx)
+    else:
+        r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
+        x = _temporal(ops, P.init_tattn, r, F, H, W, cs)
     skips: List[Tuple[Tensor, int, int]] = []
     for lvl in P.downs:
         x = _resblock(ops, lvl["rb1"], x, None, F, H, W, film_all, cs)
         x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)
-        x = _spatial_linear(ops, lvl["sla"], x, F, H, W, out=_temporal_input_buffer(cs, F, H, W, x.shape[1], x))
-        x = _temporal(ops, lvl["tattn"], x, F, H, W, cs)
+        x = _spatial_then_temporal(ops, lvl["sla"], lvl["tattn"], x, F, H, W, cs, _spatial_linear)
         skips.append((x, H, W))
         if lvl["down"] is not None:
             wd, bd, wds = lvl["down"]
@@ -251,16 +302,14 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
                               bias=bd, w_bf3=wds)
             H, W = H // 2, W // 2
     x = _resblock(ops, P.mid["rb1"], x, None, F, H, W, film_all, cs)
-    x = _mid_spatial(ops, P.mid["sattn"], x, F, H, W, out=_temporal_input_buffer(cs, F, H, W, x.shape[1], x))
-    x = _temporal(ops, P.mid["tattn"], x, F, H, W, cs)
+    x = _spatial_then_temporal(ops, P.mid["sattn"], P.mid["tattn"], x, F, H, W, cs, _mid_spatial)
     x = _resblock(ops, P.mid["rb2"], x, None, F, H, W, film_all, cs)
     for lvl in P.ups:
         skip, sh, sw = skips.pop()
         assert (sh, sw) == (H, W)
         x = _resblock(ops, lvl["rb1"], x, skip, F, H, W, film_all, cs)       # torch.cat((x, h.pop())) MT:948
         x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)
-        x = _spatial_linear(ops, lvl["sla"], x, F, H, W, out=_temporal_input_buffer(cs, F, H, W, x.shape[1], x))
-        x = _temporal(ops, lvl["tattn"], x, F, H, W, cs)
+        x = _spatial_then_temporal(ops, lvl["sla"], lvl["tattn"], x, F, H, W, cs, _spatial_linear)
         if lvl["up"] is not None:
             wu, bu, wus = lvl["up"]
             x = ops.conv_gemm(x, wu, x.shape[1], F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=bu, w_bf3=wus)

@@ -187,6 +187,9 @@ int dawn_frame_attn(const float* qkv, int F, int N, float* out, void* stream);
 
 /* ---- A1 x-part of init_conv (3 of 275 channels) + hoisted fea part + bias (MT:776-777, 910) ------
  * x (3,F,h,w) reference layout; w3 [7*7*3][Co] ; fea_pre (h,w,Co) = conv7x7(fea272)+bias; out (F,h,w,Co) */
+/* the same on a frame sub-range of a longer latent: x points at its first frame, plane_stride = floats between channel planes */
+int dawn_init_conv_x_ex(const float* x, long plane_stride, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
+                        float* out, void* stream);
 int dawn_init_conv_x(const float* x, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
                      float* out, void* stream);
 /* ---- A13 heads: two 1x1 convs (Co->2, Co->1) + concat, written as (3,F,h,w) (MT:863,876,956) ------ */

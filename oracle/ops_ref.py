@@ -310,11 +310,16 @@ class RefOps:
         return o.permute(0, 2, 1, 3).reshape(F * N, 256).contiguous()
 
     # ------------------------------------------------------------------ boundary ops
-    def init_conv_x(self, x, w3, fea_pre, F, h, w, Co):
+    def init_conv_x(self, x, w3, fea_pre, F, h, w, Co, frames=None, out=None):
+        fa, fb = frames if frames is not None else (0, F)
         wk = w3.reshape(7, 7, 3, Co).permute(3, 2, 0, 1)
-        y = F_.conv2d(x.permute(1, 0, 2, 3), wk, None, padding=3)            # (F, Co, h, w)
-        y = y.permute(0, 2, 3, 1).reshape(F, h * w, Co) + fea_pre[None]
-        return y.reshape(F * h * w, Co).contiguous()
+        y = F_.conv2d(x[:, fa:fb].permute(1, 0, 2, 3), wk, None, padding=3)  # (fb - fa, Co, h, w)
+        y = y.permute(0, 2, 3, 1).reshape(fb - fa, h * w, Co) + fea_pre[None]
+        y = y.reshape((fb - fa) * h * w, Co).contiguous()
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     def head_out(self, hg, ho, wg, bg, wo, bo):
         return torch.cat((hg @ wg.t() + bg, ho @ wo.t() + bo), dim=1).t().contiguous()

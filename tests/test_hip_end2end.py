@@ -289,3 +289,32 @@ def test_video_generator_pipeline_on_gpu(tmp_path):
     vg2 = VideoGenerator(args, generator=dec, config=cfg, device="cuda:0", allow_random_weights=True, hubert=hub)
     vg2.video_model.load_state_dict(vg.video_model.state_dict())
     assert np.array_equal(vg2.run(), frames)
+
+
+def test_tshard_rank_paths_agree_at_benchmark_length():
+    """One interior T-shard rank's workload (tshard.SimulatedInteriorShard: 200 own frames + 2 x 40 halo frames, full DAWN
+    architecture, small latent): the edge-first schedule (producer writes the edge frames, posts the exchange, computes the interior;
+    the fused temporal layers then run as two balanced 100-query launches on the 280-row buffer) == the interior-first schedule
+    (exchange posted by the temporal layer, 120 interior queries first, two 40-query edge launches): same arithmetic per query, so the
+    two evaluations agree to fp32 rounding; and both == the unsharded evaluation of the 280-frame clip [halo | own | halo] on the
+    own frames whose window stays inside that clip... which needs the same GroupNorm statistics, so that comparison is made with
+    the statistics pass disabled: it is covered by tests/test_tshard_cpu.py (gloo, world 2-4) instead."""
+    from fullsize_cases import KW, build_inputs
+    from dawn_pytorch_amd.tshard import SimulatedInteriorShard
+    from dawn_pytorch_amd.unet_forward import unet_forward
+    Tn, h = 200, 8
+    unet = D.DynamicNfUnet3D(default_num_frames=Tn, **KW, init_seed=0).cuda()
+    ops, P = unet._ops(), unet.packed()
+    fea272, cond, x3 = build_inputs(Tn, h)
+    fea272, cond, x3 = fea272[0].cuda().contiguous(), cond[0].cuda().contiguous(), x3[0].cuda().contiguous()
+    outs = {}
+    for edge_first in (True, False):
+        comm = SimulatedInteriorShard(Tn, world=8, rank=3)
+        comm.edge_first = edge_first
+        cs = unet.build_clip(fea272, cond, comm=comm, Ttotal=comm.Ttotal, f0=comm.f0)
+        outs[edge_first] = unet_forward(ops.with_comm(comm), P, cs, x3, 500)
+        assert comm.n_halo == 10
+    torch.cuda.synchronize()
+    assert torch.isfinite(outs[True]).all()
+    err = log("tshard_rank_edge_first_vs_interior_first", outs[True], outs[False])
+    assert err <= 2e-5 * max(1.0, float(outs[False].abs().max())), err
