@@ -271,10 +271,17 @@ struct Eval {
     int rc = 0;
     void* sk_ws = nullptr;
     size_t sk_bytes = 0;
+    const dawn_shard_comm* sc = nullptr;     // T-shard exchanges (dawn_unet_forward_sharded) or nullptr = single GPU
+    int Ftot = 0, f0g = 0;                   // clip length and first own frame, global
 
     Eval(dawn_ctx* ctx, hipStream_t s, int F_, int h, int w, const void* clip_mem)
         : c(ctx), cur(s), main(s), A(ctx->arena), dry(ctx->arena.dry), F(F_), H0(h), W0(w), clip((const char*)clip_mem) {
         L = clip_layout(ctx, F_, h, w);
+        Ftot = F_;
+    }
+    void set_shard(const dawn_shard_comm* comm) {
+        sc = comm;
+        if (comm) { Ftot = comm->world * F; f0g = comm->rank * F; }
     }
     const float* clipf(size_t off) const { return (const float*)(clip + off); }
 
@@ -288,6 +295,14 @@ struct Eval {
 #define LAUNCH(call)                                   \
     do {                                               \
         if (!dry && rc == 0) { const int r__ = (call); if (r__ != 0) rc = r__; } \
+    } while (0)
+    // a host callback of the T-shard path: skipped in the measuring pass; a missing one is an error, not a silent no-op
+#define CALLBACK(fn, ...)                                                                              \
+    do {                                                                                               \
+        if (!dry && rc == 0) {                                                                         \
+            if (!sc->fn) rc = dawn_set_error_msg(-210, "dawn_ctx: dawn_shard_comm." #fn " is NULL");       \
+            else { const int r__ = sc->fn(sc->user, __VA_ARGS__); if (r__ != 0) rc = r__ < 0 ? r__ : -211; } \
+        }                                                                                              \
     } while (0)
 
     // ---- conv / linear on MFMA (ops.conv_gemm)
@@ -338,7 +353,17 @@ struct Eval {
     // per-channel (a, b): silu(x*a+b) == SiLU(FiLM(GroupNorm8(x)))   (ops.gn_coeffs, single-GPU form)
     void gn_coeffs(const double* part, int nblk, long total_rows, int Cc, const float* gamma, const float* beta, const float* fs,
                    const float* fsh, float* a, float* b) {
-        LAUNCH(dawn_gn_reduce_finalize(part, nblk, (double)total_rows * (Cc / 8), gamma, beta, fs, fsh, Cc, 1e-5f, a, b, cur));
+        // statistics over the WHOLE clip (MT:230,235): total_rows counts this rank's rows
+        const double cnt = (double)total_rows * ((double)Ftot / (double)F) * (Cc / 8);
+        if (!sc) {
+            LAUNCH(dawn_gn_reduce_finalize(part, nblk, cnt, gamma, beta, fs, fsh, Cc, 1e-5f, a, b, cur));
+            return;
+        }
+        double* sums = (double*)falloc(32);          // T-sharded: reduce -> all-reduce of the 16 fp64 sums -> finalize
+        LAUNCH(dawn_gn_reduce(part, nblk, sums, cur));
+        CALLBACK(allreduce_sum_f64, sums, 16, (void*)cur);
+        LAUNCH(dawn_gn_finalize(sums, cnt, gamma, beta, fs, fsh, Cc, 1e-5f, a, b, cur));
+        A.free(sums);
     }
     T2 gn_apply_res(const T2& x, const float* a, const float* b, const float* res) {
         T2 o = t2(x.rows, x.C);
@@ -346,9 +371,11 @@ struct Eval {
         return o;
     }
     // LayerNorm over the channels of [x | x2] (gain folded into w) + projection (unet_forward._ln_gemm)
-    T2 ln_gemm(const T2& x, const T2* x2, const float* w, int N, const void* w_bf3, int Fr, int Hi, int Wi) {
+    T2 ln_gemm(const T2& x, const T2* x2, const float* w, int N, const void* w_bf3, int Fr, int Hi, int Wi, float* outp = nullptr) {
         const int C1 = x2 ? x2->C : 0;
-        T2 o = t2(x.rows, N);
+        T2 o;
+        if (outp) { o.rows = x.rows; o.C = N; o.p = outp; }          // (caller-owned rows of a larger tensor)
+        else o = t2(x.rows, N);
         ConvArgs a;
         a.w = w; a.w_bf3 = w_bf3; a.N = N; a.Fr = Fr; a.Hi = Hi; a.Wi = Wi; a.out = o.p; a.ld_out = N;
         const int pol = c->conv_policy;     // (A/B policies without the row-stationary split kernels take the statistics pass)
@@ -477,7 +504,65 @@ struct Eval {
     }
 
     // ---- temporal attention layer (unet_forward._temporal, single GPU: no halo)
+    // T-sharded form (unet_forward._temporal_sharded): [lower halo | own | upper halo] rows in one buffer; the exchange is posted,
+    // the projection of the own rows (unfused levels) runs while it is in flight, everything that reads halo rows after halo_end
+    T2 temporal_sharded(const AT& a, const T2& x, int Fr, int H, int W) {
+        const int HW = H * W, win = c->cfg.win, C = a.C;
+        const int lo = f0g - win > 0 ? f0g - win : 0, hi = f0g + Fr + win < Ftot ? f0g + Fr + win : Ftot;
+        const int hl = f0g - lo, hh = hi - (f0g + Fr), Fext = hl + Fr + hh;
+        T2 xe = t2((long)Fext * HW, C);
+        float* own = xe.p ? xe.p + (size_t)hl * HW * C : nullptr;
+        if (!dry && rc == 0) {
+            const hipError_t e = hipMemcpyAsync(own, x.p, (size_t)x.rows * C * 4, hipMemcpyDeviceToDevice, cur);
+            if (e != hipSuccess) rc = dawn_set_error(e, __FILE__, __LINE__);
+        }
+        CALLBACK(halo_begin, xe.p, hl, Fr, hh, (long)HW * C, (void*)cur);
+        T2 o;
+        const bool seg_ok = C == 64 && win <= 40;
+        const bool one = can_fuse_temporal(C, Fext, Fr, win) && (Fext <= 200 || !seg_ok);
+        if (one || seg_ok) {
+            CALLBACK(halo_end, (void*)cur);
+            o = t2(x.rows, 64);
+            if (one) {
+                LAUNCH(dawn_temporal_layer_c64_ex(xe.p, Fext, HW, hl, Fr, win, a.wqkv, a.wqkv_s, a.wout, a.wout_sp, clipf(L.rcos),
+                                                  clipf(L.rsin), clipf(L.band), 1e-5f, o.p, c->temporal_flags, cur));
+            } else {
+                // more rows than one launch holds in LDS: the fewest launches of at most 120 queries, equal to within one
+                const int k = (Fr + 119) / 120, step = (Fr + k - 1) / k;
+                for (int qa = hl; qa < hl + Fr; qa += step) {
+                    const int qb = qa + step < hl + Fr ? qa + step : hl + Fr;
+                    const int r0 = qa - win > 0 ? qa - win : 0, r1 = qb + win < Fext ? qb + win : Fext;
+                    LAUNCH(dawn_temporal_layer_c64_ex(xe.p + (size_t)r0 * HW * 64, r1 - r0, HW, qa - r0, qb - qa, win, a.wqkv, a.wqkv_s,
+                                                      a.wout, a.wout_sp, clipf(L.rcos), clipf(L.rsin), clipf(L.band), 1e-5f,
+                                                      o.p + (size_t)(qa - hl) * HW * 64, c->temporal_flags, cur));
+                }
+            }
+            rel(xe);
+            return o;
+        }
+        T2 qkv = t2((long)Fext * HW, 768);
+        auto project = [&](int fa, int fb) {             // LayerNorm + qkv projection of buffer frames [fa, fb)
+            T2 v; v.rows = (long)(fb - fa) * HW; v.C = C; v.p = xe.p ? xe.p + (size_t)fa * HW * C : nullptr;
+            ln_gemm(v, nullptr, a.wqkv, 768, a.wqkv_s, fb - fa, H, W, qkv.p ? qkv.p + (size_t)fa * HW * 768 : (float*)4096);
+        };
+        project(hl, hl + Fr);
+        CALLBACK(halo_end, (void*)cur);
+        if (hl) project(0, hl);
+        if (hh) project(hl + Fr, Fext);
+        T2 at = t2(x.rows, 256);
+        LAUNCH(dawn_temporal_attn(qkv.p, Fext, HW, hl, Fr, win, clipf(L.rcos), clipf(L.rsin), clipf(L.band), at.p, cur));
+        rel(qkv);
+        rel(xe);
+        o = t2(x.rows, a.C);
+        ConvArgs g;
+        g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.N = a.C; g.Fr = Fr; g.Hi = H; g.Wi = W;
+        g.res = x.p; g.ld_res = a.C; g.out = o.p; g.ld_out = a.C;
+        conv(g);
+        rel(at);
+        return o;
+    }
     T2 temporal(const AT& a, const T2& x, int Fr, int H, int W) {
+        if (sc) return temporal_sharded(a, x, Fr, H, W);
         const int HW = H * W, win = c->cfg.win;
         T2 o;
         const bool seg_ok = a.C == 64 && win <= 40;
@@ -815,7 +900,7 @@ extern "C" int dawn_clip_prepare(dawn_ctx* c, int F, int h, int w, const float* 
     return 0;
 }
 
-extern "C" size_t dawn_workspace_bytes(dawn_ctx* c, int F, int h, int w) {
+static size_t workspace_bytes_impl(dawn_ctx* c, int F, int h, int w, const dawn_shard_comm* shard) {
     if (!c || F <= 0 || h <= 0 || w <= 0) return 0;
     // sized for BOTH schedules (two-stream: frees inside a side-stream region are deferred to the join; one-stream: immediate --
     // with a first-fit arena neither high-water mark bounds the other), so that toggling DAWN_OPT_OVERLAP after sizing cannot make a
@@ -827,6 +912,7 @@ extern "C" size_t dawn_workspace_bytes(dawn_ctx* c, int F, int h, int w) {
         c->arena.reset(nullptr, 0, true);
         {
             Eval ev(c, nullptr, F, h, w, nullptr);
+            ev.set_shard(shard);
             ev.forward((const float*)4096, 0.f, (float*)4096);
         }
         if (c->arena.high > fwd) fwd = c->arena.high;
@@ -840,22 +926,51 @@ extern "C" size_t dawn_workspace_bytes(dawn_ctx* c, int F, int h, int w) {
     size_t need = fwd + samp;
     return need > prep ? need : prep;
 }
+extern "C" size_t dawn_workspace_bytes(dawn_ctx* c, int F, int h, int w) { return workspace_bytes_impl(c, F, h, w, nullptr); }
+extern "C" size_t dawn_workspace_bytes_sharded(dawn_ctx* c, int F, int h, int w, int rank, int world) {
+    if (world < 1 || rank < 0 || rank >= world) return 0;
+    dawn_shard_comm geo;                       // geometry only: the measuring pass calls nothing
+    memset(&geo, 0, sizeof(geo));
+    geo.rank = rank; geo.world = world;
+    return workspace_bytes_impl(c, F, h, w, &geo);
+}
 
-extern "C" int dawn_unet_forward(dawn_ctx* c, int F, int h, int w, const void* clip_mem, const float* x3, float t,
-                                 float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
+static int shard_check(const dawn_shard_comm* comm) {
+    if (comm && (comm->world < 1 || comm->rank < 0 || comm->rank >= comm->world))
+        return dawn_set_error_msg(-212, "dawn_shard_comm: need 0 <= rank < world");
+    return 0;
+}
+extern "C" int dawn_unet_forward_sharded(dawn_ctx* c, int F, int h, int w, const void* clip_mem, const float* x3, float t, float* eps_out,
+                                         void* workspace, size_t workspace_bytes, const dawn_shard_comm* comm, void* stream) {
     if (!c || !clip_mem || !x3 || !eps_out || !workspace) return dawn_set_error_msg(-202, "dawn_unet_forward: null argument");
+    if (shard_check(comm)) return -212;
     c->arena.reset(workspace, workspace_bytes, false);
     Eval ev(c, (hipStream_t)stream, F, h, w, clip_mem);
+    ev.set_shard(comm);
     ev.forward(x3, t, eps_out);
     return ev.rc;
 }
+extern "C" int dawn_unet_forward(dawn_ctx* c, int F, int h, int w, const void* clip_mem, const float* x3, float t,
+                                 float* eps_out, void* workspace, size_t workspace_bytes, void* stream) {
+    return dawn_unet_forward_sharded(c, F, h, w, clip_mem, x3, t, eps_out, workspace, workspace_bytes, nullptr, stream);
+}
 
-extern "C" int dawn_sampler_run(dawn_ctx* c, int F, int h, int w, const void* clip_mem, const float* x_init, int S,
-                                const dawn_ddim_step* steps, uint64_t seed, const float* const* noises, float* x_out,
-                                float* thresholds, void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int dawn_sampler_run_sharded(dawn_ctx* c, int F, int h, int w, const void* clip_mem, const float* x_init, int S,
+                                        const dawn_ddim_step* steps, uint64_t seed, const float* const* noises, float* x_out,
+                                        float* thresholds, void* workspace, size_t workspace_bytes, const dawn_shard_comm* comm,
+                                        void* stream) {
     if (!c || !clip_mem || !x_init || !steps || !x_out || !workspace) return dawn_set_error_msg(-202, "dawn_sampler_run: null argument");
+    if (shard_check(comm)) return -212;
+    if (comm && (!comm->allreduce_sum_u32 || !comm->allreduce_min_u32))
+        return dawn_set_error_msg(-210, "dawn_sampler_run_sharded: dawn_shard_comm.allreduce_sum_u32 / allreduce_min_u32 is NULL");
     hipStream_t s = (hipStream_t)stream;
-    const long n = (long)3 * F * h * w;
+    const long n = (long)3 * F * h * w;                       // this rank's elements
+    const int Ftot = comm ? comm->world * F : F, f0g = comm ? comm->rank * F : 0;
+    const long n_total = (long)3 * Ftot * h * w;              // the quantile is over the whole clip (MT:1186-1190)
+#define SHARD_CB(call)                                                        \
+    do {                                                                      \
+        if (comm) { const int r__ = (call); if (r__ != 0) return r__ < 0 ? r__ : -211; } \
+    } while (0)
     const size_t lat = al256((size_t)n * 4);
     char* ws = (char*)workspace;
     const size_t samp = 4 * lat + al256(2048 * 4) + 2 * al256(1024 * 4) + 4 * 256;
@@ -876,13 +991,13 @@ extern "C" int dawn_sampler_run(dawn_ctx* c, int F, int h, int w, const void* cl
     // quantile rank: torch.quantile's own fp32 arithmetic up to 2^24 elements, exact (fp64) above (ops.quantile_rank)
     unsigned long long lo;
     float weight;
-    if (n <= (1L << 24)) {
-        const float pos = 0.9f * (float)(n - 1);
+    if (n_total <= (1L << 24)) {
+        const float pos = 0.9f * (float)(n_total - 1);
         const float fl = floorf(pos);
         lo = (unsigned long long)fl;
         weight = pos - fl;
     } else {
-        const double pos = 0.9 * (double)(n - 1);
+        const double pos = 0.9 * (double)(n_total - 1);
         const double fl = floor(pos);
         lo = (unsigned long long)fl;
         weight = (float)(pos - fl);
@@ -892,32 +1007,44 @@ extern "C" int dawn_sampler_run(dawn_ctx* c, int F, int h, int w, const void* cl
         c->arena.reset(ws, fwd_bytes, false);
         {
             Eval ev(c, s, F, h, w, clip_mem);
+            ev.set_shard(comm);
             ev.forward(x, (float)st.t, eps);
             if (ev.rc) return ev.rc;
         }
         HCK(hipMemsetAsync(hist1, 0, 2048 * 4, s));
         CK(dawn_ddim_x0(x, eps, st.recip, st.recipm1, n, x0, hist1, s));
+        SHARD_CB(comm->allreduce_sum_u32(comm->user, hist1, 2048, stream));
         HCK(hipMemsetAsync(state, 0, 16, s));
         CK(dawn_select_scan(hist1, 2048, lo, state, 1, s));
         HCK(hipMemsetAsync(hist2, 0, 1024 * 4, s));
         CK(dawn_select_hist(x0, n, state, 2, hist2, s));
+        SHARD_CB(comm->allreduce_sum_u32(comm->user, hist2, 1024, stream));
         CK(dawn_select_scan(hist2, 1024, 0, state, 2, s));
         HCK(hipMemsetAsync(hist3, 0, 1024 * 4, s));
         CK(dawn_select_hist(x0, n, state, 3, hist3, s));
+        SHARD_CB(comm->allreduce_sum_u32(comm->user, hist3, 1024, stream));
         CK(dawn_select_scan(hist3, 1024, 0, state, 3, s));
         HCK(hipMemsetD32Async((hipDeviceptr_t)hmin, 0x7fffffff, 4, s));
         CK(dawn_select_hist(x0, n, state, 4, hmin, s));
+        SHARD_CB(comm->allreduce_min_u32(comm->user, hmin, 1, stream));
         CK(dawn_select_finalize(state, hmin, weight, sthr, s));
         if (thresholds) HCK(hipMemcpyAsync(thresholds + 2 * i, sthr, 8, hipMemcpyDeviceToDevice, s));
         const float* nz = nullptr;
         if (st.t_next > 0) {                                    // noise only if t_next > 0 (MT:1201)
             if (noises) nz = noises[i];
-            else { CK(dawn_philox_normal(noise, 3, F, 0, F, h * w, seed, (uint32_t)(i + 1), s)); nz = noise; }
+            else { CK(dawn_philox_normal(noise, 3, F, f0g, Ftot, h * w, seed, (uint32_t)(i + 1), s)); nz = noise; }
         }
         CK(dawn_ddim_update(x0, eps, sthr, nz, st.sqrt_alpha_next, st.c, st.sigma, n, (i + 1 == S) ? x_out : x, s));
     }
     if (S == 0) HCK(hipMemcpyAsync(x_out, x, (size_t)n * 4, hipMemcpyDeviceToDevice, s));
     return 0;
+#undef SHARD_CB
+}
+extern "C" int dawn_sampler_run(dawn_ctx* c, int F, int h, int w, const void* clip_mem, const float* x_init, int S,
+                                const dawn_ddim_step* steps, uint64_t seed, const float* const* noises, float* x_out,
+                                float* thresholds, void* workspace, size_t workspace_bytes, void* stream) {
+    return dawn_sampler_run_sharded(c, F, h, w, clip_mem, x_init, S, steps, seed, noises, x_out, thresholds, workspace, workspace_bytes,
+                                    nullptr, stream);
 }
 
 // profile read-out: after a synchronise, (kind, algorithmic flops, algorithmic bytes, milliseconds) per recorded conv launch

@@ -35,6 +35,79 @@ class DdimStep(C.Structure):
 
 OPT_CONV_POLICY, OPT_TEMPORAL_FLAGS, OPT_OVERLAP, OPT_PROFILE = 1, 2, 3, 4
 
+# ---- T-shard callbacks (include/dawn_hip.h: dawn_shard_comm)
+HALO_BEGIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p)
+HALO_END_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p)
+
+
+class ShardCommC(C.Structure):
+    """Mirror of ``dawn_shard_comm``."""
+    _fields_ = [("user", C.c_void_p), ("rank", C.c_int), ("world", C.c_int), ("halo_begin", HALO_BEGIN_FN),
+                ("halo_end", HALO_END_FN), ("allreduce_sum_f64", ALLREDUCE_FN), ("allreduce_sum_u32", ALLREDUCE_FN),
+                ("allreduce_min_u32", ALLREDUCE_FN)]
+
+
+class ShardCallbacks:
+    """Builds a ``dawn_shard_comm`` from five Python callables working on torch VIEWS of the evaluator's workspace (the buffers the C
+    side hands to the callbacks live inside it):
+        halo_begin(xe (Fext*HW, C) float32, hl, F, hh)   halo_end()   sum_f64(t)   sum_i32(t)   min_i32(t)
+    `from_tshard(comm)` wires them to a tshard.TShardComm (torch.distributed: RCCL on GPUs)."""
+
+    def __init__(self, rank: int, world: int, halo_begin, halo_end, sum_f64, sum_i32, min_i32):
+        self.rank, self.world = rank, world
+        self.fns = (halo_begin, halo_end, sum_f64, sum_i32, min_i32)
+        self.ws: Optional[Tensor] = None         # set by CtxEvaluator before each sharded call
+        self.frame_shape = None
+        self.error: Optional[BaseException] = None
+
+        def view(ptr, nbytes, dtype):
+            off = ptr - self.ws.data_ptr()
+            if off < 0 or off + nbytes > self.ws.numel():
+                raise _lib.DawnHipError("shard callback: buffer outside the evaluator's workspace")
+            return self.ws[off:off + nbytes].view(dtype)
+
+        def guard(f):
+            def g(*a):
+                try:
+                    f(*a)
+                    return 0
+                except BaseException as e:       # noqa: BLE001  (must not propagate through the C frames)
+                    self.error = e
+                    return -213
+            return g
+
+        def hb(user, xe, hl, F, hh, frame_floats, stream):
+            t = view(xe, (hl + F + hh) * frame_floats * 4, torch.float32)
+            halo_begin(t, hl, F, hh, frame_floats)
+
+        def he(user, stream):
+            halo_end()
+
+        def mk(fn, dtype, size):
+            def cb(user, buf, n, stream):
+                fn(view(buf, n * size, dtype))
+            return cb
+
+        self._keep = (HALO_BEGIN_FN(guard(hb)), HALO_END_FN(guard(he)), ALLREDUCE_FN(guard(mk(sum_f64, torch.float64, 8))),
+                      ALLREDUCE_FN(guard(mk(sum_i32, torch.int32, 4))), ALLREDUCE_FN(guard(mk(min_i32, torch.int32, 4))))
+        self.c = ShardCommC(None, rank, world, *self._keep)
+
+    @staticmethod
+    def from_tshard(comm, win: int) -> "ShardCallbacks":
+        """comm: tshard.TShardComm; win: the model's temporal window (what each neighbour needs from this rank)."""
+        comm.set_window(win)
+        state = {}
+
+        def hb(xe, hl, F, hh, frame_floats):
+            state["works"] = comm.halo_post(xe, hl, F, hh, frame_floats)
+
+        def he():
+            for w in state.pop("works", []):
+                w.wait()
+
+        return ShardCallbacks(comm.rank, comm.world, hb, he, comm.all_reduce_sum, comm.all_reduce_sum, comm.all_reduce_min)
+
 
 def named_weights(P: PackedUNet) -> Dict[str, Tensor]:
     """PackedUNet -> {dotted name: device tensor} in the naming scheme of include/dawn_hip.h."""
@@ -105,6 +178,13 @@ class CtxEvaluator:
                                        C.POINTER(DdimStep), C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
                                        C.c_void_p, C.c_size_t, C.c_void_p]
         L.dawn_ctx_profile_read.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.c_int]
+        L.dawn_workspace_bytes_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+        L.dawn_workspace_bytes_sharded.restype = C.c_size_t
+        L.dawn_unet_forward_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p,
+                                                C.c_void_p, C.c_size_t, C.POINTER(ShardCommC), C.c_void_p]
+        L.dawn_sampler_run_sharded.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int,
+                                               C.POINTER(DdimStep), C.c_uint64, C.POINTER(C.c_void_p), C.c_void_p, C.c_void_p,
+                                               C.c_void_p, C.c_size_t, C.POINTER(ShardCommC), C.c_void_p]
         self.P = P
         self.device = P.rel_emb.device
         self.weights = named_weights(P)                      # keeps every tensor alive
@@ -145,11 +225,12 @@ class CtxEvaluator:
     def _stream() -> int:
         return torch.cuda.current_stream().cuda_stream
 
-    def workspace(self, F: int, h: int, w: int) -> Tensor:
-        key = (F, h, w, self._policy)
+    def workspace(self, F: int, h: int, w: int, shard: Optional[ShardCallbacks] = None) -> Tensor:
+        key = (F, h, w, self._policy, None if shard is None else (shard.rank, shard.world))
         need = self._need.get(key)
-        if need is None:                    # sized in C for the two-stream (overlap) case, the larger of the two
-            need = self._need[key] = int(self.L.dawn_workspace_bytes(self.h, F, h, w))
+        if need is None:                    # sized in C for both schedules (one / two streams)
+            need = self._need[key] = int(self.L.dawn_workspace_bytes(self.h, F, h, w) if shard is None else
+                                         self.L.dawn_workspace_bytes_sharded(self.h, F, h, w, shard.rank, shard.world))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
@@ -168,18 +249,32 @@ class CtxEvaluator:
                                        mem.data_ptr(), mem.numel(), ws.data_ptr(), ws.numel(), self._stream()), "dawn_clip_prepare")
         return {"mem": mem, "F": F, "h": h, "w": w}
 
-    def forward(self, clip: dict, x3: Tensor, t: float) -> Tensor:
+    def _shard_call(self, shard: ShardCallbacks, rc: int, what: str) -> None:
+        err, shard.error = shard.error, None
+        if err is not None:
+            raise err
+        check(rc, what)
+
+    def forward(self, clip: dict, x3: Tensor, t: float, shard: Optional[ShardCallbacks] = None) -> Tensor:
+        """shard: this evaluator runs ONE rank of a T-sharded clip (clip = this rank's frames), exchanging through the callbacks."""
         F, h, w = clip["F"], clip["h"], clip["w"]
         if not (x3.is_cuda and x3.is_contiguous() and tuple(x3.shape) == (3, F, h, w) and x3.dtype == torch.float32):
             raise _lib.DawnHipError(f"forward: x3 must be a contiguous fp32 GPU tensor of shape (3, {F}, {h}, {w})")
         out = torch.empty_like(x3)
-        ws = self.workspace(F, h, w)
+        ws = self.workspace(F, h, w, shard)
+        if shard is not None:
+            shard.ws = ws
+            self._shard_call(shard, self.L.dawn_unet_forward_sharded(self.h, F, h, w, clip["mem"].data_ptr(), x3.data_ptr(), float(t),
+                                                                     out.data_ptr(), ws.data_ptr(), ws.numel(), C.byref(shard.c),
+                                                                     self._stream()), "dawn_unet_forward_sharded")
+            return out
         check(self.L.dawn_unet_forward(self.h, F, h, w, clip["mem"].data_ptr(), x3.data_ptr(), float(t), out.data_ptr(),
                                        ws.data_ptr(), ws.numel(), self._stream()), "dawn_unet_forward")
         return out
 
     def sample(self, clip: dict, x_init: Tensor, steps: Sequence[dict], seed: int = 0,
-               noises: Optional[List[Optional[Tensor]]] = None, want_thresholds: bool = False):
+               noises: Optional[List[Optional[Tensor]]] = None, want_thresholds: bool = False,
+               shard: Optional[ShardCallbacks] = None):
         F, h, w = clip["F"], clip["h"], clip["w"]
         S = len(steps)
         arr = (DdimStep * max(S, 1))()
@@ -197,7 +292,14 @@ class CtxEvaluator:
         x_init = x_init.contiguous().float()
         out = torch.empty_like(x_init)
         thr = torch.empty(S, 2, device=self.device) if want_thresholds else None
-        ws = self.workspace(F, h, w)
+        ws = self.workspace(F, h, w, shard)
+        if shard is not None:
+            shard.ws = ws
+            self._shard_call(shard, self.L.dawn_sampler_run_sharded(self.h, F, h, w, clip["mem"].data_ptr(), x_init.data_ptr(), S, arr,
+                                                                    int(seed), nz, out.data_ptr(), None if thr is None else thr.data_ptr(),
+                                                                    ws.data_ptr(), ws.numel(), C.byref(shard.c), self._stream()),
+                             "dawn_sampler_run_sharded")
+            return (out, thr) if want_thresholds else out
         check(self.L.dawn_sampler_run(self.h, F, h, w, clip["mem"].data_ptr(), x_init.data_ptr(), S, arr, int(seed), nz,
                                       out.data_ptr(), None if thr is None else thr.data_ptr(), ws.data_ptr(), ws.numel(),
                                       self._stream()), "dawn_sampler_run")

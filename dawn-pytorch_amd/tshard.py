@@ -49,6 +49,7 @@ class TShardComm:
         if world > 1 and (f0 != rank * F or Ttotal != world * F):
             raise ValueError("TShardComm expects equal contiguous shards: f0 == rank*F and Ttotal == world*F")
         self._bufs = {}
+        self._win = 0                 # attention window of the exchanges (set by halo_begin / set_window)
         self.n_halo = self.n_allreduce = 0
         self.halo_bytes_sent = self.halo_bytes_recv = self.allreduce_bytes = 0
 
@@ -96,22 +97,34 @@ class TShardComm:
         return self.own_buffer(F, HW, C, win, like)[hl * HW:(hl + F) * HW]
 
     def halo_begin(self, x: Tensor, HW: int, win: int) -> HaloExchange:
-        """x (F*HW, C) own frames.  Copies them into the middle of the (cached) extended buffer and posts the point-to-point
-        sends / receives.  NOTE the returned buffer is CACHED per (rows, C): it stays valid only until the next exchange of the
-        same shape on this communicator (the three 64-channel level-0 layers share one); callers consume it before the next
-        exchange (stream order).  `release_buffers()` drops the cache between clips.
-        sends / receives of the halo frames: the lower halo = global frames [f0 - win, f0), the upper = [f0 + F, f0 + F +
-        win), clipped to the clip, each piece from the rank that owns it."""
+        """x (F*HW, C) own frames.  Copies them into the middle of the (cached) extended buffer (unless a producer already wrote them
+        there: own_view) and posts the point-to-point sends / receives of the halo frames: the lower halo = global frames
+        [f0 - win, f0), the upper = [f0 + F, f0 + F + win), clipped to the clip, each piece from the rank that owns it.
+        NOTE the returned buffer is CACHED per (rows, C): it stays valid only until the next exchange of the same shape on this
+        communicator (the three 64-channel level-0 layers share one); callers consume it before the next exchange (stream
+        order).  `release_buffers()` drops the cache between clips."""
         F = x.shape[0] // HW
         assert F == self.F, (F, self.F)
         C = x.shape[1]
         lo_g, hi_g = max(0, self.f0 - win), min(self.Ttotal, self.f0 + F + win)     # global frame range of the buffer
         hl, hh = self.f0 - lo_g, hi_g - (self.f0 + F)
+        self._win = win
         xe = self._buffer((hl + F + hh) * HW, C, x)
         if x.data_ptr() != xe[hl * HW:].data_ptr():          # (already in place when the producer wrote into own_view())
             xe[hl * HW:(hl + F) * HW].copy_(x)
+        return HaloExchange(xe, hl, hh, F, self.halo_post(xe, hl, F, hh, HW * C))
+
+    def halo_post(self, xe: Tensor, hl: int, F: int, hh: int, frame_floats: int):
+        """Post the sends / receives for an extended buffer whose own frames are in place: xe = [hl | F | hh] frames of
+        frame_floats floats (any 2-D / 1-D contiguous float view).  Returns the outstanding requests (halo_end waits for them).
+        Also the body of the C evaluator's halo_begin callback (ctx.ShardCallbacks.from_tshard), after set_window(win)."""
+        assert F == self.F, (F, self.F)
+        assert self._win >= max(hl, hh), "halo_post: set_window(win) first"
+        xe = xe.reshape(hl + F + hh, frame_floats)
+        lo_g, hi_g = self.f0 - hl, self.f0 + F + hh
         d = self.dist
         ops = []
+        esz = xe.element_size() * frame_floats
         for r in range(self.world):
             if r == self.rank:
                 continue
@@ -119,16 +132,21 @@ class TShardComm:
             # what I receive from r: its frames inside my buffer range
             a, b = max(r0, lo_g), min(r1, hi_g)
             if a < b:
-                ops.append(d.P2POp(d.irecv, xe[(a - lo_g) * HW:(b - lo_g) * HW], r, group=self.group))
-                self.halo_bytes_recv += (b - a) * HW * C * x.element_size()
-            # what I send to r: my frames inside ITS buffer range [r0 - win, r1 + win)
-            a, b = max(self.f0, r0 - win), min(self.f0 + F, r1 + win)
+                ops.append(d.P2POp(d.irecv, xe[a - lo_g:b - lo_g], r, group=self.group))
+                self.halo_bytes_recv += (b - a) * esz
+            # what I send to r: my frames inside ITS buffer range [r0 - win_r, r1 + win_r), win_r = its halo widths
+            wl, wh = min(self._win, r0), min(self._win, self.Ttotal - r1)
+            a, b = max(self.f0, r0 - wl), min(self.f0 + F, r1 + wh)
             if a < b:
-                ops.append(d.P2POp(d.isend, x[(a - self.f0) * HW:(b - self.f0) * HW], r, group=self.group))
-                self.halo_bytes_sent += (b - a) * HW * C * x.element_size()
+                ops.append(d.P2POp(d.isend, xe[a - lo_g:b - lo_g], r, group=self.group))
+                self.halo_bytes_sent += (b - a) * esz
         works = d.batch_isend_irecv(ops) if ops else []
         self.n_halo += 1
-        return HaloExchange(xe, hl, hh, F, works)
+        return works
+
+    def set_window(self, win: int) -> None:
+        """Attention window of the exchanges (what the NEIGHBOURS need from this rank; halo_begin sets it itself)."""
+        self._win = win
 
     def release_buffers(self) -> None:
         """Drop the cached extended buffers (they pin (Fext*HW, C) per level for the lifetime of the communicator)."""

@@ -328,6 +328,36 @@ typedef struct dawn_ddim_step {          /* per-step scalars of MT:1170-1205 (ho
 int dawn_sampler_run(dawn_ctx* ctx, int F, int h, int w, const void* clip_mem, const float* x_init, int S,
                      const dawn_ddim_step* steps, uint64_t seed, const float* const* noises, float* x_out,
                      float* thresholds, void* workspace, size_t workspace_bytes, void* stream);
+/* ---- T-shard through the C ABI.  One rank of a clip sharded along T over `world` processes / GPUs: this rank
+ * owns the global frames [rank*F, (rank+1)*F) of a clip of world*F frames; clip_mem is prepared (dawn_clip_prepare) with THIS rank's
+ * F rows of the condition.  The path has exactly three exchanges; the host supplies them as callbacks (RCCL / MPI / anything):
+ *   halo_begin   a temporal layer's input as frame-major rows [hl lower-halo frames | F own frames | hh upper-halo frames] of
+ *                frame_floats floats each, own frames in place: send the own edge frames the neighbours need, receive the halo
+ *                frames (global frames [rank*F - hl, rank*F) and [(rank+1)*F, (rank+1)*F + hh); hl, hh <= win, 0 at the clip ends;
+ *                a halo wider than a shard spans several ranks).  May return before the transfer completes;
+ *   halo_end     make `stream` wait for the transfer posted by the last halo_begin (the evaluator launches the work that only
+ *                reads own frames between the two);
+ *   allreduce_*  in-place sum / min over the ranks: 16 fp64 GroupNorm sums (40 per evaluation), the radix-select histograms
+ *                (2048 / 1024 / 1024 u32) and one u32 minimum per DDIM step.
+ * Every callback is stream-ordered: it sees the work already enqueued on `stream`, and work enqueued on `stream` after it sees
+ * its result.  Return 0 or a negative error code (the evaluation stops and returns it).  NULL comm = dawn_unet_forward. */
+typedef struct dawn_shard_comm {
+    void* user;
+    int rank, world;
+    int (*halo_begin)(void* user, float* xe, int hl, int F, int hh, long frame_floats, void* stream);
+    int (*halo_end)(void* user, void* stream);
+    int (*allreduce_sum_f64)(void* user, double* buf, int n, void* stream);
+    int (*allreduce_sum_u32)(void* user, unsigned* buf, int n, void* stream);
+    int (*allreduce_min_u32)(void* user, unsigned* buf, int n, void* stream);
+} dawn_shard_comm;
+size_t dawn_workspace_bytes_sharded(dawn_ctx* ctx, int F, int h, int w, int rank, int world);
+int dawn_unet_forward_sharded(dawn_ctx* ctx, int F, int h, int w, const void* clip_mem, const float* x3, float t, float* eps_out,
+                              void* workspace, size_t workspace_bytes, const dawn_shard_comm* comm, void* stream);
+/* noise of step i: noises[i] (this rank's frames) or the counter-based generator keyed by the GLOBAL element index (shard-invariant);
+ * the 0.9-quantile is over the whole clip (histogram all-reduces) */
+int dawn_sampler_run_sharded(dawn_ctx* ctx, int F, int h, int w, const void* clip_mem, const float* x_init, int S,
+                             const dawn_ddim_step* steps, uint64_t seed, const float* const* noises, float* x_out,
+                             float* thresholds, void* workspace, size_t workspace_bytes, const dawn_shard_comm* comm, void* stream);
 /* after a stream synchronise: (kind, algorithmic flops, algorithmic bytes, ms) per conv launch recorded under
  * DAWN_OPT_PROFILE; kind 0 = split 3x3, 1 = split 1x1, 2 = fp32 MFMA; returns the number of entries (and clears them) */
 int dawn_ctx_profile_read(dawn_ctx* ctx, double* out4, int max_entries);

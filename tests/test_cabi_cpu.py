@@ -23,7 +23,8 @@ def test_library_exports_every_declared_symbol():
     # whole-path entry points (bound with their own argtypes in dawn_pytorch_amd/ctx.py) + host-side helpers
     CTX = {"dawn_ctx_create", "dawn_ctx_destroy", "dawn_ctx_set_option", "dawn_clip_bytes", "dawn_workspace_bytes",
            "dawn_clip_prepare", "dawn_unet_forward", "dawn_sampler_run", "dawn_ctx_profile_read", "dawn_chw_to_hwc",
-           "dawn_rotary_tables", "dawn_rel_pos_bucket"}
+           "dawn_rotary_tables", "dawn_rel_pos_bucket", "dawn_workspace_bytes_sharded", "dawn_unet_forward_sharded",
+           "dawn_sampler_run_sharded"}
     declared = set(names) - {"dawn_last_error", "dawn_abi_version"} - CTX
     assert CTX <= set(names)
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
@@ -78,3 +79,6 @@ def test_ctx_structs_match_header():
     assert ctypes.sizeof(ctx.UnetCfg) == 4 * (2 + 8 + 1 + 3 + 1)
     assert ctypes.sizeof(ctx.DdimStep) == 4 * 7
     assert ctypes.sizeof(ctx.NamedPtr) == 16
+    # dawn_shard_comm: void* user; int rank, world; five function pointers
+    assert ctypes.sizeof(ctx.ShardCommC) == 8 + 4 + 4 + 5 * 8
+    assert ctx.ShardCommC.halo_begin.offset == 16 and ctx.ShardCommC.allreduce_min_u32.offset == 48
