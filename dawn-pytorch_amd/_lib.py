@@ -83,6 +83,7 @@ SIGNATURES = {
     "dawn_select_hist": [c_f, _l, c_f, _i, c_f, c_f],
     "dawn_select_finalize": [c_f, c_f, _f, c_f, c_f],
     "dawn_select_ws_reset": [c_f, c_f],
+    "dawn_attn_bias32": [c_f, _i, c_f, _i, c_f, _i, _i, _i, _i, c_f, c_f, c_f, _i, _f, c_f, _i, c_f],
     "dawn_ubench_mfma_bf16": [_i, _i, c_f, c_f, C.POINTER(C.c_float), c_f],
     "dawn_ddim_update": [c_f, c_f, c_f, c_f, _f, _f, _f, _l, c_f, c_f],
     "dawn_cfg_combine": [c_f, c_f, _f, _l, c_f, c_f],

@@ -648,6 +648,22 @@ class HipOps:
         check(self.L.dawn_attn64(_p(qkv), T, heads, _p(out), self._stream()), "dawn_attn64")
         return out
 
+    def attn_bias32(self, q: Tensor, k: Tensor, v: Tensor, heads: int, bias: Optional[Tensor], rcos: Optional[Tensor],
+                    rsin: Optional[Tensor], scale: float) -> Tensor:
+        """PBnet decoder attention: q (Tq, >= heads*32), k / v (Tk, ...) -- column slices allowed --, bias
+        (heads, Tq, Tk) additive, rotary tables (>= max(Tq, Tk), nrot) for the first 2*nrot features of every head."""
+        Tq, Tk = q.shape[0], k.shape[0]
+        for t in (q, k, v):
+            assert t.stride(1) == 1 and t.shape[1] == heads * 32
+        self._require(q, k, v, bias, rcos, rsin)
+        assert bias is None or (bias.is_contiguous() and tuple(bias.shape) == (heads, Tq, Tk))
+        nrot = 0 if rcos is None else rcos.shape[1]
+        assert rcos is None or (rcos.is_contiguous() and rsin.is_contiguous() and rcos.shape[0] >= max(Tq, Tk))
+        out = self.empty(Tq, heads * 32, like=q)
+        check(self.L.dawn_attn_bias32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), Tq, Tk, heads, _p(bias), _p(rcos),
+                                      _p(rsin), nrot, float(scale), _p(out), heads * 32, self._stream()), "dawn_attn_bias32")
+        return out
+
     def interp_linear(self, y: Tensor, xi: Tensor) -> Tensor:
         """scipy interp1d(arange(n), y, kind='linear', axis=0)(xi) as float32; xi float64 positions on the device."""
         assert y.is_contiguous() and xi.dtype == torch.float64 and xi.is_contiguous()

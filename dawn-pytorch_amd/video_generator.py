@@ -24,7 +24,7 @@ from .flow_diffusion import FlowDiffusion
 
 class VideoGenerator:
     def __init__(self, args, *, generator=None, frontend=None, config: Optional[dict] = None, device=None,
-                 allow_random_weights: bool = False, deterministic: bool = True, hubert=None):
+                 allow_random_weights: bool = False, deterministic: bool = True, hubert=None, pbnet=None):
         """`allow_random_weights`: explicit opt-in (benches, tests) to run with the deterministic random-init denoiser
         when the configured checkpoint is absent; without it a missing checkpoint raises, as the reference's
         `torch.load` does (UVG:527).  `deterministic`: seed the sampler's counter-based noise with the config's
@@ -32,6 +32,7 @@ class VideoGenerator:
         NOTE (reference quirk, kept): `FlowDiffusion.face_loc_emb` is never saved / loaded by the reference (it is a
         sibling of `.diffusion`, FD:169), so it stays at its constructor initialisation here too."""
         self.hubert = hubert              # hubert.HubertFeatures: stage 2 (process_audio, UVG:202-250) on the GPU (SURVEY 8f N3)
+        self.pbnet = pbnet                # (pose, blink) pbnet.PoseBlinkGenerator pair: stage 3 (generate_pose_blink, UVG:252-302; N4)
         self.allow_random_weights = bool(allow_random_weights) or bool(getattr(args, "allow_random_weights", False))
         self.deterministic = deterministic
         self.audio_path = args.audio_path
@@ -94,7 +95,22 @@ class VideoGenerator:
         np.save(self.audio_emb_path, feats)
 
     def generate_pose_blink(self):
-        return self._front("generate_pose_blink")
+        """UVG:252-302.  With a (pose, blink) pair of `pbnet.PoseBlinkGenerator` (built from the decoders of the reference's own
+        PBnet checkpoints) the stage runs here: init_pose.npy / init_eye_bbox.npy (or the reference's defaults when the 3DDFA
+        extraction left none, UVG:275-279) + target_audio.npy -> dri_pose.npy / dri_blink.npy.  Otherwise delegated."""
+        if self.pbnet is None:
+            return self._front("generate_pose_blink")
+        from .pbnet import pose_blink_stage
+        try:
+            init_pose = torch.from_numpy(np.load(osp.join(self.cache_path, 'init_pose.npy')))
+            init_blink = torch.from_numpy(np.load(osp.join(self.cache_path, 'init_eye_bbox.npy')))
+        except Exception:                                     # noqa: BLE001  (UVG:275: default values when 3DDFA extraction failed)
+            init_pose = torch.from_numpy(np.array([[0, 0, 0, 4.79e-04, 5.65e+01, 6.49e+01]]))
+            init_blink = torch.from_numpy(np.array([[0.3, 0.3]]))
+        audio = torch.from_numpy(np.load(self.audio_emb_path))
+        pose, blink = pose_blink_stage(self.pbnet[0], self.pbnet[1], audio, init_pose, init_blink)
+        np.save(osp.join(self.cache_path, 'dri_pose.npy'), pose.numpy())
+        np.save(osp.join(self.cache_path, 'dri_blink.npy'), blink.numpy())
 
     def _front(self, name):
         if self.frontend is not None:

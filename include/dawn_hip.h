@@ -275,6 +275,15 @@ int dawn_attn64(const float* qkv, int T, int heads, float* out, void* stream);
 /* scipy interp1d(arange(n), y (n, C) fp32, kind="linear", axis=0)(xi) -> out (m, C) fp32; xi (m) doubles on the device */
 int dawn_interp_linear(const float* y, long n, int C, const double* xi, long m, float* out, void* stream);
 
+/* ---- PBnet pose / blink decoder (PBnet/src/models/architectures/transformerdecoder5.py:40-98, 120-166).
+ * Attention core for heads of 32: out[i][h] = softmax_j(scale * rot(q_i,h) . rot(k_j,h) + bias[h][i][j]) v_j,h -- q / k / v rows with
+ * strides ldq / ldk / ldv (column slices of a qkv tensor are fine), head h at columns [32h, 32h + 32); rotary embedding on the first
+ * 2*nrot features of every head (interleaved pairs, position = row index) from cos / sin tables (max(Tq, Tk), nrot); bias
+ * (heads, Tq, Tk) additive or NULL.  The rest of the decoder is dawn_linear / dawn_ln_affine_act / dawn_add_act. */
+int dawn_attn_bias32(const float* q, int ldq, const float* k, int ldk, const float* v, int ldv, int Tq, int Tk, int heads,
+                     const float* bias, const float* rot_cos, const float* rot_sin, int nrot, float scale, float* out, int ld_out,
+                     void* stream);
+
 /* ---- whole-path entry points (C-side evaluator, csrc/dawn_ctx.hip) ----------------------------------
  * A host in any language runs the denoiser with these five calls; the Python package keeps its own orchestration
  * (unet_forward.py, needed for the T-sharded path) and the GPU tests require both to agree bit for bit.

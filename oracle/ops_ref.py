@@ -490,6 +490,26 @@ class RefOps:
         att = torch.softmax((q * 0.125) @ k.transpose(1, 2), dim=-1)
         return (att @ v).transpose(0, 1).reshape(T_, heads * 64).contiguous()
 
+    def attn_bias32(self, q, k, v, heads, bias, rcos, rsin, scale):
+        def split(t):
+            return t.reshape(t.shape[0], heads, 32).transpose(0, 1)
+
+        def rot(t):                                              # interleaved pairs of the first 2*nrot features, position = row
+            if rcos is None:
+                return t
+            n, nr = t.shape[1], rcos.shape[1]
+            c, s = rcos[:n].repeat_interleave(2, dim=1), rsin[:n].repeat_interleave(2, dim=1)
+            tr, tp = t[..., :2 * nr], t[..., 2 * nr:]
+            x = tr.reshape(*tr.shape[:-1], nr, 2)
+            half = torch.stack((-x[..., 1], x[..., 0]), dim=-1).reshape(tr.shape)
+            return torch.cat((tr * c + half * s, tp), dim=-1)
+        qh, kh, vh = rot(split(q) * scale), rot(split(k)), split(v)
+        sim = qh @ kh.transpose(1, 2)
+        if bias is not None:
+            sim = sim + bias
+        sim = sim - sim.amax(dim=-1, keepdim=True)
+        return (sim.softmax(dim=-1) @ vh).transpose(0, 1).reshape(q.shape[0], heads * 32).contiguous()
+
     def interp_linear(self, y, xi):
         from scipy.interpolate import interp1d
         f = interp1d(np.arange(y.shape[0]), y.cpu().numpy(), kind="linear", axis=0)
