@@ -166,6 +166,23 @@ class PoseBlinkGenerator:
         return {"x": x, "z": fact * z, "y": y, "mask": mask, "lengths": lengths.to(self.device), "output": out}
 
 
+def load_pbnet(pose_ckpt: str, blink_ckpt: str, device=None, ops=None) -> Tuple[PoseBlinkGenerator, PoseBlinkGenerator]:
+    """The (pose, blink) pair from the reference's checkpoint layout (UVG:74-113): `<dir>/checkpoint_*.pth.tar` = the CVAE's
+    state_dict (`encoder.*` / `decoder.*`), `<dir>/opt.yaml` = its training options (`archiname`, `num_heads`, ...)."""
+    import os
+    import yaml
+    gens = []
+    for ckpt in (pose_ckpt, blink_ckpt):
+        with open(os.path.join(os.path.dirname(ckpt), "opt.yaml")) as f:
+            opt = yaml.safe_load(f)
+        sd = torch.load(ckpt, map_location="cpu")
+        dec = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+        gens.append(PoseBlinkGenerator(dec, archiname=opt["archiname"], num_heads=int(opt.get("num_heads", 4)),
+                                       num_buckets=int(opt.get("num_buckets", 32)), max_distance=int(opt.get("max_distance", 32)),
+                                       device=device, ops=ops))
+    return gens[0], gens[1]
+
+
 @torch.no_grad()
 def pose_blink_stage(gen_pose: PoseBlinkGenerator, gen_blink: PoseBlinkGenerator, audio: Tensor, init_pose: Tensor, init_blink: Tensor,
                      z_pose: Optional[Tensor] = None, z_blink: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:

@@ -227,13 +227,20 @@ def parse_args(argv=None):
     p.add_argument('--config', type=str, default=None, help='DAWN_{res}.yaml (defaults to ./config/DAWN_<res>.yaml)')
     p.add_argument('--sampling_step', type=int, default=None, help='override DDIM steps (YAML ships 20)')
     p.add_argument('--max_n_frames', type=int, default=None, help='override the clip-length cap (YAML ships 200)')
+    p.add_argument('--pbnet_pose_ckpt', type=str, default='./pretrain_models/pbnet_seperate/pose/checkpoint_40000.pth.tar')
+    p.add_argument('--pbnet_blink_ckpt', type=str, default='./pretrain_models/pbnet_seperate/blink/checkpoint_95000.pth.tar')
     p.add_argument('--allow_random_weights', action='store_true',
                    help='run with the deterministic random-init denoiser when the checkpoint is absent (plumbing only)')
     return p.parse_args(argv)
 
 
 def main():
-    VideoGenerator(parse_args()).run()
+    args = parse_args()
+    pbnet = None
+    if osp.exists(args.pbnet_pose_ckpt) and osp.exists(args.pbnet_blink_ckpt):     # stage 3 here, else via the cache files
+        from .pbnet import load_pbnet
+        pbnet = load_pbnet(args.pbnet_pose_ckpt, args.pbnet_blink_ckpt, device="cuda:0" if torch.cuda.is_available() else "cpu")
+    VideoGenerator(args, pbnet=pbnet).run()
 
 
 if __name__ == "__main__":
