@@ -62,7 +62,9 @@ SIGNATURES = {
     "dawn_xattn_ln_sum": [c_f, c_f, c_f, _l, _i, _f, c_f],
     "dawn_xattn_tables": [c_f, c_f, c_f, c_f, c_f, c_f, _i, _i, c_f, c_f],
     "dawn_xattn_sigma_out": [c_f, _l, _i, c_f, c_f, _i, _f, c_f, c_f],
+    "dawn_xattn_sigma_out_h1": [c_f, _l, _i, c_f, c_f, _i, _f, c_f, c_f, c_f, c_f, c_f],
     "dawn_xattn_layer_c64": [c_f, _i, _i, c_f, _i, _i, _l, _i, c_f, c_f, c_f, c_f, _f, c_f, c_f],
+    "dawn_xattn_layer_c64_h1": [c_f, _i, _i, c_f, _i, _i, _l, _i, c_f, c_f, c_f, c_f, _f, c_f, c_f, c_f, c_f, c_f],
     "dawn_temporal_attn": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f],
     "dawn_temporal_layer_c64": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f, c_f, _f, c_f, c_f],
     "dawn_temporal_layer_c64_ex": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, _f, c_f, _i, c_f],

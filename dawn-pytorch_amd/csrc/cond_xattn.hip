@@ -153,7 +153,9 @@ __global__ __launch_bounds__(256) void xattn_ln_sum_kernel(const float* __restri
 template <int L, int MAXQ>
 __global__ __launch_bounds__(256) void xattn_sigma_out_kernel(const float* __restrict__ q, long rows, int HW,
                                                               const float* __restrict__ xtab, const float* __restrict__ g3,
-                                                              int Co, float eps, float* __restrict__ out) {
+                                                              int Co, float eps, float* __restrict__ out,
+                                                              const float* __restrict__ gn_x, const float* __restrict__ gn_a,
+                                                              const float* __restrict__ gn_b) {
     constexpr int RPB = 256 / L, R = 4;
     const int sub = threadIdx.x % L;
     const int lane = threadIdx.x & 63;
@@ -222,14 +224,24 @@ __global__ __launch_bounds__(256) void xattn_sigma_out_kernel(const float* __res
 #pragma unroll
         for (int i = 0; i < MAXQ; ++i) {
             const int qd = sub + i * L;
-            if (qd < nq) *reinterpret_cast<f32x4*>(out + (row0 + r) * Co + qd * 4) = acc[r][i];
+            if (qd < nq) {
+                f32x4 v = acc[r][i];
+                if (gn_x) {                                    // h1 = SiLU(FiLM(GroupNorm(c1))) + h_cond in this epilogue (see xattn_layer.hip)
+                    const f32x4 c4 = *reinterpret_cast<const f32x4*>(gn_x + (row0 + r) * Co + qd * 4);
+                    const f32x4 a4 = *reinterpret_cast<const f32x4*>(gn_a + qd * 4), b4 = *reinterpret_cast<const f32x4*>(gn_b + qd * 4);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) v[j] = dawn_silu(c4[j] * a4[j] + b4[j]) + v[j];
+                }
+                *reinterpret_cast<f32x4*>(out + (row0 + r) * Co + qd * 4) = v;
+            }
         }
 }
 
 }  // namespace
 
-extern "C" int dawn_xattn_sigma_out(const float* q, long rows, int HW, const float* xtab, const float* g3, int Co, float eps,
-                                    float* out, void* stream) {
+extern "C" int dawn_xattn_sigma_out_h1(const float* q, long rows, int HW, const float* xtab, const float* g3, int Co, float eps,
+                                       const float* gn_x, const float* gn_a, const float* gn_b, float* out, void* stream) {
+    if (gn_x && (!gn_a || !gn_b)) return dawn_set_error_msg(-54, "dawn_xattn_sigma_out_h1: gn_x needs gn_a and gn_b");
     if (Co % 32 != 0 || Co < 32 || Co > 512 || HW % 4 != 0 || rows % 4 != 0)
         return dawn_set_error_msg(-53, "dawn_xattn_sigma_out: need Co % 32 == 0, 32 <= Co <= 512, H*W % 4 == 0");
     if (rows <= 0) return 0;
@@ -237,7 +249,7 @@ extern "C" int dawn_xattn_sigma_out(const float* q, long rows, int HW, const flo
     const int nq = Co / 4;
 #define LAUNCH_XS(L, MQ)                                                                                                   \
     hipLaunchKernelGGL((xattn_sigma_out_kernel<L, MQ>), dim3(dawn_cdiv(rows, (256 / L) * 4)), dim3(256), 0, s, q, rows, HW, xtab, \
-                       g3, Co, eps, out)
+                       g3, Co, eps, out, gn_x, gn_a, gn_b)
     if (nq > 64) LAUNCH_XS(64, 2);
     else if (nq > 32) LAUNCH_XS(64, 1);
     else if (nq > 16) LAUNCH_XS(32, 1);
@@ -246,6 +258,10 @@ extern "C" int dawn_xattn_sigma_out(const float* q, long rows, int HW, const flo
 #undef LAUNCH_XS
     DAWN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int dawn_xattn_sigma_out(const float* q, long rows, int HW, const float* xtab, const float* g3, int Co, float eps,
+                                    float* out, void* stream) {
+    return dawn_xattn_sigma_out_h1(q, rows, HW, xtab, g3, Co, eps, nullptr, nullptr, nullptr, out, stream);
 }
 
 extern "C" int dawn_xattn_prep(const float* kv, int F, const float* k_scale, const float* null_kv, float* kvtab,

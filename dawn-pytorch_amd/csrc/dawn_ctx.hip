@@ -427,9 +427,17 @@ struct Eval {
         const long rows = (long)Fr * HW, total_rows = rows;
         T2 hcond;
         const float *fs = nullptr, *fsh = nullptr;
+        // fused epilogue: conv1 + statistics first, then the cross-attention kernel writes h1 = SiLU(FiLM(GN(c1))) + h_cond itself
+        // (unet_forward._resblock: no h_cond tensor, no GroupNorm-apply pass, no second stream)
+        const size_t xt_h1 = rb.conditioned ? L.xtab[rb.cond_index] : (size_t)-1;
+        const bool h1_c64 = rb.conditioned && xt_h1 != (size_t)-1 && can_fuse_xattn(rb.Cin, Co, x.C, HW);
+        const bool h1_out = rb.conditioned && xt_h1 != (size_t)-1 && !h1_c64 && can_fuse_xattn_out(Co, HW);
+        const bool fuse_h1 = h1_c64 || h1_out;
         if (rb.conditioned) {
             fs = film_all + rb.film_off;
             fsh = film_all + rb.film_off + Co;
+        }
+        if (rb.conditioned && !fuse_h1) {
             // cross-attention chain on the side stream
             fork();
             const size_t xt = L.xtab[rb.cond_index];
@@ -472,8 +480,21 @@ struct Eval {
         }
         float* ab1 = falloc(2 * (size_t)Co);
         gn_coeffs(part, nblk, total_rows, Co, rb.g1, rb.be1, fs, fsh, ab1, ab1 + Co);
-        if (rb.conditioned) join();
-        T2 h1 = gn_apply_res(c1, ab1, ab1 + Co, hcond.p);
+        T2 h1;
+        if (fuse_h1) {
+            h1 = t2(rows, Co);
+            if (h1_c64) {
+                LAUNCH(dawn_xattn_layer_c64_h1(x.p, x.C, x.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x2 ? x2->C : 0, rows, HW, rb.wq, rb.wqs,
+                                               rb.g3, clipf(xt_h1), 1e-5f, c1.p, ab1, ab1 + Co, h1.p, cur));
+            } else {
+                T2 q = ln_gemm(x, x2, rb.wq, 192, rb.wqs, Fr, H, W);
+                LAUNCH(dawn_xattn_sigma_out_h1(q.p, rows, HW, clipf(xt_h1), rb.g3, Co, 1e-5f, c1.p, ab1, ab1 + Co, h1.p, cur));
+                rel(q);
+            }
+        } else {
+            if (rb.conditioned) join();
+            h1 = gn_apply_res(c1, ab1, ab1 + Co, hcond.p);
+        }
         rel(c1); A.free(ab1); A.free(part);
         if (hcond.p) rel(hcond);
         double* part2 = gn_part_alloc(rows, Co);

@@ -50,7 +50,8 @@ __global__ __launch_bounds__(512, (CIN == 64 && !SPLIT) ? 4 : 2) void xattn_c64_
                                                         const float* __restrict__ wq, const unsigned short* __restrict__ wq_s,
                                                         const float* __restrict__ g3,
                                                         const float* __restrict__ xtab, float eps,
-                                                        float* __restrict__ out, long ntiles) {
+                                                        float* __restrict__ out, long ntiles, const float* __restrict__ gn_x,
+                                                        const float* __restrict__ gn_a, const float* __restrict__ gn_b) {
     constexpr int NC = CIN / 8;
     constexpr int WQF = SPLIT ? CIN * 1152 / 4 : (CIN / 4) * 192 * 4;       // floats of LDS taken by the to_q weights
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -257,11 +258,21 @@ __global__ __launch_bounds__(512, (CIN == 64 && !SPLIT) ? 4 : 2) void xattn_c64_
         {
             const __amdgpu_buffer_rsrc_t ro = __builtin_amdgcn_make_buffer_rsrc((void*)(out + t * 32 * CO), 0, 32 * CO * 4, 0x00020000);
             typedef int i32x4 __attribute__((ext_vector_type(4)));
+            // optional: the block's h1 = SiLU(FiLM(GroupNorm(c1))) + h_cond (MT:473-476) straight from this epilogue -- gn_x = c1 rows,
+            // (gn_a, gn_b) = the per-channel coefficients of dawn_gn_finalize: no h_cond tensor, no separate GroupNorm-apply pass
+            const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)((gn_x ? gn_x : out) + t * 32 * CO), 0, 32 * CO * 4, 0x00020000);
 #pragma unroll
             for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
-                    const f32x4 v = {hc[ot][4 * g], hc[ot][4 * g + 1], hc[ot][4 * g + 2], hc[ot][4 * g + 3]};
+                    f32x4 v = {hc[ot][4 * g], hc[ot][4 * g + 1], hc[ot][4 * g + 2], hc[ot][4 * g + 3]};
+                    if (gn_x) {
+                        const int cch = 32 * ot + 8 * g + 4 * half;
+                        const f32x4 c4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, (l31 * CO + cch) * 4, 0, 0));
+                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(gn_a + cch), b4 = *reinterpret_cast<const f32x4*>(gn_b + cch);
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = dawn_silu(c4[j] * a4[j] + b4[j]) + v[j];
+                    }
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, v), ro,
                                                            (l31 * CO + 32 * ot + 8 * g + 4 * half) * 4, 0, 0);
                 }
@@ -323,10 +334,11 @@ extern "C" int dawn_xattn_tables(const float* kvtab, const float* nulltab, const
     return 0;
 }
 
-extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
-                                    int HW, const float* wq, const void* wq_bf3, const float* g3, const float* xtab, float eps,
-                                    float* out, void* stream) {
+extern "C" int dawn_xattn_layer_c64_h1(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
+                                       int HW, const float* wq, const void* wq_bf3, const float* g3, const float* xtab, float eps,
+                                       const float* gn_x, const float* gn_a, const float* gn_b, float* out, void* stream) {
     const int Cin = C0 + C1;
+    if (gn_x && (!gn_a || !gn_b)) return dawn_set_error_msg(-54, "dawn_xattn_layer_c64_h1: gn_x needs gn_a and gn_b");
     if ((Cin != 64 && Cin != 128) || C0 % 8 != 0 || (ld0 % 4) || (in1 && (ld1 % 4)))
         return dawn_set_error_msg(-51, "dawn_xattn_layer_c64: Cin must be 64 or 128 (two sources allowed), Co = 64");
     if (HW % 32 != 0 || rows % 32 != 0)
@@ -350,11 +362,16 @@ extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const flo
     do {                                                                                                                     \
         (void)hipFuncSetAttribute((const void*)xattn_c64_kernel<CINV, SPV>, hipFuncAttributeMaxDynamicSharedMemorySize, lds); \
         hipLaunchKernelGGL((xattn_c64_kernel<CINV, SPV>), dim3((unsigned)grid), dim3(512), lds, s, in0, C0, ld0, in1, ld1, rows, \
-                           HW, wq, (const unsigned short*)wq_bf3, g3, xtab, eps, out, ntiles);                              \
+                           HW, wq, (const unsigned short*)wq_bf3, g3, xtab, eps, out, ntiles, gn_x, gn_a, gn_b);            \
     } while (0)
     if (Cin == 64) { if (split) LAUNCH_XA(64, true); else LAUNCH_XA(64, false); }
     else { if (split) LAUNCH_XA(128, true); else LAUNCH_XA(128, false); }
 #undef LAUNCH_XA
     DAWN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows,
+                                    int HW, const float* wq, const void* wq_bf3, const float* g3, const float* xtab, float eps,
+                                    float* out, void* stream) {
+    return dawn_xattn_layer_c64_h1(in0, C0, ld0, in1, C1, ld1, rows, HW, wq, wq_bf3, g3, xtab, eps, nullptr, nullptr, nullptr, out, stream);
 }

@@ -45,6 +45,7 @@ class HipOps:
         self.conv_policy = 0         # dawn_conv_desc.policy of every conv_gemm launch (0 = shipped kernel policy)
         self.temporal_flags = 0      # kernel-family selector of the fused temporal layer (0 = automatic; A/B and tests)
         self.stream_k = True         # supply the stream-K scratch when conv_policy selects that kernel (bit 0x400; opt-in)
+        self.fuse_h1 = True          # cross-attention kernels write h1 = SiLU(GN(c1)) + h_cond themselves (False: A/B, two-stream form)
         self._sk_ws = {}             # device index -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
         self._sel_ws = {}            # device index -> scratch of the threshold selection (histograms, state)
 
@@ -73,6 +74,7 @@ class HipOps:
         o.conv_policy = self.conv_policy
         o.temporal_flags = self.temporal_flags
         o.stream_k = self.stream_k
+        o.fuse_h1 = self.fuse_h1
         o._sk_ws = self._sk_ws
         o._sel_ws = self._sel_ws
         return o
@@ -301,21 +303,26 @@ class HipOps:
     def can_fuse_xattn_out(Co: int, HW: int) -> bool:
         return Co % 32 == 0 and 32 <= Co <= 512 and HW % 4 == 0
 
-    def xattn_sigma_out(self, q: Tensor, HW: int, xtab: Tensor, g3: Tensor, Co: int, eps: float = 1e-5) -> Tensor:
+    def xattn_sigma_out(self, q: Tensor, HW: int, xtab: Tensor, g3: Tensor, Co: int, eps: float = 1e-5,
+                        gn: Optional[Tuple[Tensor, Tensor, Tensor]] = None) -> Tensor:
         """q (rows,192) = raw to_q output -> h_cond (rows,Co): the 2-key attention, the three to_out projections, their
-        LayerNorms and the branch sum in one pass (per-clip tables `xtab` from xattn_tables)."""
+        LayerNorms and the branch sum in one pass (per-clip tables `xtab` from xattn_tables).  gn = (c1, a, b): returns the block's
+        h1 = SiLU(c1*a + b) + h_cond instead (MT:473-476: no h_cond tensor, no GroupNorm-apply pass)."""
         rows = q.shape[0]
         assert q.is_contiguous() and q.shape[1] == 192 and xtab.is_contiguous() and xtab.shape[1:] == (3, 64 + 9 * Co)
         assert rows == xtab.shape[0] * HW
         self._require(q, xtab, g3)
         out = self.empty(rows, Co, like=q)
-        check(self.L.dawn_xattn_sigma_out(_p(q), rows, HW, _p(xtab), _p(g3), Co, eps, _p(out), self._stream()),
-              "dawn_xattn_sigma_out")
+        gx, ga, gb = gn if gn is not None else (None, None, None)
+        assert gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, Co))
+        self._require(gx, ga, gb)
+        check(self.L.dawn_xattn_sigma_out_h1(_p(q), rows, HW, _p(xtab), _p(g3), Co, eps, _p(gx), _p(ga), _p(gb), _p(out),
+                                             self._stream()), "dawn_xattn_sigma_out")
         return out
 
     def xattn_layer_c64(self, x: Tensor, x2: Optional[Tensor], HW: int, wq: Tensor, wo, g3: Tensor, q_scale: Tensor,
                         kvtab: Tensor, nulltab: Tensor, eps: float = 1e-5, xtab: Optional[Tensor] = None,
-                        wq_bf3: Optional[Tensor] = None) -> Tensor:
+                        wq_bf3: Optional[Tensor] = None, gn: Optional[Tuple[Tensor, Tensor, Tensor]] = None) -> Tensor:
         """h_cond (rows,64) = sum over the three branches of LN(to_out(attn(LN(x)))) in one launch.  The kernel reads
         the per-clip tables `xtab` (xattn_tables of kvtab / nulltab / q_scale / wo); built here if not supplied.
         `wq_bf3` (pack_bf3 of to_q) puts the Q projection on the bf16 matrix pipe (exact operand split)."""
@@ -325,9 +332,12 @@ class HipOps:
         self._require(x, x2, wq, g3, xtab)
         assert xtab.is_contiguous() and xtab.shape[1:] == (3, 640) and rows == xtab.shape[0] * HW
         out = self.empty(rows, 64, like=x)
-        check(self.L.dawn_xattn_layer_c64(_p(x), x.shape[1], _ld(x), _p(x2), 0 if x2 is None else x2.shape[1], _ld(x2),
-                                          rows, HW, _p(wq), _p(wq_bf3), _p(g3), _p(xtab), eps, _p(out), self._stream()),
-              "dawn_xattn_layer_c64")
+        gx, ga, gb = gn if gn is not None else (None, None, None)       # (c1, a, b): write h1 = SiLU(c1*a + b) + h_cond instead of h_cond
+        assert gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, 64))
+        self._require(gx, ga, gb)
+        check(self.L.dawn_xattn_layer_c64_h1(_p(x), x.shape[1], _ld(x), _p(x2), 0 if x2 is None else x2.shape[1], _ld(x2),
+                                             rows, HW, _p(wq), _p(wq_bf3), _p(g3), _p(xtab), eps, _p(gx), _p(ga), _p(gb), _p(out),
+                                             self._stream()), "dawn_xattn_layer_c64")
         return out
 
     # ------------------------------------------------------------------ attention cores

@@ -106,14 +106,18 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     g = dict(F=F, Hi=H, Wi=W)
     hcond, film = None, None
 
-    def cross_attention():
-        if ops.can_fuse_xattn(rb.Cin, Co, x.shape[1], H * W) and cs.xtab[rb.cond_index] is not None:
+    fused_c64 = ops.can_fuse_xattn(rb.Cin, Co, x.shape[1], H * W) and rb.conditioned and cs.xtab[rb.cond_index] is not None
+    fused_out = ops.can_fuse_xattn_out(Co, H * W) and rb.conditioned and cs.xtab[rb.cond_index] is not None
+
+    def cross_attention(gn=None):
+        """h_cond -- or, with gn = (c1, a, b), the block's h1 = SiLU(GN(c1)) + h_cond straight from the kernel's epilogue."""
+        if fused_c64:
             return ops.xattn_layer_c64(x, x2, H * W, rb.wq, rb.wo, rb.g3, rb.q_scale, cs.kvtab[rb.cond_index],
-                                       cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index], wq_bf3=rb.wqs)
+                                       cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index], wq_bf3=rb.wqs, gn=gn)
         # LayerNorm_img is materialised (one streaming pass) so that to_q runs as a prologue-free GEMM
         q = _ln_gemm(ops, x, x2, rb.wq, 192, rb.wqs, **g)
-        if ops.can_fuse_xattn_out(Co, H * W) and cs.xtab[rb.cond_index] is not None:
-            return ops.xattn_sigma_out(q, H * W, cs.xtab[rb.cond_index], rb.g3, Co)
+        if fused_out:
+            return ops.xattn_sigma_out(q, H * W, cs.xtab[rb.cond_index], rb.g3, Co, gn=gn)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)
         y3 = ops.empty(F * H * W, 3 * Co, like=x)
         for b in range(3):
@@ -127,17 +131,26 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
         c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, gn_part=part, w_bf3=rb.w1s, **g)
         return c, ops.gn_coeffs(c, rb.g1, rb.be1, film, total_rows, part=part)
 
+    h1 = None
     if rb.conditioned:
         film = (film_all[rb.film_off:rb.film_off + Co], film_all[rb.film_off + Co:rb.film_off + 2 * Co])
-        # the HBM-bound cross-attention chain and the MFMA-bound conv1 + GroupNorm statistics only meet at
-        # h1 = SiLU(GN(c1)) + h_cond: run them on two HIP streams so that they overlap on the GPU
-        hcond, (c1, ab1) = ops.fork_join(cross_attention, conv1_and_stats)
+        if (fused_c64 or fused_out) and getattr(ops, "fuse_h1", True):
+            # conv1 + statistics first, then the cross-attention kernel writes h1 = SiLU(FiLM(GN(c1))) + h_cond from its epilogue:
+            # no h_cond tensor, no GroupNorm-apply pass (20 launches and 0.42 GB per level-0 block less per evaluation).  The
+            # two-stream overlap this replaces bought nothing on a power-limited chip (profiles/r3_*: 145.4 vs 140 frames/s without it)
+            c1, ab1 = conv1_and_stats()
+            h1 = cross_attention(gn=(c1, ab1[0], ab1[1]))
+        else:
+            # the HBM-bound cross-attention chain and the MFMA-bound conv1 + GroupNorm statistics only meet at
+            # h1 = SiLU(GN(c1)) + h_cond: run them on two HIP streams so that they overlap on the GPU
+            hcond, (c1, ab1) = ops.fork_join(cross_attention, conv1_and_stats)
     else:
         c1, ab1 = conv1_and_stats()
     # h1 = SiLU(FiLM(GN(c1))) + h_cond is materialised once (one streaming pass) instead of being fused into
     # the 3x3 loader: an implicit GEMM reads every input element 9x, and 9x exp/div per element cost the conv
     # ~35 % of its MFMA rate (profiles/r1_b_conv_shapes.txt) -- far more than the extra 3 x C x 4 B per pixel.
-    h1 = ops.gn_apply_res(c1, ab1[0], ab1[1], hcond)
+    if h1 is None:
+        h1 = ops.gn_apply_res(c1, ab1[0], ab1[1], hcond)
     part2 = ops.conv_gn_part(F * H * W, Co, x)
     c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, w_bf3=rb.w2s, **g)
     a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows, part=part2)

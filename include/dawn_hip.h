@@ -128,6 +128,8 @@ int dawn_xattn_tables(const float* kvtab, const float* nulltab, const float* q_s
 /* Levels without the fused kernel (Co = 128 / 256 / 512; any Co % 32 == 0 up to 512, H*W % 4 == 0): everything after the
  * Q projection in one pass -- q (rows,192) raw to_q output, xtab (F,3,64+9*Co) from dawn_xattn_tables, g3 (3,Co):
  * out[row][:] = sum_b LN(y0_b + sum_h sigma_bh u_bh) * g3[b]   ==   dawn_xattn_core + 3 x to_out + dawn_xattn_ln_sum. */
+int dawn_xattn_sigma_out_h1(const float* q, long rows, int HW, const float* xtab, const float* g3, int Co, float eps,
+                            const float* gn_x, const float* gn_a, const float* gn_b, float* out, void* stream);   /* same, gn_x (rows, Co) */
 int dawn_xattn_sigma_out(const float* q, long rows, int HW, const float* xtab, const float* g3, int Co, float eps,
                          float* out, void* stream);
 /* Fused cross-attention branch for Co = 64, Cin in {64, 128} (two sources allowed), H*W % 32 == 0:
@@ -135,6 +137,11 @@ int dawn_xattn_sigma_out(const float* q, long rows, int HW, const float* xtab, c
  * wq packed (Cin -> 192, LayerNorm gains folded), g3 (3,64), xtab (F,3,640) from dawn_xattn_tables.
  * wq_bf3 (optional): the exact 3-way bf16 split of wq, [Cin/16][3][2][192][8] (pack_bf3 order): to_q then runs on the bf16
  * matrix pipe (fp32 results, 6 cross terms); NULL = fp32-MFMA projection. */
+/* ... and the block's h1 = SiLU(FiLM(GroupNorm(c1))) + h_cond (MT:473-476) written straight from the epilogue: gn_x = c1 (rows, 64),
+ * (gn_a, gn_b) = the per-channel coefficients of dawn_gn_finalize -- no h_cond tensor and no dawn_gn_apply_res pass (NULL: h_cond) */
+int dawn_xattn_layer_c64_h1(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows, int HW,
+                            const float* wq, const void* wq_bf3, const float* g3, const float* xtab, float eps, const float* gn_x,
+                            const float* gn_a, const float* gn_b, float* out, void* stream);
 int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows, int HW,
                          const float* wq, const void* wq_bf3, const float* g3, const float* xtab, float eps, float* out,
                          void* stream);

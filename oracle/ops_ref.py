@@ -184,7 +184,7 @@ class RefOps:
     def can_fuse_xattn_out(Co, HW):
         return Co % 32 == 0 and 32 <= Co <= 512 and HW % 4 == 0
 
-    def xattn_sigma_out(self, q, HW, xtab, g3, Co, eps=1e-5):
+    def xattn_sigma_out(self, q, HW, xtab, g3, Co, eps=1e-5, gn=None):
         """Reference of the one-pass kernel, evaluated from the per-clip tables (the tables themselves are checked
         against the definitions by test_xattn_tables, the whole chain against the original formulation by
         test_xattn_sigma_out_equals_unfused_chain)."""
@@ -199,7 +199,8 @@ class RefOps:
         y = y0[:, None] + torch.einsum("fpbh,fbhc->fpbc", sig, U)
         mean = y.mean(-1, keepdim=True)
         var = y.var(-1, unbiased=False, keepdim=True)
-        return ((y - mean) * torch.rsqrt(var + eps) * g3[None, None]).sum(2).reshape(rows, Co)
+        out = ((y - mean) * torch.rsqrt(var + eps) * g3[None, None]).sum(2).reshape(rows, Co)
+        return out if gn is None else F_.silu(gn[0] * gn[1] + gn[2]) + out        # h1 = SiLU(GN(c1)) + h_cond (MT:473-476)
 
     def xattn_tables(self, kvtab, nulltab, q_scale, wo, Co):
         """[D | u_0..u_7 | y0] per (frame, branch), written from the definitions (fp64)."""
@@ -216,7 +217,7 @@ class RefOps:
             out[:, b, 64 + 8 * Co:] = y0[None]
         return out.float().to(kvtab.device)
 
-    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5, xtab=None, wq_bf3=None):
+    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5, xtab=None, wq_bf3=None, gn=None):
         """The ORIGINAL formulation (MT:516-559 op by op); `xtab` (the kernel's per-clip tables) is not used here, so the
         GPU test of the fused kernel also proves the table algebra."""
         rows = x.shape[0]
@@ -226,7 +227,8 @@ class RefOps:
         y3 = torch.zeros(rows, 192, device=x.device)
         for b in range(3):
             self.conv_gemm(q[:, 64 * b:64 * b + 64], wo[b], 64, F=rows, Hi=1, Wi=1, out=y3[:, 64 * b:64 * b + 64])
-        return self.xattn_ln_sum(y3, g3, 64, eps)
+        out = self.xattn_ln_sum(y3, g3, 64, eps)
+        return out if gn is None else F_.silu(gn[0] * gn[1] + gn[2]) + out
 
     # ------------------------------------------------------------------ attention cores
     def temporal_attn(self, qkv, Fext, HW, q0, Fq, win, rcos, rsin, band):

@@ -549,6 +549,38 @@ def test_xattn_sigma_out_equals_unfused_chain(hip, ref, Co, Fn, HW):
     check(f"xattn_sigma_out/Co{Co}_vs_table_ref", got, ref.xattn_sigma_out(q, HW, ref.xattn_tables(kvtab, nulltab, qs, wo, Co), g3, Co), 3e-5)
 
 
+@pytest.mark.parametrize("Co,C0,Fn,HW", [(64, 64, 3, 64), (64, 128, 2, 96), (128, 128, 3, 1024), (512, 512, 5, 16)])
+def test_xattn_h1_epilogue(hip, ref, Co, C0, Fn, HW):
+    """The cross-attention kernels writing h1 = SiLU(c1*a + b) + h_cond from their epilogue == h_cond followed by the
+    GroupNorm-apply pass (dawn_gn_apply_res), for the fused Co = 64 kernel and the one-pass kernel after to_q."""
+    rows = Fn * HW
+    g3, qs = rnd(3, Co, seed=4) * 0.2 + 1, rnd(3, 8, seed=5) * 0.2 + 1
+    kvtab, nulltab = torch.zeros(Fn, 3, 128), torch.zeros(3, 16)
+    for b in range(3):
+        ref.xattn_prep(rnd(Fn, 128, seed=20 + b), rnd(8, seed=30 + b) * 0.2 + 1, rnd(2, 8, seed=40 + b), kvtab, b, nulltab)
+    wo = [packw(64, Co, seed=10 + b) for b in range(3)]
+    c1, ga, gb = rnd(rows, Co, seed=7) * 1.5, rnd(Co, seed=8) * 0.3 + 1, rnd(Co, seed=9) * 0.3
+    xtab = hip.xattn_tables(kvtab.cuda(), nulltab.cuda(), qs.cuda(), [w.cuda() for w in wo], Co)
+    gn = (c1.cuda(), ga.cuda(), gb.cuda())
+    if Co == 64:
+        from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
+        x = rnd(rows, C0, seed=1) * 1.5 + 0.3
+        wq = packw(C0, 192, seed=3)
+        for bf3 in (None, pack_bf3(unpack_kn(wq)).cuda()):
+            kw = dict(xtab=xtab, wq_bf3=bf3)
+            hc = hip.xattn_layer_c64(x.cuda(), None, HW, wq.cuda(), None, g3.cuda(), None, None, None, **kw)
+            h1 = hip.xattn_layer_c64(x.cuda(), None, HW, wq.cuda(), None, g3.cuda(), None, None, None, gn=gn, **kw)
+            check(f"xattn_h1/c64_C{C0}_split{int(bf3 is not None)}", h1, hip.gn_apply_res(*gn, hc), 2e-6)
+        want = ref.xattn_layer_c64(x, None, HW, wq, wo, g3, qs, kvtab, nulltab, gn=(c1, ga, gb))
+        check(f"xattn_h1/c64_C{C0}_vs_ref", h1, want, 3e-5)
+    else:
+        q = rnd(rows, 192, seed=1) * 1.3
+        hc = hip.xattn_sigma_out(q.cuda(), HW, xtab, g3.cuda(), Co)
+        h1 = hip.xattn_sigma_out(q.cuda(), HW, xtab, g3.cuda(), Co, gn=gn)
+        check(f"xattn_h1/sigma_out_Co{Co}", h1, hip.gn_apply_res(*gn, hc), 2e-6)
+        check(f"xattn_h1/sigma_out_Co{Co}_vs_ref", h1, ref.xattn_sigma_out(q, HW, ref.xattn_tables(kvtab, nulltab, qs, wo, Co), g3, Co, gn=(c1, ga, gb)), 3e-5)
+
+
 def test_xattn_layer_c64_rejects_straddling_tiles(hip):
     """H*W not a multiple of 32 (a pixel tile would straddle two frames' tables): the op refuses, the orchestration
     (`can_fuse_xattn`) takes the unfused chain instead."""
