@@ -36,14 +36,15 @@ namespace {
 // default: in isolation it takes 6..16 % off the 128..512-channel levels, inside the benchmark it is 3..5 % slower end to end --
 // the chip is power-limited in these kernels (profiles/r3_conv_power_by_data.txt, r3_mfma_power_ubench.txt), so cycles saved by
 // the schedule come back as a lower clock for everything that follows.
+// 0x1000000 (shipped): conv3x3_bf16_v2_kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction).
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
 // split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
-constexpr int DAWN_CONV_POLICY_DEFAULT = 0x580D;
+constexpr int DAWN_CONV_POLICY_DEFAULT = 0x100580D;
 #ifdef DAWN_ABLATION
-constexpr int DAWN_CONV_POLICY_MASK = 0x000FFFFF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x010FFFFF;
 #else
-constexpr int DAWN_CONV_POLICY_MASK = 0x00F3FFCF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x01F3FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
@@ -1062,8 +1063,16 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_
 //    instructions with no branches and no 64-bit address arithmetic.
 // (measured with the s_memtime build, tools/conv_phase_timing.py: per chunk the first version spent 3 x 1650 cycles
 //  issuing loads and 2400 in the split pass next to 3 x 2300 cycles of MFMA.)
-template <int WN, int NT, int ABL>
-__global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_conv_desc d, const int xcd_remap,
+//
+// K32 (round 3): the same kernel on v_mfma_f32_16x16x32_bf16.  The split kernels are POWER-limited (profiles/r3_mfma_power_ubench.txt),
+// and the 16x16x32 shape spends ~11 % less energy per flop than 32x32x16 on the same operand data (half the accumulator traffic
+// per flop).  Its K = 32 is filled from ONE 16-channel chunk by giving the two k-halves of an instruction two different cross
+// terms: lanes 0..31 (k-groups 0, 1) and lanes 32..63 (k-groups 2, 3) read different split planes, so with
+//   X1 = [x1 | x2], X2 = [x3 | x1] (pixels)   W1 = [w1 | w2], W2 = [w3 | w1] (weights)
+// the three products X2.W1 = x3 w1 + x1 w2, X1.W2 = x1 w3 + x2 w1, X1.W1 = x1 w1 + x2 w2 are exactly the 6 cross terms: 3 half-size
+// MFMAs per 16 x 16 block instead of 6 full-size ones per 32 x 32, 16 fragment reads per tap instead of 12, same LDS layout.
+template <int WN, int NT, int ABL, bool K32 = false>
+__global__ __launch_bounds__(256 * WN, K32 ? 2 / WN : 1) void conv3x3_bf16_v2_kernel(const dawn_conv_desc d, const int xcd_remap,
                                                                     const int TR, const int nf, const int P16,
                                                                     const int WT, const int stagger) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; buffer-resource builtins are device-only)
@@ -1160,6 +1169,24 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
         const int ty = (int)(((float)rem + 0.5f) * rW), x = rem - ty * WT;
         pc[i] = fi * PP + (ty + 1) * PW + (x + 1);
     }
+    // K32: lane = (pixel | channel l15 of a 16-block, k-group kg); k-groups 0,1 = the two k-halves of the FIRST term of an MFMA,
+    // 2,3 = of the second.  Byte offsets of this lane's fragments: pixels X1 = [x1|x2], X2 = [x3|x1]; weights W1 = [w1|w2], W2 = [w3|w1]
+    const int l15 = lane & 15, kg = lane >> 4, kh = kg & 1, ks = kg >> 1;
+    int px1[4], dpx = 0, wo1 = 0, wo2 = 0;                // X2 fragment = X1 fragment + dpx bytes (another plane)
+    if constexpr (K32) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int r = wm * 64 + b * 16 + l15;
+            const int fi = (int)(((float)r + 0.5f) * rTW);
+            const int rem = r - fi * TR * WT;
+            const int ty = (int)(((float)rem + 0.5f) * rW), x = rem - ty * WT;
+            const int pcb = (fi * PP + (ty + 1) * PW + (x + 1)) * 16;
+            px1[b] = ((ks ? 1 : 0) * 2 + kh) * HPS + pcb;
+        }
+        dpx = (ks ? -2 : 4) * HPS;
+        wo1 = (((ks ? 1 : 0) * 2 + kh) * BN + wn * 64 + l15) * 16;
+        wo2 = (((ks ? 0 : 2) * 2 + kh) * BN + wn * 64 + l15) * 16;
+    }
     // weight DMA lane offsets (bytes) within a (chunk cc, kernel row ky) stage
     unsigned voffB[NBJ];
 #pragma unroll
@@ -1217,6 +1244,11 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    f32x4 acq[4][4];                                    // K32: [pixel block][channel block], lane = pixel l15, channels 4 kg + 0..3
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acq[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     TSTAMP();   // 1: index math done
     issueB(0, 0, 0);
@@ -1248,6 +1280,58 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
             }
             TSTAMP();   // stage: loads issued
             const unsigned char* Bb = Bs + (size_t)bufB * SB;
+            if constexpr (K32) {
+                const int yoff = (ky - 1) * PW * 16 - 16;           // taps kx = 0..2 are +0 / +16 / +32 bytes from here
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    // pixel fragments of the 4 pixel blocks for the whole tap (32 VGPRs), weight fragments one 16-channel block ahead
+                    // (16 VGPRs); per channel block the three products in the order smallest first, each weight fragment held as the A
+                    // operand of four consecutive MFMAs
+                    bf16x8 fx1[4], fx2[4], fw1[2], fw2[2];
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) fx2[b] = *reinterpret_cast<const bf16x8*>(planes + px1[b] + (dpx + yoff) + kx * 16);
+                    fw1[0] = *reinterpret_cast<const bf16x8*>(Bb + wo1 + (kx * 6 * BN) * 16);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b) fx1[b] = *reinterpret_cast<const bf16x8*>(planes + px1[b] + yoff + kx * 16);
+                    fw2[0] = *reinterpret_cast<const bf16x8*>(Bb + wo2 + (kx * 6 * BN) * 16);
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        const int c = cb & 1, n = c ^ 1;
+                        if (cb < 3) {
+                            fw1[n] = *reinterpret_cast<const bf16x8*>(Bb + wo1 + (kx * 6 * BN + (cb + 1) * 16) * 16);
+                            fw2[n] = *reinterpret_cast<const bf16x8*>(Bb + wo2 + (kx * 6 * BN + (cb + 1) * 16) * 16);
+                        }
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acq[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[c], fx2[b], acq[b][cb], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acq[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw2[c], fx1[b], acq[b][cb], 0, 0, 0);
+#pragma unroll
+                        for (int b = 0; b < 4; ++b) acq[b][cb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw1[c], fx1[b], acq[b][cb], 0, 0, 0);
+                    }
+                    if (more && ky > 0) {
+#pragma unroll
+                        for (int i = 0; i < MAXQ; ++i) {
+                            const bool mine = ky == 1 ? i < L0 : i >= L0;
+                            const int ord = ky == 1 ? i : i - L0;
+                            if (mine && ord % 3 == kx) convA(i);
+                        }
+                    }
+                    __builtin_amdgcn_sched_group_barrier(0x100, 10, 0);           // X2, W1[0], X1, W2[0] first
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb) {
+                        if (cb < 3) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                            __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);    // the next channel block's weight fragments
+                            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                        }
+#pragma unroll
+                        for (int t = cb < 3 ? 1 : 0; t < 12; ++t) {
+                            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);    // MFMA, 1 VALU (split), MFMA, ...
+                            __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+                        }
+                    }
+                }
+            } else {
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
                 const int toff = (ky - 1) * PW + (kx - 1);
@@ -1292,6 +1376,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
                     }
                 }
             }
+            }
             TSTAMP();   // stage: MFMAs issued
             if (ky < 2) {
                 // (the register operands pin the split of these quads behind the wait)
@@ -1329,6 +1414,48 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
     for (int j = 0; j < TN; ++j)
 #pragma unroll
         for (int g = 0; g < 4; ++g) { gs[j][g] = 0.f; gss[j][g] = 0.f; }
+    if constexpr (K32) {
+        // lane = output pixel l15 of a 16-pixel block, registers = channels 16 cb + 4 kg + {0..3}: 16-byte row segments, 4 lanes
+        // cover the 64 contiguous bytes of a pixel's 16-channel block.  The lane's GroupNorm partials belong to the 8-channel
+        // subgroup 2 cb + (kg >> 1) of the wave's 64 channels; the other subgroup of the pair gets a zero from this lane
+        // (columns of the block reduction below: j = cb >> 1, g = 2 (cb & 1) + {0, 1}).
+        long mrq[4];
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            const int r = wm * 64 + b * 16 + l15;
+            const int fi = (int)(((float)r + 0.5f) * rTW);
+            const int rem = r - fi * TR * WT;
+            const int ty = (int)(((float)rem + 0.5f) * rW), x = rem - ty * WT;
+            mrq[b] = ((long)(f0 + fi) * H + y0 + ty) * W + x0 + x;
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int n = n0 + wn * 64 + cb * 16 + 4 * kg;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
+            float sv = 0.f, sq = 0.f;
+#pragma unroll
+            for (int b = 0; b < 4; ++b) {
+                const long m = mrq[b];
+                f32x4 v = acq[b][cb] + bv;
+                if (d.res) v = v + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
+                if (d.tr) {
+                    const f32x4 t4 = *reinterpret_cast<const f32x4*>(d.tr + m * d.ld_tr + n);
+                    const f32x4 ta = *reinterpret_cast<const f32x4*>(d.tr_a + n), tb = *reinterpret_cast<const f32x4*>(d.tr_b + n);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] += dawn_silu(t4[e] * ta[e] + tb[e]);
+                }
+                *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n) = v;
+                sv += (v.x + v.y) + (v.z + v.w);
+                sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+            const int up = kg >> 1;
+            gs[cb >> 1][2 * (cb & 1)] = up ? 0.f : sv;
+            gs[cb >> 1][2 * (cb & 1) + 1] = up ? sv : 0.f;
+            gss[cb >> 1][2 * (cb & 1)] = up ? 0.f : sq;
+            gss[cb >> 1][2 * (cb & 1) + 1] = up ? sq : 0.f;
+        }
+    } else {
     long mrow[TM];                                      // output pixel (row of the (M, N) result) of this lane
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -1361,6 +1488,7 @@ __global__ __launch_bounds__(256 * WN) void conv3x3_bf16_v2_kernel(const dawn_co
                 gss[j][g] += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
         }
+    }
     }
     TSTAMP();   // stores issued
     if (d.gn_part) {
@@ -1433,15 +1561,21 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     // isolation it takes 8..11 % off the 64-input-channel launches (354 -> 316..328 us, profiles/r2_conv_stagger.txt) and nothing
     // off deeper K; inside an evaluation, next to the side stream's kernels, it changes nothing (385.4 vs 384.5 us): off
     const int stagger = nwg >= 1024 ? ((policy_of(d) >> 20) & 15) : 0;
-#define LAUNCH_V2(NTV, ABLV)                                                                                          \
+#define LAUNCH_V2K(NTV, ABLV, K32V)                                                                                   \
     do {                                                                                                              \
-        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_v2_kernel<WN, NTV, ABLV>,                                 \
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_v2_kernel<WN, NTV, ABLV, K32V>,                           \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                              \
-        hipLaunchKernelGGL((conv3x3_bf16_v2_kernel<WN, NTV, ABLV>), dim3(nwg), dim3(256 * WN), lds, s, d, remap, TR, nf, \
+        hipLaunchKernelGGL((conv3x3_bf16_v2_kernel<WN, NTV, ABLV, K32V>), dim3(nwg), dim3(256 * WN), lds, s, d, remap, TR, nf, \
                            P16, WT, stagger);                                                                         \
     } while (0)
+#define LAUNCH_V2(NTV, ABLV) LAUNCH_V2K(NTV, ABLV, false)
     if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     if (nine) LAUNCH_V2(9, 0);
+    // 16x16x32 form: less energy per flop, more instructions -- inside an evaluation -2.4..-5.6 % per launch wherever the grid keeps
+    // the chip busy (power-limited), +4..6 % on the four under-filled launches of the deepest level (100 workgroups;
+    // profiles/r3_k32_shapes.txt).  Chosen by the policy alone, never by the grid size: a frame computes the same bits whatever
+    // the batch it is launched in
+    else if (policy_of(d) & 0x1000000) LAUNCH_V2K(6, 0, true);
 #ifdef DAWN_ABLATION
     else if (timing) LAUNCH_V2(6, 8);
     else if (((policy_of(d) >> 16) & 15) == 1) LAUNCH_V2(6, 1);
@@ -1451,6 +1585,7 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
 #endif
     else LAUNCH_V2(6, 0);
 #undef LAUNCH_V2
+#undef LAUNCH_V2K
     return true;
 }
 

@@ -77,10 +77,11 @@ int dawn_conv_gemm_nblocks(long M, int N);
 size_t dawn_conv_sk_workspace_bytes(void);
 int dawn_conv_sk_workspace_init(void* ws, void* stream);
 int dawn_conv_sk_check(const void* ws, void* stream);
-/* dawn_conv_desc.policy bits (0 = shipped policy 0x580D; per call, no process-global state): bit0 BK=32 tiles,
+/* dawn_conv_desc.policy bits (0 = shipped policy 0x100580D; per call, no process-global state): bit0 BK=32 tiles,
  * bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel,
  * 0x1000 split-operand (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000
- * second-generation split 3x3 kernel, 0x400 its persistent stream-K variant (opt-in; needs dawn_conv_desc.sk_ws).  Every combination computes the same function (tests run the kernel families
+ * second-generation split 3x3 kernel, 0x1000000 that kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction: less energy per
+ * flop on a power-limited chip), 0x400 its persistent stream-K variant (opt-in; needs dawn_conv_desc.sk_ws).  Every combination computes the same function (tests run the kernel families
  * against each other); perf-ablation / s_memtime builds exist only under -DDAWN_ABLATION (tools/build_timing_lib.sh). */
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --

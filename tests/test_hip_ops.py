@@ -116,10 +116,10 @@ def test_conv_gemm(hip, ref, case):
     if k == 3 and C0 % 16 == 0 and C1 % 16 == 0:
         from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
         kw["w_bf3"] = pack_bf3(unpack_kn(w)).cuda()
-        for variant in (14349, 30733, 6157, 22541):           # split-operand bf16 MFMA: 9 / 6 terms, v1 / v2 kernels
+        for variant in (14349, 30733, 6157, 22541, 22541 | 0x1000000):   # split-operand bf16 MFMA: 9 / 6 terms, v1 / v2 kernels, v2 on 16x16x32
             hip.conv_policy = variant
             _conv_case(hip, name + f"/v{variant}", in0, in1, w, N, kw, want)
-    hip.conv_policy = 22541                        # shipped policy (left active)
+    hip.conv_policy = 0                            # shipped policy (left active)
 
 
 def _conv_case(hip, name, in0, in1, w, N, kw, want):
@@ -170,7 +170,7 @@ def test_conv3x3_stream_k(hip, ref, case):
     x0g, x1g, wg = in0.cuda(), None if in1 is None else in1.cuda(), w.cuda()
     try:
         outs = []
-        for variant in (0x5C0D | (leave << 20), 0x5C0D | 0x200 | (leave << 20), 0x580D):   # stream-K, without the pair offset, v2
+        for variant in (0x5C0D | (leave << 20), 0x5C0D | 0x200 | (leave << 20), 0x580D, 0x580D | 0x1000000):   # stream-K, without the pair offset, v2, v2 on 16x16x32
             hip.conv_policy = variant
             part = hip.conv_gn_part(rows, N, x0g) if ex.get("gn") else None
             got = hip.conv_gemm(x0g, wg, N, in1=x1g, gn_part=part, **gkw)
@@ -188,6 +188,7 @@ def test_conv3x3_stream_k(hip, ref, case):
         assert torch.equal(again, outs[0])                                    # fixed summation order
         scale = max(1.0, float(want.abs().max()))
         assert float((outs[0] - outs[2]).abs().max()) <= 2e-5 * scale         # vs the v2 kernel: fp32 rounding only
+        assert float((outs[3] - outs[2]).abs().max()) <= 2e-5 * scale         # the 16x16x32 form of the v2 kernel: likewise
         hip.sk_check()
         ws = hip.sk_workspace(x0g)
         assert int(ws[:4096].view(torch.int32).abs().sum()) == 0              # every published partial was consumed
@@ -204,7 +205,7 @@ def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
     gamma, beta = rnd(N, seed=4) * 0.2 + 1, rnd(N, seed=5) * 0.2
     from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
     ws = pack_bf3(unpack_kn(w)).cuda() if C0 % 16 == 0 else None
-    for variant in (5, 525, 13, 2061, 6157, 22541):
+    for variant in (5, 525, 13, 2061, 6157, 22541, 22541 | 0x1000000):
         hip.conv_policy = variant
         xg = x.cuda()
         part = hip.conv_gn_part(rows, N, xg)
@@ -230,18 +231,20 @@ def test_conv_bf16_split_is_fp32_accurate(hip, ref):
     w4 = wkn.reshape(3, 3, Cc, N).permute(3, 2, 0, 1)
     want = F_.conv2d(x.double().reshape(F, H, W, Cc).permute(0, 3, 1, 2), w4, padding=1).permute(0, 2, 3, 1).reshape(rows, N)
     errs = {}
+    K32 = 22541 | 0x1000000
     for variant, ws in ((2061, None), (6157, pack_bf3(unpack_kn(w)).cuda()), (14349, pack_bf3(unpack_kn(w)).cuda()),
-                        (22541, pack_bf3(unpack_kn(w)).cuda())):
+                        (22541, pack_bf3(unpack_kn(w)).cuda()), (K32, pack_bf3(unpack_kn(w)).cuda())):
         hip.conv_policy = variant
         got = hip.conv_gemm(x.cuda(), w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, w_bf3=ws)
         torch.cuda.synchronize()
         errs[variant] = float((got.cpu().double() - want).abs().max() / want.abs().max())
     with open(LOG, "a") as f:
         f.write(json.dumps({"op": "conv_bf16_split/rel_err_vs_fp64", "fp32_mfma": errs[2061], "bf16x6": errs[6157],
-                            "bf16x9": errs[14349], "bf16x6_v2": errs[22541]}) + "\n")
-    hip.conv_policy = 22541
+                            "bf16x9": errs[14349], "bf16x6_v2": errs[22541], "bf16x6_v2_16x16x32": errs[K32]}) + "\n")
+    hip.conv_policy = 0
     assert errs[6157] <= 2.0 * errs[2061] + 1e-7, errs
     assert errs[22541] <= 2.0 * errs[2061] + 1e-7, errs
+    assert errs[K32] <= 2.0 * errs[2061] + 1e-7, errs
     assert errs[14349] <= 2.0 * errs[2061] + 1e-7, errs
 
 
@@ -345,7 +348,7 @@ def test_gemm1x1_split_variants(hip, ref, M, C0, C1, N, extra):
     # and it is the split kernel's accuracy class: no worse than the fp32 MFMA path against fp64
     hip.conv_policy = 2061
     got32 = hip.conv_gemm(x0.cuda(), w.cuda(), N, in1=None if x1 is None else x1.cuda(), **gkw)
-    hip.conv_policy = 22541
+    hip.conv_policy = 0
     e_split, e_f32 = float((got.cpu() - want).abs().max()), float((got32.cpu() - want).abs().max())
     assert e_split <= 2.0 * e_f32 + 1e-5 * max(1.0, float(want.abs().max())), (e_split, e_f32)
 

@@ -19,6 +19,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE>   // 0 = one operand pair, 1 = 8 rotating register sets, 2 = rotating + operands re-read from LDS
 __global__ __launch_bounds__(256, 2) void k(const u32x4* __restrict__ src, float* out, int iters) {
@@ -49,6 +50,53 @@ __global__ __launch_bounds__(256, 2) void k(const u32x4* __restrict__ src, float
                 for (int i = 0; i < 4; ++i)
                     acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[(t + (i >> 1)) % 6]),
                                                                      __builtin_bit_cast(bf16x8, fa[(t + (i & 1)) % 6]), acc[i], 0, 0, 0);
+        } else if (MODE == 6) {
+            // 16x16x32 with the conv kernels' LDS ratio: a 64 x 64 wave tile per K = 32 step = 12 A + 12 B fragment reads per 96 MFMAs
+            f32x4* a4 = reinterpret_cast<f32x4*>(acc);
+#pragma unroll
+            for (int rep = 0; rep < 2; ++rep) {
+                u32x4 fa[6], fb[6];
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    fa[s] = lds[(((it + s + rep) & 7) * 2) * 256 + threadIdx.x];
+                    fb[s] = lds[(((it + s + rep) & 7) * 2 + 1) * 256 + threadIdx.x];
+                }
+#pragma unroll
+                for (int t = 0; t < 3; ++t)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i)
+                        a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, fb[(t + (i >> 2)) % 6]),
+                                                                        __builtin_bit_cast(bf16x8, fa[(t + (i & 3)) % 6]), a4[i], 0, 0, 0);
+            }
+        } else if (MODE == 5) {
+            // the 16x16x32 shape (half the flops per instruction, same rate): 48 per iteration = the same flops as 24 32x32x16
+            f32x4* a4 = reinterpret_cast<f32x4*>(acc);
+#pragma unroll
+            for (int t = 0; t < 6; ++t)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int s = (t * 8 + i) & 7;
+                    a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, rb[s]), __builtin_bit_cast(bf16x8, ra[(s + t) & 7]),
+                                                                    a4[i], 0, 0, 0);
+                }
+        } else if (MODE == 3) {
+            // rot, but the 6 MFMAs of an accumulator back to back (dependent chain: does accumulator forwarding save power?)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int t = 0; t < 6; ++t) {
+                    const int s = (t * 4 + i) & 7;
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb[s]), __builtin_bit_cast(bf16x8, ra[(s + t) & 7]),
+                                                                     acc[i], 0, 0, 0);
+                }
+        } else if (MODE == 4) {
+            // rot, A operand held for 3 consecutive MFMAs (3 accumulators), B changes: operand-latch reuse
+#pragma unroll
+            for (int t = 0; t < 8; ++t)
+#pragma unroll
+                for (int i = 0; i < 3; ++i)
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, rb[t]), __builtin_bit_cast(bf16x8, ra[(t + i) & 7]),
+                                                                     acc[i], 0, 0, 0);
         } else {
 #pragma unroll
             for (int t = 0; t < 6; ++t)
@@ -128,5 +176,11 @@ int main() {
     run<1>("rot-3p (8 rotating sets, split planes x1/x2/x3)", p3, iters);
     run<2>("+lds   (split planes re-read from LDS, 12 reads / 24 MFMAs)", p3, iters);
     run<2>("+lds   (zeros re-read from LDS)", zero, iters);
+    run<3>("rot-3p, 6 MFMAs per accumulator back to back", p3, iters);
+    run<4>("rot-3p, A held for 3 consecutive MFMAs", p3, iters);
+    run<5>("rot-3p on v_mfma_f32_16x16x32_bf16 (same flops)", p3, iters);
+    run<6>("16x16x32 + lds (12 reads / 24 MFMA-equivalents)", p3, iters);
+    run<2>("+lds 32x32x16 again", p3, iters);
+    run<1>("rot-3p again (drift check)", p3, iters);
     return 0;
 }
