@@ -116,14 +116,16 @@ def power_ceiling(ops, device, iters=20000):
     scratch = torch.empty(2 * torch.cuda.get_device_properties(device).multi_processor_count * 256, device=device)
     out = {}
     v = ctypes.c_float(0.0)
-    for key, mode, src in (("mfma_lds_tflops", 2, planes), ("mfma_regs_tflops", 1, planes), ("mfma_regs_zero_operands_tflops", 1, zeros)):
+    for key, mode, src in (("mfma_lds_tflops", 3, planes), ("mfma32_lds_tflops", 2, planes), ("mfma_regs_tflops", 1, planes),
+                           ("mfma_regs_zero_operands_tflops", 1, zeros)):
         rc = ops.L.dawn_ubench_mfma_bf16(mode, iters, src.data_ptr(), scratch.data_ptr(), ctypes.byref(v), torch.cuda.current_stream().cuda_stream)
         if rc != 0:
             raise RuntimeError(f"dawn_ubench_mfma_bf16 failed: {rc}")
         out[key] = float(v.value)
-    out["what"] = ("executed TFLOP/s of a loop of nothing but v_mfma_f32_32x32x16_bf16 (two waves per SIMD, every SIMD), measured right "
-                   "after the timed region on this GPU: operands = bf16 split planes of N(0,1) values re-read from LDS at the conv "
-                   "kernels' ratio / held in registers / zeros.  The chip clocks to its power budget, so the first figure -- not the "
+    out["what"] = ("executed TFLOP/s of a loop of nothing but MFMAs (two waves per SIMD, every SIMD), measured right after the timed region "
+                   "on this GPU: mfma_lds = v_mfma_f32_16x16x32_bf16 (the shape the shipped 3x3 kernel issues) on bf16 split planes of "
+                   "N(0,1) values re-read from LDS at that kernel's ratio; mfma32_lds = the same for v_mfma_f32_32x32x16_bf16; regs = "
+                   "32x32x16 with operands held in registers / zeros.  The chip clocks to its power budget, so the first figure -- not the "
                    "nominal 2500 -- is what the split-operand kernels could reach with a perfect schedule and no other work")
     return out
 
@@ -390,7 +392,7 @@ def main():
         KINDS = {
             "conv3x3": ("hbm_bytes_per_launch_conv3x3_bf16",
                         "conv3x3_bf16_v2_kernel (3x3 ResBlock convs: fp32 operands split exactly into 3 bf16 pieces, 6 cross "
-                        "terms on v_mfma_f32_32x32x16_bf16, fp32 accumulate)"),
+                        "terms, two per v_mfma_f32_16x16x32_bf16, fp32 accumulate)"),
             "gemm1x1": ("hbm_bytes_per_launch_gemm1x1_bf16",
                         "gemm1x1_rowreg / gemm1x1_rowacc / gemm1x1_bf16 kernels (1x1 projections: to_qkv / to_out / to_q / res_conv, same split-operand scheme)"),
             "fp32": ("hbm_bytes_per_launch_fp32",

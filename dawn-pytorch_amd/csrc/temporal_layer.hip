@@ -638,9 +638,11 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     TSTAMP();
 
     // ---- phase 0: bias table; LayerNorm rows, split once into three bf16 planes (16 lanes per row, float4 each)
+    // (the whole softmax runs in log2 units: log2(e) is folded into this table and into the query scale, so that exp is one
+    //  v_exp_f32 of a difference)
     for (int i = tid; i < HEADS * BLD; i += 512) {
         const int hh = i / BLD, idx = i - hh * BLD - 32;
-        band_s[i] = (idx >= 0 && idx <= 2 * win) ? band[idx * HEADS + hh] : NEG;
+        band_s[i] = (idx >= 0 && idx <= 2 * win) ? band[idx * HEADS + hh] * 1.4426950408889634f : NEG;
     }
     {
         // a thread owns float4 #sub of the rows (tid >> 4) + 32 i: ALL its row loads are issued before the first reduction
@@ -687,8 +689,17 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     const int iq = i0 + l31;
     const int iqc = max(0, min(iq, Fext - 1));
     const int qend = q0 + Fq;
-    const float scale = 0.17677669529663687f;
-    constexpr float LOG2E = 1.4426950408889634f;
+    // rotary table of this lane's query row times scale * log2(e): the same for every head, loaded and scaled once
+    float2 qcs[4], qsn[4];
+    {
+        const float sl = 0.17677669529663687f * 1.4426950408889634f;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            qcs[c] = *reinterpret_cast<const float2*>(rcos + iqc * 16 + 4 * c + 2 * half);
+            qsn[c] = *reinterpret_cast<const float2*>(rsin + iqc * 16 + 4 * c + 2 * half);
+            qcs[c].x *= sl; qcs[c].y *= sl; qsn[c].x *= sl; qsn[c].y *= sl;
+        }
+    }
     constexpr int PA6[6] = {2, 0, 1, 1, 0, 0}, PB6[6] = {0, 2, 1, 0, 1, 0};      // smallest cross terms first
     f32x16 outT[2];
     outT[0] = zero16();
@@ -830,12 +841,6 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
             // ---- Q^T (registers = B fragments): scale + rotary (lane-local), split into three bf16 pieces per d-chunk
             bf16x8t qp[3][2];
             {
-                float2 qcs[4], qsn[4];                     // requested before the projection MFMAs (L1/L2 round trip hidden)
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    qcs[c] = *reinterpret_cast<const float2*>(rcos + iqc * 16 + 4 * c + 2 * half);
-                    qsn[c] = *reinterpret_cast<const float2*>(rsin + iqc * 16 + 4 * c + 2 * half);
-                }
                 const f32x16 qT = proj_Q_split(rsw, wvoff, h * DH, Xp + ((size_t)half * FA + iqc) * 16, FA);
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
@@ -845,8 +850,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                         const int c = 2 * kc + cc;
                         const float2 cs = qcs[c];
                         const float2 sn = qsn[c];
-                        const float a0 = qT[4 * c] * scale, a1 = qT[4 * c + 1] * scale;
-                        const float a2 = qT[4 * c + 2] * scale, a3 = qT[4 * c + 3] * scale;
+                        const float a0 = qT[4 * c], a1 = qT[4 * c + 1], a2 = qT[4 * c + 2], a3 = qT[4 * c + 3];
                         qr[4 * cc] = a0 * cs.x - a1 * sn.x;
                         qr[4 * cc + 1] = a1 * cs.x + a0 * sn.x;
                         qr[4 * cc + 2] = a2 * cs.y - a3 * sn.y;
@@ -862,8 +866,13 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
             const float* bb = band_s + h * BLD + 32 - l31 + 4 * half;
             constexpr int HA = (NKT + 1) / 2;
             f32x16 st[NKT];
-            auto s_tile = [&](int t) {                                         // S^T tile = K . Q^T, 12 bf16 MFMAs
+            auto nreg = [](int t) { return (HL && t == NKT - 1) ? 8 : 16; };
+            auto s_tile = [&](int t) {                                         // S^T tile = bias + K . Q^T, 12 bf16 MFMAs
+                // the accumulators START from the relative-position bias (window mask included: NEG + anything = NEG): no add pass
                 st[t] = zero16();
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (r < nreg(t)) st[t][r] = bb[32 * t + (r & 3) + 8 * (r >> 2)];
                 const int j = max(0, min(j0 + 32 * t + l31, Fext - 1));
                 const unsigned char* kr = Kp + ((size_t)half * FA + j) * 16;
                 bf16x8t kf[3][2];
@@ -885,21 +894,14 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
             const unsigned span = (unsigned)(hi - lo);
             // HL: 32 + 2 win <= 32 NKT - 16, i.e. the upper 16 keys of the last tile (registers 8..15) are outside the window
             // of EVERY query of the tile: their bias / exp / split / P.V work is skipped (1/8 of the softmax + P.V at win 40)
-            auto nreg = [](int t) { return (HL && t == NKT - 1) ? 8 : 16; };
             auto bias_max = [&](int t, float& m) {
-                float bz[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    if (r < nreg(t)) bz[r] = bb[32 * t + (r & 3) + 8 * (r >> 2)];
                 // all slots of the tile are frames of the clip (wave-uniform; true for every tile away from the clip ends):
                 // the window mask is already in the table, no per-element select (v_cndmask issues at ~20 cycles here)
                 if (32 * t >= lo && 32 * t + 2 * nreg(t) <= hi) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         if (r >= nreg(t)) continue;
-                        const float sv = st[t][r] + bz[r];
-                        st[t][r] = sv;
-                        m = fmaxf(m, sv);
+                        m = fmaxf(m, st[t][r]);                                 // (pairs become v_max3_f32)
                     }
                 } else {
 #pragma unroll
@@ -907,7 +909,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                         if (r >= nreg(t)) continue;
                         const int c = 32 * t + (r & 3) + 8 * (r >> 2);
                         const bool ok = (unsigned)(vbase + c) < span;
-                        const float sv = ok ? st[t][r] + bz[r] : NEG;
+                        const float sv = ok ? st[t][r] : NEG;
                         st[t][r] = sv;
                         m = fmaxf(m, sv);
                     }
@@ -947,7 +949,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r >= nreg(t)) continue;
-                    const float pv = __builtin_amdgcn_exp2f((st[t][r] - mA) * LOG2E);
+                    const float pv = __builtin_amdgcn_exp2f(st[t][r] - mA);
                     st[t][r] = pv;
                     lA += pv;
                 }
@@ -968,14 +970,14 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
 #pragma unroll
             for (int t = HA; t < NKT; ++t) bias_max(t, m);
             m = fmaxf(m, __shfl_xor(m, 32, 64));
-            const float alpha = __builtin_amdgcn_exp2f((mA - m) * LOG2E);
+            const float alpha = __builtin_amdgcn_exp2f(mA - m);
             float l = lA * alpha;
 #pragma unroll
             for (int t = HA; t < NKT; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     if (r >= nreg(t)) continue;
-                    const float pv = __builtin_amdgcn_exp2f((st[t][r] - m) * LOG2E);
+                    const float pv = __builtin_amdgcn_exp2f(st[t][r] - m);
                     st[t][r] = pv;
                     l += pv;
                 }

@@ -3,7 +3,8 @@
 // r3_conv_power_by_data.txt), so bench.py prices the dominant kernel against this ceiling next to the nominal 2.5 PFLOP/s: a loop
 // of nothing but MFMAs (4 independent accumulators, two waves per SIMD, every SIMD busy) whose operands are
 //   mode 0: zeros   mode 1: the three bf16 split planes of N(0,1) values, 8 rotating register sets
-//   mode 2: the same planes re-read from LDS at the conv kernels' ratio (12 ds_read_b128 per 24 MFMAs).
+//   mode 2: the same planes re-read from LDS at the 32x32x16 conv kernels' ratio (12 ds_read_b128 per 24 MFMAs)
+//   mode 3: v_mfma_f32_16x16x32_bf16 (what the shipped 3x3 kernel issues) at ITS ratio: 16 ds_read_b128 per 48 half-size MFMAs.
 // Stand-alone version with more variants: tools/ubench/mfma_power.hip.
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
@@ -26,7 +27,21 @@ __global__ __launch_bounds__(256, 2) void mfma_power_kernel(const u32x4* __restr
     }
     __syncthreads();
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 2) {
+        if (MODE == 3) {
+            f32x4* a4 = reinterpret_cast<f32x4*>(acc);
+            u32x4 fa[8], fb[8];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                fa[s] = lds[(((it + s) & 7) * 2) * 256 + threadIdx.x];
+                fb[s] = lds[(((it + s) & 7) * 2 + 1) * 256 + threadIdx.x];
+            }
+#pragma unroll
+            for (int t = 0; t < 3; ++t)
+#pragma unroll
+                for (int i = 0; i < 16; ++i)
+                    a4[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(dawn_bf16x8, fb[(2 * t + (i >> 2)) & 7]),
+                                                                    __builtin_bit_cast(dawn_bf16x8, fa[(t + (i & 3)) & 7]), a4[i], 0, 0, 0);
+        } else if (MODE == 2) {
             u32x4 fa[6], fb[6];
 #pragma unroll
             for (int s = 0; s < 6; ++s) {
@@ -60,7 +75,7 @@ __global__ __launch_bounds__(256, 2) void mfma_power_kernel(const u32x4* __restr
 /* operands: 16 images x 256 threads x 8 bf16 (64 KB, device); scratch: >= grid * 256 floats (device).  Launches the loop twice
  * (a tenth of `iters` to warm up, then `iters`), SYNCHRONISES, and returns the sustained executed TFLOP/s of the second launch. */
 extern "C" int dawn_ubench_mfma_bf16(int mode, int iters, const void* operands, float* scratch, float* tflops_out, void* stream) {
-    if (mode < 0 || mode > 2 || iters <= 0 || !operands || !scratch || !tflops_out)
+    if (mode < 0 || mode > 3 || iters <= 0 || !operands || !scratch || !tflops_out)
         return dawn_set_error_msg(-90, "dawn_ubench_mfma_bf16: bad argument");
     hipStream_t s = (hipStream_t)stream;
     int dev = 0, ncu = 256;
@@ -72,7 +87,8 @@ extern "C" int dawn_ubench_mfma_bf16(int mode, int iters, const void* operands, 
     for (int pass = 0; pass < 2; ++pass) {
         const int n = pass == 0 ? (iters + 9) / 10 : iters;
         if (pass == 1) (void)hipEventRecord(e0, s);
-        if (mode == 2) hipLaunchKernelGGL(mfma_power_kernel<2>, dim3(grid), dim3(256), 0, s, src, scratch, n);
+        if (mode == 3) hipLaunchKernelGGL(mfma_power_kernel<3>, dim3(grid), dim3(256), 0, s, src, scratch, n);
+        else if (mode == 2) hipLaunchKernelGGL(mfma_power_kernel<2>, dim3(grid), dim3(256), 0, s, src, scratch, n);
         else hipLaunchKernelGGL(mfma_power_kernel<1>, dim3(grid), dim3(256), 0, s, src, scratch, n);
     }
     (void)hipEventRecord(e1, s);

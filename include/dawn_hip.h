@@ -386,8 +386,8 @@ int dawn_gemm1x1_ln_inline_ok(long M, int N, int C0, int C1);       /* host: may
 int dawn_gemm1x1_split_ok(long M, int N, int C0, int C1);             /* host: does a 1x1 projection take the split GEMM? */
 
 /* ---- measurement helper (bench.py; not on the product path): sustained executed TFLOP/s of an MFMA-only bf16 loop on this
- * box under its power budget.  mode 0 = zero operands, 1 = operands from registers, 2 = re-read from LDS at the conv kernels'
- * ratio; operands = 16 x 256 x 8 bf16 (64 KB), scratch >= 2 * CUs * 256 floats.  Synchronises. */
+ * box under its power budget.  mode 0 = zero operands, 1 = operands from registers, 2 = re-read from LDS at the 32x32x16 conv kernels'
+ * ratio, 3 = v_mfma_f32_16x16x32_bf16 with the shipped 3x3 kernel's LDS ratio; operands = 16 x 256 x 8 bf16 (64 KB), scratch >= 2 * CUs * 256 floats.  Synchronises. */
 int dawn_ubench_mfma_bf16(int mode, int iters, const void* operands, float* scratch, float* tflops_out, void* stream);
 
 #ifdef __cplusplus
