@@ -268,6 +268,7 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="disable the two-stream overlap inside ResBlocks")
     ap.add_argument("--no-fuse-h1", action="store_true",
                     help="A/B only: separate h_cond tensor + GroupNorm-apply pass instead of the cross-attention kernels' fused h1 epilogue")
+    ap.add_argument("--temporal-attn-flags", type=int, default=0, help="dawn_temporal_attn_ex flags (A/B: 1 = the fp32-MFMA attention core)")
     ap.add_argument("--conv-policy", type=lambda v: int(v, 0), default=0,
                     help="A/B only: dawn_conv_desc.policy of every conv launch (0 = the shipped kernel policy)")
     ap.add_argument("--host", choices=["python", "ctx"], default="python",
@@ -311,6 +312,7 @@ def main():
     ops = unet._ops()
     ops.overlap = not args.no_overlap
     ops.conv_policy = args.conv_policy
+    ops.temporal_attn_flags = args.temporal_attn_flags
     ops.fuse_h1 = not args.no_fuse_h1
     diff.use_ctx = args.host == "ctx" and mode != "tshard"
     if diff.use_ctx:

@@ -66,6 +66,7 @@ SIGNATURES = {
     "dawn_xattn_layer_c64": [c_f, _i, _i, c_f, _i, _i, _l, _i, c_f, c_f, c_f, c_f, _f, c_f, c_f],
     "dawn_xattn_layer_c64_h1": [c_f, _i, _i, c_f, _i, _i, _l, _i, c_f, c_f, c_f, c_f, _f, c_f, c_f, c_f, c_f, c_f],
     "dawn_temporal_attn": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f],
+    "dawn_temporal_attn_ex": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, _i, c_f],
     "dawn_temporal_layer_c64": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f, c_f, _f, c_f, c_f],
     "dawn_temporal_layer_c64_ex": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, _f, c_f, _i, c_f],
     "dawn_sla_context": [c_f, _i, _i, c_f, c_f],

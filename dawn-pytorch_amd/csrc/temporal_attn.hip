@@ -185,10 +185,21 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos,
-                                  const float* rot_sin, const float* band, float* out, void* stream) {
+// (temporal_layer.hip) the same attention on the bf16 matrix pipe with exactly split operands; false = shape not covered
+bool dawn_temporal_attn_bf16_try(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos,
+                                 const float* rot_sin, const float* band, float* out, bool force, hipStream_t s);
+
+extern "C" int dawn_temporal_attn_ex(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos,
+                                     const float* rot_sin, const float* band, float* out, int flags, void* stream) {
     if (Fq <= 0) return 0;
     if (q0 < 0 || q0 + Fq > Fext || win < 0) return dawn_set_error_msg(-30, "dawn_temporal_attn: bad frame range");
+    // flags bit 0: the fp32-MFMA kernel below even where the split-operand kernel covers the shape; bit 1: the split-operand kernel
+    // also on grids too small for it to pay (tests, A/B)
+    if (!(flags & 1) &&
+        dawn_temporal_attn_bf16_try(qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, (flags & 2) != 0, (hipStream_t)stream)) {
+        DAWN_LAUNCH_CHECK();
+        return 0;
+    }
     const int nkt = (32 + 2 * win + 31) / 32;
     const int nseg = (Fq + SEG - 1) / SEG;
     const long nblk = (long)HW * HEADS * nseg;
@@ -213,4 +224,9 @@ extern "C" int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, in
 #undef LAUNCH_TA
     DAWN_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos,
+                                  const float* rot_sin, const float* band, float* out, void* stream) {
+    return dawn_temporal_attn_ex(qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, 0, stream);
 }

@@ -29,6 +29,7 @@ namespace {
 constexpr int C = 64;
 constexpr int HEADS = 8;
 constexpr int DH = 32;
+constexpr int QKV = 3 * HEADS * DH;   // 768 columns of the qkv tensor (EXT form of the WMODE-3 kernel)
 constexpr int XLD = 68;   // Xs row stride (floats): conflict-free ds_read_b128
 constexpr int KLD = 36;   // Ks row stride
 constexpr float NEG = -1.0e30f;
@@ -610,7 +611,11 @@ __device__ __forceinline__ f32x16 proj_Q_split(const __amdgpu_buffer_rsrc_t rw, 
     return d;
 }
 
-template <int NKT, int SCHED, bool HL, bool OB, int FAC, bool KVI>
+// EXT: the attention core alone for the levels whose to_qkv projection is a separate GEMM (C >= 128): `x` is the (Fext*HW, 768) qkv
+// tensor, K / V / Q tiles are LOADED in the register layouts the projections produce (requested one head ahead, under the previous
+// head's attention), `out` receives O (rows, 256) -- the drop-in for temporal_attn_kernel (fp32 MFMA: 2 x 4096 matrix cycles per
+// (tile, head) against 2 x 1536 here).  No X planes: K planes + V^T + bias table = 86 KB at Fext = 200.
+template <int NKT, int SCHED, bool HL, bool OB, int FAC, bool KVI, bool EXT = false>
 __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     const float* __restrict__ x, int Fext, int HW, int q0, int Fq, int win, const unsigned short* __restrict__ wqkv_s,
     const float* __restrict__ wout, const unsigned short* __restrict__ wout_sp, const float* __restrict__ rcos,
@@ -622,10 +627,11 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     const int FA = FAC ? FAC : Fext;
     const int NBV = 2 * nrt;                                     // 16-key blocks of V^T
     unsigned char* Xp = reinterpret_cast<unsigned char*>(smem);  // [3][4][2][FA] x 16 B
-    unsigned char* Kp = Xp + (size_t)24 * FA * 16;               // [3][2][2][FA] x 16 B
+    unsigned char* Kp = Xp + (EXT ? (size_t)0 : (size_t)24 * FA * 16);   // [3][2][2][FA] x 16 B
     unsigned char* Vt = Kp + (size_t)12 * FA * 16;               // [3][NBV][2][32] x 16 B
     constexpr int BLD = 32 * NKT + 32;
     float* band_s = reinterpret_cast<float*>(Vt + (size_t)3 * NBV * 64 * 16);   // [8][BLD]
+    float* rot_s = band_s + HEADS * BLD;                         // EXT: [Fext][cos 16 | sin 16] (the tables of every buffer row)
 
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
@@ -644,7 +650,13 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
         const int hh = i / BLD, idx = i - hh * BLD - 32;
         band_s[i] = (idx >= 0 && idx <= 2 * win) ? band[idx * HEADS + hh] * 1.4426950408889634f : NEG;
     }
-    {
+    if constexpr (EXT) {
+        for (int i = tid; i < Fext * 8; i += 512) {
+            const int row = i >> 3, q4 = i & 7;
+            *reinterpret_cast<f32x4*>(rot_s + row * 32 + q4 * 4) =
+                *reinterpret_cast<const f32x4*>((q4 < 4 ? rcos : rsin) + row * 16 + (q4 & 3) * 4);
+        }
+    } else {
         // a thread owns float4 #sub of the rows (tid >> 4) + 32 i: ALL its row loads are issued before the first reduction
         // (one exposed HBM round trip per block instead of one per row)
         const int sub = tid & 15;
@@ -691,7 +703,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     const int qend = q0 + Fq;
     // rotary table of this lane's query row times scale * log2(e): the same for every head, loaded and scaled once
     float2 qcs[4], qsn[4];
-    {
+    if constexpr (!EXT) {
         const float sl = 0.17677669529663687f * 1.4426950408889634f;
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -705,11 +717,116 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     outT[0] = zero16();
     outT[1] = zero16();
 
+    // EXT: K / V tiles of this wave's first two work items and the Q tile, requested one head ahead.  A wave's items are all K (even
+    // waves: lane = row, 4 x 16 B = features 8c + 4 half + 0..3) or all V (odd waves: lane = feature, 16 keys of the row tile).
+    // Buffer loads: one per-lane byte offset for K / Q and one for V, everything else (row tile, key, head) in the scalar offset
+    // -- no per-load address registers; rows past the buffer are out of range and read as 0
+    float kvr[2][16], qreg[16];
+    const int wv = __builtin_amdgcn_readfirstlane(wave);      // (scalar: the row-tile / key / head offsets below stay in SGPRs)
+    typedef int i32x4_t __attribute__((ext_vector_type(4)));
+    const __amdgpu_buffer_rsrc_t rsx = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, EXT ? Fext * HW * (QKV * 4) : 0, 0x00020000);
+    const unsigned kvoff = (unsigned)((l31 * HW + (int)p) * (QKV * 4) + half * 16);            // row l31 of a row tile, k-half
+    const unsigned vvoff = (unsigned)((4 * half * HW + (int)p) * (QKV * 4) + l31 * 4);         // key 4 half of a 16-key group, feature
+    const unsigned qvoff = (unsigned)((iqc * HW + (int)p) * (QKV * 4) + half * 16);
+    auto kv_load = [&](int hh, int it, float (&reg)[16]) {
+        const int rt = it >> 1;
+        if (!(wv & 1)) {
+            const int so = 32 * rt * HW * (QKV * 4) + (HEADS * DH + hh * DH) * 4;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const f32x4 v = __builtin_bit_cast(f32x4, (i32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsx, kvoff, so + 32 * c, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) reg[4 * c + e] = v[e];
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int so = (32 * rt + (r & 3) + 8 * (r >> 2)) * HW * (QKV * 4) + (2 * HEADS * DH + hh * DH) * 4;
+                reg[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, vvoff, so, 0));
+            }
+        }
+    };
+    auto kv_request = [&](int hh) {
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2)
+            if (wv + 8 * s2 < 2 * nrt) kv_load(hh, wv + 8 * s2, kvr[s2]);
+    };
+    // rotary on K / zero padding on V, split, planes into LDS
+    auto kv_store = [&](int it, const float (&reg)[16]) {
+        const int rt = it >> 1;
+        if (!(wv & 1)) {
+            const int j = 32 * rt + l31;
+#pragma unroll
+            for (int kc = 0; kc < 2; ++kc) {
+                float kr[8];
+#pragma unroll
+                for (int cc = 0; cc < 2; ++cc) {
+                    const int c = 2 * kc + cc;
+                    const float* rt_ = rot_s + min(j, Fext - 1) * 32 + 4 * c + 2 * half;
+                    const float2 cs = *reinterpret_cast<const float2*>(rt_), sn = *reinterpret_cast<const float2*>(rt_ + 16);
+                    kr[4 * cc] = reg[4 * c] * cs.x - reg[4 * c + 1] * sn.x;
+                    kr[4 * cc + 1] = reg[4 * c + 1] * cs.x + reg[4 * c] * sn.x;
+                    kr[4 * cc + 2] = reg[4 * c + 2] * cs.y - reg[4 * c + 3] * sn.y;
+                    kr[4 * cc + 3] = reg[4 * c + 3] * cs.y + reg[4 * c + 2] * sn.y;
+                }
+                bf16x8t k1, k2, k3;
+                dawn_split3_oct(kr, k1, k2, k3);
+                if (j < Fext) {
+                    unsigned char* dst = Kp + ((size_t)(kc * 2 + half) * FA + j) * 16;
+                    *reinterpret_cast<bf16x8t*>(dst) = k1;
+                    *reinterpret_cast<bf16x8t*>(dst + (size_t)4 * FA * 16) = k2;
+                    *reinterpret_cast<bf16x8t*>(dst + (size_t)8 * FA * 16) = k3;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int g = 0; g < 2; ++g) {
+                float vr[8];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int key = 32 * rt + 16 * g + 4 * half + (i & 3) + 8 * (i >> 2);
+                    vr[i] = key < Fext ? reg[8 * g + i] : 0.f;                 // finite zeros for the padded keys (their P is exactly 0)
+                }
+                bf16x8t v1, v2, v3;
+                dawn_split3_oct(vr, v1, v2, v3);
+                unsigned char* dst = Vt + ((size_t)((2 * rt + g) * 2 + half) * 32 + l31) * 16;
+                *reinterpret_cast<bf16x8t*>(dst) = v1;
+                *reinterpret_cast<bf16x8t*>(dst + (size_t)NBV * 64 * 16) = v2;
+                *reinterpret_cast<bf16x8t*>(dst + (size_t)2 * NBV * 64 * 16) = v3;
+            }
+        }
+    };
+    auto q_request = [&](int hh) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const f32x4 v = __builtin_bit_cast(f32x4, (i32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsx, qvoff, hh * DH * 4 + 32 * c, 0));
+#pragma unroll
+            for (int e = 0; e < 4; ++e) qreg[4 * c + e] = v[e];
+        }
+    };
+    if constexpr (EXT) {
+        kv_request(0);
+        if (has_q) q_request(0);
+    }
     TSTAMP();   // phase 0 done (+ setup)
     for (int h = 0; h < HEADS; ++h) {
         if (h < 2) TSTAMP();   // head start
         // ---- K^T / V projection of every frame row; rotary on K; both split into bf16 planes in LDS
-        if (KVI) {
+        if constexpr (EXT) {
+            // every outstanding request of this wave has landed before its registers are read (explicit, with the registers pinned
+            // behind the wait: with the requests conditional on the work-item count the automatic counter placement let the second
+            // item of the last K wave be read early -- a timing-dependent wrong K tile, tools/dbg_ta.py)
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(kvr[0][0]), "+v"(kvr[0][1]), "+v"(kvr[0][2]), "+v"(kvr[0][3]), "+v"(kvr[0][4]), "+v"(kvr[0][5]), "+v"(kvr[0][6]), "+v"(kvr[0][7]), "+v"(kvr[0][8]), "+v"(kvr[0][9]), "+v"(kvr[0][10]), "+v"(kvr[0][11]), "+v"(kvr[0][12]), "+v"(kvr[0][13]), "+v"(kvr[0][14]), "+v"(kvr[0][15]) :: "memory");
+            asm volatile("" : "+v"(kvr[1][0]), "+v"(kvr[1][1]), "+v"(kvr[1][2]), "+v"(kvr[1][3]), "+v"(kvr[1][4]), "+v"(kvr[1][5]), "+v"(kvr[1][6]), "+v"(kvr[1][7]), "+v"(kvr[1][8]), "+v"(kvr[1][9]), "+v"(kvr[1][10]), "+v"(kvr[1][11]), "+v"(kvr[1][12]), "+v"(kvr[1][13]), "+v"(kvr[1][14]), "+v"(kvr[1][15]) :: "memory");
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+                if (wv + 8 * s2 < 2 * nrt) kv_store(wv + 8 * s2, kvr[s2]);         // requested during the previous head
+            for (int it = wv + 16; it < 2 * nrt; it += 8) {                        // buffers beyond 256 rows: not prefetched
+                float t4[16];
+                kv_load(h, it, t4);
+                kv_store(it, t4);
+            }
+        } else if (KVI) {
         // 2 * nrt work items (row tile, K | V) over the 8 waves: a wave per 32-row tile left the SIMDs that host two of the
         // 6..7 tiles with twice the work of the others (7.7 k vs 5.9 k cycles per head in the s_memtime profile)
         for (int it = wave; it < 2 * nrt; it += 8) {
@@ -836,12 +953,29 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
         if (h < 2) TSTAMP();   // K/V projected (before barrier)
         __syncthreads();
         if (h < 2) TSTAMP();   // barrier passed
+        if constexpr (EXT)
+            if (!has_q && h + 1 < HEADS) kv_request(h + 1);                   // (waves with a query tile: after their Q step, below)
 
         if (has_q) {
             // ---- Q^T (registers = B fragments): scale + rotary (lane-local), split into three bf16 pieces per d-chunk
             bf16x8t qp[3][2];
             {
-                const f32x16 qT = proj_Q_split(rsw, wvoff, h * DH, Xp + ((size_t)half * FA + iqc) * 16, FA);
+                f32x16 qT;
+                if constexpr (EXT) {
+                    asm volatile("s_waitcnt vmcnt(0)" : "+v"(qreg[0]), "+v"(qreg[1]), "+v"(qreg[2]), "+v"(qreg[3]), "+v"(qreg[4]), "+v"(qreg[5]), "+v"(qreg[6]), "+v"(qreg[7]), "+v"(qreg[8]), "+v"(qreg[9]), "+v"(qreg[10]), "+v"(qreg[11]), "+v"(qreg[12]), "+v"(qreg[13]), "+v"(qreg[14]), "+v"(qreg[15]) :: "memory");      // (the next head's K / V requests follow the Q step)
+                    const float sl = 0.17677669529663687f * 1.4426950408889634f;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const float* rt_ = rot_s + iqc * 32 + 4 * c + 2 * half;
+                        qcs[c] = *reinterpret_cast<const float2*>(rt_);
+                        qsn[c] = *reinterpret_cast<const float2*>(rt_ + 16);
+                        qcs[c].x *= sl; qcs[c].y *= sl; qsn[c].x *= sl; qsn[c].y *= sl;
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) qT[4 * c + e] = qreg[4 * c + e];
+                    }
+                } else {
+                    qT = proj_Q_split(rsw, wvoff, h * DH, Xp + ((size_t)half * FA + iqc) * 16, FA);
+                }
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
                     float qr[8];
@@ -859,6 +993,10 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                     dawn_split3_oct(qr, qp[0][kc], qp[1][kc], qp[2][kc]);
                 }
             }
+            // the next head's K / V tiles: requested once this head's Q registers are consumed (so that waiting for Q does not wait for
+            // them), landing under S / softmax / P.V
+            if constexpr (EXT)
+                if (h + 1 < HEADS) kv_request(h + 1);
             if (h < 2) TSTAMP();   // Q projected + rotated
             const int j0 = i0 - win;                                           // multiple of 16 (delta)
             int j0m = j0;
@@ -1015,7 +1153,16 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                 for (int r = 0; r < 16; ++r) oT[r] = oA[r] * ia + oT[r] * inv;
             }
             if (h < 2) TSTAMP();   // PV issued
-            if (OB) {
+            if constexpr (EXT) {
+                if (h + 1 < HEADS) q_request(h + 1);            // lands under the end-of-head barrier + the next K / V phase
+                // O (rows, 256): lane = query row, registers 4c..4c+3 = features 8c + 4 half + 0..3 of this head
+                if (iq >= q0 && iq < qend) {
+                    float* orow = out + ((long)(iq - q0) * HW + p) * (HEADS * DH) + h * DH + 4 * half;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        *reinterpret_cast<f32x4*>(orow + 8 * c) = f32x4{oT[4 * c], oT[4 * c + 1], oT[4 * c + 2], oT[4 * c + 3]};
+                }
+            } else if (OB) {
                 // ---- out^T += Wout_h^T . O^T on the bf16 pipe: O^T split from the accumulators (registers 8kc..8kc+7 = the
                 // B fragment of d-chunk kc), to_out as the k-permuted 3-way split image wout_sp (pack.pack_bf3_temporal_out:
                 // slot (kc, k-half, i) of head h holds row h*32 + 16 kc + 8 (i >> 2) + 4 k-half + (i & 3))
@@ -1052,7 +1199,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
         __syncthreads();       // K / V planes are rewritten by the next head
     }
 
-    if (has_q && iq >= q0 && iq < qend) {
+    if (!EXT && has_q && iq >= q0 && iq < qend) {
         const float* xr = x + ((long)iq * HW + p) * C;
         float* orow = out + ((long)(iq - q0) * HW + p) * C;
 #pragma unroll
@@ -1168,6 +1315,42 @@ extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int 
 #undef LAUNCH_TL3D
     DAWN_LAUNCH_CHECK();
     return 0;
+}
+
+// The attention core of the unfused levels (dawn_temporal_attn) on the bf16 pipe: the WMODE-3 kernel in its EXT form.  Returns
+// false (nothing launched) when the shape is outside its instantiations: the caller falls back to temporal_attn_kernel.
+bool dawn_temporal_attn_bf16_try(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos,
+                                 const float* rot_sin, const float* band, float* out, bool force, hipStream_t s) {
+    // one 512-thread workgroup per pixel column: below ~128 columns the grid leaves most CUs idle and the 256-thread (pixel, head,
+    // segment) blocks of the fp32 kernel win (HW = 64: 72 vs 36 us, profiles/r3_temporal_attn_split_vs_fp32.txt)
+    if (HW < 128 && !force) return false;
+    const int nkt = (32 + 2 * win + 31) / 32;
+    const int nrt = (Fext + 31) / 32;
+    if (nkt != 2 && nkt != 4) return false;
+    const int delta = (((q0 - win) % 16) + 16) % 16;
+    if (Fq + delta > 256 || Fext > 512 || (long)(Fext + 32) * HW * 3072 >= (1L << 31)) return false;   // 32-bit buffer offsets
+    const size_t band_bytes = (size_t)HEADS * (32 * nkt + 32) * sizeof(float);
+    const bool fac200 = Fext <= 200;
+    const size_t lds = (size_t)(fac200 ? 200 : Fext) * 192 + (size_t)nrt * 6144 + band_bytes + (size_t)Fext * 128;   // + rotary tables
+    if (lds > 163840) return false;
+    const bool hl = 32 + 2 * win <= 32 * nkt - 16;
+#define LAUNCH_TAX(N, HLV, FACV)                                                                                       \
+    do {                                                                                                               \
+        (void)hipFuncSetAttribute((const void*)temporal_layer_c64_bf16_kernel<N, 0, HLV, false, FACV, true, true>,     \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                               \
+        hipLaunchKernelGGL((temporal_layer_c64_bf16_kernel<N, 0, HLV, false, FACV, true, true>), dim3(HW), dim3(512),  \
+                           lds, s, qkv, Fext, HW, q0, Fq, win, nullptr, nullptr, nullptr, rot_cos, rot_sin, band, 0.f, \
+                           out, nrt, delta);                                                                           \
+    } while (0)
+#define LAUNCH_TAXB(N, HLV)                                                                                            \
+    do {                                                                                                               \
+        if (fac200) LAUNCH_TAX(N, HLV, 200); else LAUNCH_TAX(N, HLV, 0);                                               \
+    } while (0)
+    if (nkt == 2) { if (hl) LAUNCH_TAXB(2, true); else LAUNCH_TAXB(2, false); }
+    else { if (hl) LAUNCH_TAXB(4, true); else LAUNCH_TAXB(4, false); }
+#undef LAUNCH_TAXB
+#undef LAUNCH_TAX
+    return true;
 }
 
 extern "C" int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,

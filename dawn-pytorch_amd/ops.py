@@ -44,6 +44,7 @@ class HipOps:
         self.graph_error = None      # set when a HIP-graph capture failed and the sampler fell back to eager
         self.conv_policy = 0         # dawn_conv_desc.policy of every conv_gemm launch (0 = shipped kernel policy)
         self.temporal_flags = 0      # kernel-family selector of the fused temporal layer (0 = automatic; A/B and tests)
+        self.temporal_attn_flags = 0  # dawn_temporal_attn_ex flags (1 = the fp32-MFMA attention core; A/B and tests)
         self.stream_k = True         # supply the stream-K scratch when conv_policy selects that kernel (bit 0x400; opt-in)
         self.fuse_h1 = True          # cross-attention kernels write h1 = SiLU(GN(c1)) + h_cond themselves (False: A/B, two-stream form)
         self._sk_ws = {}             # device index -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
@@ -73,6 +74,7 @@ class HipOps:
         o.overlap = self.overlap
         o.conv_policy = self.conv_policy
         o.temporal_flags = self.temporal_flags
+        o.temporal_attn_flags = self.temporal_attn_flags
         o.stream_k = self.stream_k
         o.fuse_h1 = self.fuse_h1
         o._sk_ws = self._sk_ws
@@ -346,8 +348,8 @@ class HipOps:
         assert qkv.is_contiguous() and qkv.shape == (Fext * HW, 768)
         self._require(qkv, rcos, rsin, band)
         out = self.empty(Fq * HW, 256, like=qkv)
-        check(self.L.dawn_temporal_attn(_p(qkv), Fext, HW, q0, Fq, win, _p(rcos), _p(rsin), _p(band), _p(out),
-                                        self._stream()), "dawn_temporal_attn")
+        check(self.L.dawn_temporal_attn_ex(_p(qkv), Fext, HW, q0, Fq, win, _p(rcos), _p(rsin), _p(band), _p(out),
+                                           self.temporal_attn_flags, self._stream()), "dawn_temporal_attn")
         return out
 
     @staticmethod

@@ -154,6 +154,12 @@ int dawn_xattn_layer_c64(const float* in0, int C0, int ld0, const float* in1, in
 int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, int Fq, int win,
                        const float* rot_cos, const float* rot_sin, const float* band,
                        float* out, void* stream);
+/* the same with flags: 0 = automatic (S and P.V on the bf16 matrix pipe with exactly split operands where the shape is covered:
+ * win <= 48, at most 256 queries, K / V planes of the buffer in LDS, >= 128 pixel columns; the fp32-MFMA kernel otherwise), bit 0 = the
+ * fp32-MFMA kernel, bit 1 = the split-operand kernel whatever the number of pixel columns */
+int dawn_temporal_attn_ex(const float* qkv, int Fext, int HW, int q0, int Fq, int win,
+                          const float* rot_cos, const float* rot_sin, const float* band,
+                          float* out, int flags, void* stream);
 
 /* Fused LAYER for 64-channel levels: out[(i-q0)] = x[i] + to_out(attn(LayerNorm(x)))  (MT:179-188, 665-725,
  * 141-147) -- x (Fext*HW, 64) rows, packed wqkv [(64/4)][768][4] (LayerNorm gain folded), wout [(256/4)][64][4].

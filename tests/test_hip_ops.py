@@ -600,7 +600,8 @@ def test_xattn_layer_c64_rejects_straddling_tiles(hip):
                                                  # the shapes the benchmark / long clips / T-shards run (several 128-query
                                                  # blocks, a full +-40 window on both sides, q0 != 0, >= 64 pixel columns)
                                                  (200, 64, 0, 200, 40), (280, 64, 40, 200, 40), (400, 64, 0, 400, 40),
-                                                 (240, 70, 40, 200, 40), (327, 64, 40, 247, 40)])
+                                                 (240, 70, 40, 200, 40), (327, 64, 40, 247, 40),
+                                                 (64, 3, 0, 64, 16), (120, 2, 31, 70, 8), (150, 2, 0, 150, 48), (100, 2, 9, 80, 45)])
 def test_temporal_attn(hip, ref, Fext, HW, q0, Fq, win):
     qkv = rnd(Fext * HW, 768, seed=1)
     ang = torch.arange(Fext).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
@@ -609,6 +610,15 @@ def test_temporal_attn(hip, ref, Fext, HW, q0, Fq, win):
     want = ref.temporal_attn(qkv, Fext, HW, q0, Fq, win, rc, rs, band)
     got = hip.temporal_attn(qkv.cuda(), Fext, HW, q0, Fq, win, rc.cuda(), rs.cuda(), band.cuda())
     check(f"temporal_attn/F{Fext}_q{q0}_{Fq}_w{win}", got, want, 2e-5)
+    try:                                                        # both kernels explicitly: fp32 MFMA / split operands on any grid
+        hip.temporal_attn_flags = 1
+        got32 = hip.temporal_attn(qkv.cuda(), Fext, HW, q0, Fq, win, rc.cuda(), rs.cuda(), band.cuda())
+        hip.temporal_attn_flags = 2
+        got16 = hip.temporal_attn(qkv.cuda(), Fext, HW, q0, Fq, win, rc.cuda(), rs.cuda(), band.cuda())
+    finally:
+        hip.temporal_attn_flags = 0
+    check(f"temporal_attn_fp32/F{Fext}_q{q0}_{Fq}_w{win}", got32, want, 2e-5)
+    check(f"temporal_attn_split/F{Fext}_q{q0}_{Fq}_w{win}", got16, want, 2e-5)
 
 
 @pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(12, 5, 0, 12, 3), (200, 3, 0, 200, 40), (280, 2, 40, 200, 40),
