@@ -1051,6 +1051,17 @@ __global__ __launch_bounds__(256) void conv3x3_halo_bf16_kernel(const dawn_conv_
     }
 }
 
+// sums over lanes 0..31 and over lanes 32..63 of a wave, valid in lanes 16..31 / 48..63: four DPP adds inside each row of 16
+// (quad xor 1, quad xor 2, half-row mirror, row mirror), then row_bcast15 into rows 1 and 3 -- no LDS round trips
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x141, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x140, 0xF, 0xF, true));
+    v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x142, 0xA, 0xF, false));
+    return v;
+}
+
 // Second-generation split-operand kernel for the large-M levels: BM = 256 output pixels x BN = 64*WN channels,
 // 64*4*WN threads (every wave owns a 64 x 64 tile).  Differences from conv3x3_halo_bf16_kernel:
 //  * the fp32 patch of the NEXT channel chunk is prefetched into registers during stages 0-1 of the current chunk,
@@ -1449,11 +1460,37 @@ __global__ __launch_bounds__(256 * WN, K32 ? 2 / WN : 1) void conv3x3_bf16_v2_ke
                 sv += (v.x + v.y) + (v.z + v.w);
                 sq += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
-            const int up = kg >> 1;
-            gs[cb >> 1][2 * (cb & 1)] = up ? 0.f : sv;
-            gs[cb >> 1][2 * (cb & 1) + 1] = up ? sv : 0.f;
-            gss[cb >> 1][2 * (cb & 1)] = up ? 0.f : sq;
-            gss[cb >> 1][2 * (cb & 1) + 1] = up ? sq : 0.f;
+            gs[cb >> 1][2 * (cb & 1)] = sv;             // (K32: slot [cb] = this lane's 4 channels of channel block cb; reduced below)
+            gss[cb >> 1][2 * (cb & 1)] = sq;
+        }
+        if (d.gn_part) {
+            // lanes 0..31 (k-groups 0, 1) own the lower 8 channels of every 16-channel block, lanes 32..63 the upper 8: two DPP
+            // half-wave sums per block, one 128-byte exchange, one barrier; fp64 from the per-wave sums on
+            float* wsum = reinterpret_cast<float*>(smem_b + DBG_OFF);          // [waves][8 subgroups][sum, sumsq]
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) {
+                const float s1 = half_wave_sum_dpp(gs[cb >> 1][2 * (cb & 1)]), s2 = half_wave_sum_dpp(gss[cb >> 1][2 * (cb & 1)]);
+                if (l31 == 31) {
+                    wsum[wave * 16 + (2 * cb + half) * 2] = s1;
+                    wsum[wave * 16 + (2 * cb + half) * 2 + 1] = s2;
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (tid < 16) {
+                const int which = tid & 1;
+                const int cpg = d.N >> 3;
+                const int lo = (tid >> 1) * cpg - n0, hi = lo + cpg;           // this group's channel range relative to the tile
+                double a = 0.0;
+#pragma unroll
+                for (int w = 0; w < NW; ++w)
+#pragma unroll
+                    for (int jg = 0; jg < 8; ++jg) {
+                        const int c = (w % WN) * 64 + 8 * jg;
+                        if (c >= lo && c < hi) a += (double)wsum[w * 16 + jg * 2 + which];
+                    }
+                d.gn_part[(long)blockIdx.x * 16 + tid] = a;
+            }
         }
     } else {
     long mrow[TM];                                      // output pixel (row of the (M, N) result) of this lane
@@ -1491,7 +1528,7 @@ __global__ __launch_bounds__(256 * WN, K32 ? 2 / WN : 1) void conv3x3_bf16_v2_ke
     }
     }
     TSTAMP();   // stores issued
-    if (d.gn_part) {
+    if (!K32 && d.gn_part) {
         // block reduction through LDS: fp32 per-lane partials (8 values each) -> fp64 from there on
         __syncthreads();
         float* pf = reinterpret_cast<float*>(smem_b);                        // [16 columns][NTHR]
@@ -1553,7 +1590,8 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     const int P16 = (P + 15) / 16 * 16;
     if (P16 > 448) return false;
     const bool timing = ((policy_of(d) >> 16) & 15) == 8;
-    const size_t lds = (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 18 * BN * 16 + (timing ? 512 : 0);
+    const bool k32 = !nine && (policy_of(d) & 0x1000000);
+    const size_t lds = (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 18 * BN * 16 + (timing || k32 ? 512 : 0);   // (+ the GroupNorm exchange)
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * (d.N / BN);
     const int remap = ((policy_of(d) & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;

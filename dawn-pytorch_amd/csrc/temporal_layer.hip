@@ -719,8 +719,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
 
     // EXT: K / V tiles of this wave's first two work items and the Q tile, requested one head ahead.  A wave's items are all K (even
     // waves: lane = row, 4 x 16 B = features 8c + 4 half + 0..3) or all V (odd waves: lane = feature, 16 keys of the row tile).
-    // Buffer loads: one per-lane byte offset for K / Q and one for V, everything else (row tile, key, head) in the scalar offset
-    // -- no per-load address registers; rows past the buffer are out of range and read as 0
+    // Buffer loads: one per-lane byte offset for K / Q and one for V plus scalar row / head offsets -- no 64-bit address registers
     float kvr[2][16], qreg[16];
     const int wv = __builtin_amdgcn_readfirstlane(wave);      // (scalar: the row-tile / key / head offsets below stay in SGPRs)
     typedef int i32x4_t __attribute__((ext_vector_type(4)));
@@ -729,20 +728,24 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
     const unsigned vvoff = (unsigned)((4 * half * HW + (int)p) * (QKV * 4) + l31 * 4);         // key 4 half of a 16-key group, feature
     const unsigned qvoff = (unsigned)((iqc * HW + (int)p) * (QKV * 4) + half * 16);
     auto kv_load = [&](int hh, int it, float (&reg)[16]) {
+        // the ROW part of the address goes into the per-lane offset: only that one is range-checked against the buffer size (the
+        // scalar offset is not), so rows past the buffer read as 0 instead of touching memory behind the tensor
         const int rt = it >> 1;
         if (!(wv & 1)) {
-            const int so = 32 * rt * HW * (QKV * 4) + (HEADS * DH + hh * DH) * 4;
+            const unsigned vo = kvoff + (unsigned)(32 * rt * HW * (QKV * 4));
+            const int so = (HEADS * DH + hh * DH) * 4;
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
-                const f32x4 v = __builtin_bit_cast(f32x4, (i32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsx, kvoff, so + 32 * c, 0));
+                const f32x4 v = __builtin_bit_cast(f32x4, (i32x4_t)__builtin_amdgcn_raw_buffer_load_b128(rsx, vo, so + 32 * c, 0));
 #pragma unroll
                 for (int e = 0; e < 4; ++e) reg[4 * c + e] = v[e];
             }
         } else {
+            const int so = (2 * HEADS * DH + hh * DH) * 4;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int so = (32 * rt + (r & 3) + 8 * (r >> 2)) * HW * (QKV * 4) + (2 * HEADS * DH + hh * DH) * 4;
-                reg[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, vvoff, so, 0));
+                const unsigned vo = vvoff + (unsigned)((32 * rt + (r & 3) + 8 * (r >> 2)) * HW * (QKV * 4));
+                reg[r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsx, vo, so, 0));
             }
         }
     };
