@@ -1872,14 +1872,17 @@ __global__ __launch_bounds__(512) void gemm1x1_rowreg_kernel(const dawn_conv_des
         const __amdgpu_buffer_rsrc_t rb =
             __builtin_amdgcn_make_buffer_rsrc((void*)((d.in1 ? d.in1 : d.in0) + r0 * ld1), 0, 32 * ld1 * 4, 0x00020000);
         f32x4 raw[KS][2];
+        // one per-lane byte offset per source (row l31, k-half); the channel chunk goes into the scalar / immediate offset (16 separate
+        // offset registers otherwise, hoisted out of the unit loop)
+        const unsigned vo0 = (unsigned)((l31 * d.ld0 + 8 * half) * 4), vo1 = (unsigned)((l31 * ld1 + 8 * half) * 4);
 #pragma unroll
         for (int kc = 0; kc < KS; ++kc) {
             const int cb = 16 * kc;                        // wave-uniform: C0 % 16 == 0
 #pragma unroll
             for (int h2 = 0; h2 < 2; ++h2)
                 raw[kc][h2] = __builtin_bit_cast(
-                    f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((l31 * d.ld0 + cb + 8 * half + 4 * h2) * 4), 0, 0)
-                                     : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((l31 * ld1 + cb - d.C0 + 8 * half + 4 * h2) * 4), 0, 0));
+                    f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, vo0, (cb + 4 * h2) * 4, 0)
+                                     : __builtin_amdgcn_raw_buffer_load_b128(rb, vo1, (cb - d.C0 + 4 * h2) * 4, 0));
         }
         float mu = 0.f, rs = 1.f;
         if (d.row_mean) { mu = d.row_mean[r0 + l31]; rs = d.row_rstd[r0 + l31]; }
