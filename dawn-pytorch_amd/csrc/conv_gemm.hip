@@ -2274,9 +2274,13 @@ static bool gemm1x1_rowacc_ok(long M, int N, int C0, int C1) {
 
 template <int MODE>
 static void launch_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
-    const int nch = d.N == 64 ? 1 : ((d.N == 128 || d.N == 256) ? 2 : 3);
-    const long npanels = (MODE == 2 ? 4 : 1) * (M / 256) * (d.N / (nch * 64));
+    int nch = d.N == 64 ? 1 : ((d.N == 128 || d.N == 256) ? 2 : 3);
     const int ncu = dawn_ncu();
+    const int Ktot = (MODE == 0 ? 1 : (MODE == 1 ? 16 : 4)) * (d.C0 + d.C1);
+    // the deepest level (M = 12,800: 50 row panels) leaves most CUs without a workgroup: one 64-column chunk per unit there -- the
+    // rows of a panel are fetched and split once per chunk instead of once per 2..3, on 2..3x as many CUs
+    if (nch > 1 && (MODE == 2 ? 4 : 1) * (M / 256) * (d.N / (nch * 64)) * 2 <= ncu && (MODE != 0 || Ktot % 128 == 0)) nch = 1;
+    const long npanels = (MODE == 2 ? 4 : 1) * (M / 256) * (d.N / (nch * 64));
     const int per = (int)((npanels + ncu - 1) / ncu);
     const int nwg = (int)((npanels + per - 1) / per);
     if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
@@ -2286,8 +2290,8 @@ static void launch_rowacc(const dawn_conv_desc& d, long M, hipStream_t s) {
         (void)hipFuncSetAttribute((const void*)gemm1x1_rowacc_kernel<NCHV, KSV, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
         hipLaunchKernelGGL((gemm1x1_rowacc_kernel<NCHV, KSV, MODE>), dim3(nwg), dim3(512), lds, s, d, M, per);             \
     } while (0)
-    if (d.N == 64) { if constexpr (MODE == 0) LAUNCH_RA(1, 8); else LAUNCH_RA(1, 4); }
-    else if (d.N == 128 || d.N == 256) LAUNCH_RA(2, 4);
+    if (nch == 1) { if constexpr (MODE == 0) LAUNCH_RA(1, 8); else LAUNCH_RA(1, 4); }
+    else if (nch == 2) LAUNCH_RA(2, 4);
     else { if constexpr (MODE == 0) LAUNCH_RA(3, 4); }
 #undef LAUNCH_RA
 }
@@ -2366,7 +2370,7 @@ int gemm1x1_split_plan(long M, int N, int C0, int C1) {
     if (N % 128 == 0) {
         const long t2 = (M / 256) * (N / 128);
         if (t2 >= 256 || (t2 >= 128 && M >= 51200)) plan = 2;
-        else plan = t2 < 128 ? 1 : 0;
+        else plan = (t2 < 128 || M <= 12800) ? 1 : 0;    // (M = 12,800 with 128..255 wide tiles fell through to the fp32 kernel: 128 x 64 tiles below)
     } else {
         plan = N == 64 ? 0 : 1;
     }
