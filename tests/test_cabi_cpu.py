@@ -67,7 +67,7 @@ def test_host_side_helpers_match_python_and_reference():
     for rel, b in zip(g["rel"].tolist(), g["bucket"].tolist()):
         assert L.dawn_rel_pos_bucket(int(rel)) == int(b), rel
     # the split-GEMM dispatch predicate is a host function of the library (HipOps asks it, there is no Python mirror)
-    want = {(204800, 768, 128, 0): 1, (819200, 64, 64, 64): 1, (12800, 768, 512, 0): 1, (12800, 512, 256, 0): 0, (256, 768, 128, 0): 0,
+    want = {(204800, 768, 128, 0): 1, (819200, 64, 64, 64): 1, (12800, 768, 512, 0): 1, (12800, 512, 256, 0): 1, (256, 768, 128, 0): 0,
             (12801, 768, 128, 0): 0, (204800, 768, 48, 0): 0, (819200, 64, 256, 0): 1, (819200, 64, 192, 0): 0, (51200, 192, 256, 256): 1}
     for (M, N, C0, C1), ok in want.items():
         assert int(L.dawn_gemm1x1_split_ok(M, N, C0, C1)) == ok, (M, N, C0, C1)
