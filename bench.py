@@ -175,11 +175,12 @@ def shard_sim(unet, diff, T, h, device, single_ms, world=8, rank=3, rccl=False):
                     "the unsharded clip of the same length"}
 
 
-def max_clip_frames(unet, diff, h, device, world, win=40, probes=(320, 480)):
+def max_clip_frames(unet, diff, h, device, world, win=40, probes=(1600, 3200)):
     """Second half of BASELINE's metric ("max clip length in HBM"): peak allocator bytes of one full DDIM step (UNet
     evaluation + dynamic threshold + update) at two probe lengths on the long-clip kernel path (> 200 frames: the fused
     64-channel temporal layers run as 120-query segments on overlapping row windows), a linear fit of bytes/frame, and the largest T with fixed + T * per_frame
-    <= 97 % of this GPU's HBM.  T-sharded over N GPUs every rank holds its T/N frames plus 2*win halo frames at the
+    <= 97 % of this GPU's HBM (probes long enough for the peak to sit where it sits on long clips: with 320 / 480 frames the
+    constant-size segment buffers moved it and the slope came out 15 % low).  T-sharded over N GPUs every rank holds its T/N frames plus 2*win halo frames at the
     attention inputs, so the clip limit grows as N * (per_gpu - 2*win).  (tools/max_clip_length.py additionally
     PROVES a length by running it: profiles/r1_max_clip_length.log, 12,070 frames.)"""
     from dawn_pytorch_amd.sampler import ddim_sample_clip, ddim_step_scalars

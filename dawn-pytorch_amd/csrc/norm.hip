@@ -134,9 +134,10 @@ __global__ void gn_finalize_kernel(const double* __restrict__ sums, double count
     if (c < C) gn_coeff(sums, count, gamma, beta, fs, fsh, C, eps, a, b, c);
 }
 
-__global__ __launch_bounds__(256) void gn_apply_res_kernel(const float* __restrict__ x, const float* __restrict__ a,
+// (x and out may be the SAME buffer -- every element is read and written by one thread: no __restrict__ on them)
+__global__ __launch_bounds__(256) void gn_apply_res_kernel(const float* x, const float* __restrict__ a,
                                                            const float* __restrict__ b, const float* __restrict__ res,
-                                                           float* __restrict__ out, long n4, int q) {
+                                                           float* out, long n4, int q) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         const int cq = (int)(i % q);
         const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];

@@ -238,10 +238,12 @@ class HipOps:
                                       Cc, eps, _p(a), _p(b), s), "dawn_gn_finalize")
         return a, b
 
-    def gn_apply_res(self, x: Tensor, a: Tensor, b: Tensor, res: Optional[Tensor]) -> Tensor:
+    def gn_apply_res(self, x: Tensor, a: Tensor, b: Tensor, res: Optional[Tensor], inplace: bool = False) -> Tensor:
+        """out = SiLU(x * a + b) (+ res); inplace: written over x (the caller has no further use for the GroupNorm input --
+        one tensor less at the allocator peak of long clips)."""
         rows, Cc = x.shape
         assert x.is_contiguous() and (res is None or res.is_contiguous())
-        out = self.empty(rows, Cc, like=x)
+        out = x if inplace else self.empty(rows, Cc, like=x)
         check(self.L.dawn_gn_apply_res(_p(x), _p(a), _p(b), _p(res), _p(out), rows, Cc, self._stream()),
               "dawn_gn_apply_res")
         return out

@@ -140,6 +140,7 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
             # two-stream overlap this replaces bought nothing on a power-limited chip (profiles/r3_*: 145.4 vs 140 frames/s without it)
             c1, ab1 = conv1_and_stats()
             h1 = cross_attention(gn=(c1, ab1[0], ab1[1]))
+            del c1                   # (dropped as soon as its last reader is enqueued: peak memory, max clip length)
         else:
             # the HBM-bound cross-attention chain and the MFMA-bound conv1 + GroupNorm statistics only meet at
             # h1 = SiLU(GN(c1)) + h_cond: run them on two HIP streams so that they overlap on the GPU
@@ -150,14 +151,16 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     # the 3x3 loader: an implicit GEMM reads every input element 9x, and 9x exp/div per element cost the conv
     # ~35 % of its MFMA rate (profiles/r1_b_conv_shapes.txt) -- far more than the extra 3 x C x 4 B per pixel.
     if h1 is None:
-        h1 = ops.gn_apply_res(c1, ab1[0], ab1[1], hcond)
+        h1 = ops.gn_apply_res(c1, ab1[0], ab1[1], hcond, inplace=True)      # (over c1: it has no other reader)
+        del c1, hcond
     part2 = ops.conv_gn_part(F * H * W, Co, x)
     c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, w_bf3=rb.w2s, **g)
+    del h1
     a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows, part=part2)
     if rb.wr is not None:
         return ops.conv_gemm(x, rb.wr, Co, in1=x2, bias=rb.br, tr=(c2, a2, b2), w_bf3=rb.wrs, **g)
     assert x2 is None
-    return ops.gn_apply_res(c2, a2, b2, x)
+    return ops.gn_apply_res(c2, a2, b2, x, inplace=True)
 
 
 def _chunks(a: int, b: int, n: int):
@@ -176,8 +179,23 @@ def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipSta
         # long frame buffers (clips > 200 frames): the fused layer, one launch per 120-query segment
         return ops.temporal_layer_c64_segmented(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
                                                 wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp)
+    if F > LONG_CLIP_FRAMES:
+        # long clips: the (rows, 768) qkv tensor of an unfused level -- 3 MB per frame at the 128-channel level, the allocator peak
+        # of the whole evaluation -- is built per segment of 200 query frames on the row window [a - win, b + win) (attention is
+        # window-local, rotary positions only matter relatively: same argument as temporal_layer_c64_segmented); the price is the
+        # projection of the 2 * win overlap rows per segment
+        out = ops.empty(F * HW, a.C, like=x)
+        for fa, fb in _chunks(0, F, TEMPORAL_SEG_FRAMES):
+            ea, eb = max(0, fa - cs.win), min(F, fb + cs.win)
+            qkv = _ln_gemm(ops, x[ea * HW:eb * HW], None, a.wqkv, 768, a.wqkv_s, F=eb - ea, Hi=H, Wi=W)
+            o = ops.temporal_attn(qkv, eb - ea, HW, fa - ea, fb - fa, cs.win, cs.rcos, cs.rsin, cs.band)
+            del qkv
+            ops.conv_gemm(o, a.wout, a.C, res=x[fa * HW:fb * HW], F=fb - fa, Hi=H, Wi=W, w_bf3=a.wout_s, out=out[fa * HW:fb * HW])
+            del o
+        return out
     qkv = _ln_gemm(ops, xe, None, a.wqkv, 768, a.wqkv_s, F=Fext, Hi=H, Wi=W)
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, cs.win, cs.rcos, cs.rsin, cs.band)
+    del qkv
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 
@@ -267,18 +285,39 @@ def _spatial_then_temporal(ops, sp, tattn: PackedAttn, x: Tensor, F: int, H: int
     return _temporal(ops, tattn, own, F, H, W, cs, hx)
 
 
+LONG_CLIP_FRAMES = 256      # above this the unfused attention levels build their qkv tensor per frame segment (peak memory) ...
+TEMPORAL_SEG_FRAMES = 200   # ... of this many query frames (+ win halo rows on either side) for the temporal attention,
+FRAME_CHUNK = 256           # ... of this many frames for the frame-local (spatial) ones
+
+
+def _per_frame_attention(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, out: Optional[Tensor], core, bias) -> Tensor:
+    """x + to_out(core(to_qkv(LayerNorm(x)))) for a frame-local attention core; long clips in frame chunks (no halo: frame-local),
+    so that the (rows, 768) qkv tensor stays bounded."""
+    HW = H * W
+    if F <= LONG_CLIP_FRAMES:
+        qkv = _ln_gemm(ops, x, None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W)
+        o = core(qkv, F, HW)
+        del qkv
+        return ops.conv_gemm(o, a.wout, a.C, bias=bias, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s, out=out)
+    if out is None:
+        out = ops.empty(F * HW, a.C, like=x)
+    for fa, fb in _chunks(0, F, FRAME_CHUNK):
+        qkv = _ln_gemm(ops, x[fa * HW:fb * HW], None, a.wqkv, 768, a.wqkv_s, F=fb - fa, Hi=H, Wi=W)
+        o = core(qkv, fb - fa, HW)
+        del qkv
+        ops.conv_gemm(o, a.wout, a.C, bias=bias, res=x[fa * HW:fb * HW], F=fb - fa, Hi=H, Wi=W, w_bf3=a.wout_s, out=out[fa * HW:fb * HW])
+        del o
+    return out
+
+
 def _spatial_linear(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, out: Optional[Tensor] = None) -> Tensor:
     if a.C == 64:
         return ops.sla_layer_c64(x, F, H * W, a.wqkv, a.wout, a.bout, wqkv_bf3=a.wqkv_s, out=out)
-    qkv = _ln_gemm(ops, x, None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W)
-    o = ops.sla(qkv, F, H * W)
-    return ops.conv_gemm(o, a.wout, a.C, bias=a.bout, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s, out=out)
+    return _per_frame_attention(ops, a, x, F, H, W, out, ops.sla, a.bout)
 
 
 def _mid_spatial(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, out: Optional[Tensor] = None) -> Tensor:
-    qkv = _ln_gemm(ops, x, None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W)
-    o = ops.frame_attn(qkv, F, H * W)
-    return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s, out=out)
+    return _per_frame_attention(ops, a, x, F, H, W, out, ops.frame_attn, None)
 
 
 def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_all: Optional[Tensor] = None) -> Tensor:
@@ -304,10 +343,19 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
         r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
         x = _temporal(ops, P.init_tattn, r, F, H, W, cs)
     skips: List[Tuple[Tensor, int, int]] = []
+    sharded = cs.comm is not None and hasattr(cs.comm, "own_view")
+
+    def _spatial_temporal(sp, tattn, xin, spatial):
+        # unsharded: two statements, so that the spatial layer's input is not held across the temporal layer (peak memory)
+        if sharded:
+            return _spatial_then_temporal(ops, sp, tattn, xin, F, H, W, cs, spatial)
+        y = spatial(ops, sp, xin, F, H, W)
+        del xin
+        return _temporal(ops, tattn, y, F, H, W, cs)
     for lvl in P.downs:
         x = _resblock(ops, lvl["rb1"], x, None, F, H, W, film_all, cs)
         x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)
-        x = _spatial_then_temporal(ops, lvl["sla"], lvl["tattn"], x, F, H, W, cs, _spatial_linear)
+        x = _spatial_temporal(lvl["sla"], lvl["tattn"], x, _spatial_linear)
         skips.append((x, H, W))
         if lvl["down"] is not None:
             wd, bd, wds = lvl["down"]
@@ -315,14 +363,15 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
                               bias=bd, w_bf3=wds)
             H, W = H // 2, W // 2
     x = _resblock(ops, P.mid["rb1"], x, None, F, H, W, film_all, cs)
-    x = _spatial_then_temporal(ops, P.mid["sattn"], P.mid["tattn"], x, F, H, W, cs, _mid_spatial)
+    x = _spatial_temporal(P.mid["sattn"], P.mid["tattn"], x, _mid_spatial)
     x = _resblock(ops, P.mid["rb2"], x, None, F, H, W, film_all, cs)
     for lvl in P.ups:
         skip, sh, sw = skips.pop()
         assert (sh, sw) == (H, W)
         x = _resblock(ops, lvl["rb1"], x, skip, F, H, W, film_all, cs)       # torch.cat((x, h.pop())) MT:948
+        del skip                     # (a loop variable would keep the level's skip tensor alive until the function returns)
         x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)
-        x = _spatial_then_temporal(ops, lvl["sla"], lvl["tattn"], x, F, H, W, cs, _spatial_linear)
+        x = _spatial_temporal(lvl["sla"], lvl["tattn"], x, _spatial_linear)
         if lvl["up"] is not None:
             wu, bu, wus = lvl["up"]
             x = ops.conv_gemm(x, wu, x.shape[1], F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=bu, w_bf3=wus)

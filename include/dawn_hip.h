@@ -97,7 +97,7 @@ int dawn_gn_finalize(const double* sums16, double count_per_group, const float* 
 int dawn_gn_reduce_finalize(const double* part, int nblk, double count_per_group, const float* gamma,
                             const float* beta, const float* film_scale, const float* film_shift, int C,
                             float eps, float* a, float* b, void* stream);
-/* out = silu(x*a[c]+b[c]) + res   (Block.act MT:248 + residual add MT:479) */
+/* out = silu(x*a[c]+b[c]) + res   (Block.act MT:248 + residual add MT:479); out may be x itself (in place) */
 int dawn_gn_apply_res(const float* x, const float* a, const float* b, const float* res, float* out,
                       long rows, int C, void* stream);
 

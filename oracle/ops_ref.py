@@ -120,7 +120,7 @@ class RefOps:
             b = b * sc + film[1]
         return a, b
 
-    def gn_apply_res(self, x, a, b, res):
+    def gn_apply_res(self, x, a, b, res, inplace=False):
         y = F_.silu(x * a[None, :] + b[None, :])
         return y if res is None else y + res
 

@@ -53,6 +53,24 @@ def test_tiny_unet_golden(tiny):
     assert log("tiny_unet_T24", y3, T(h["y"])) < 2e-5
 
 
+def test_long_clip_segmentation_of_the_unfused_attention_levels(tiny, monkeypatch):
+    """The long-clip form of the unfused attention levels (qkv per frame segment, unet_forward.LONG_CLIP_FRAMES) on the HIP op set:
+    == the whole-clip form and the reference golden (segment sizes shrunk so that the 24-frame golden runs several segments)."""
+    from dawn_pytorch_amd import unet_forward as UF
+    g, sd = tiny
+    h = load_golden("tiny_unet_T24.npz")
+    unet = tiny_unet(sd)
+    unet.update_num_frames(24)
+    args = (T(h["x"]).cuda(), T(h["time"]).cuda())
+    whole = unet.forward_with_cond_scale(*args, cond=T(h["cond"]).cuda(), cond_scale=1.0)
+    monkeypatch.setattr(UF, "LONG_CLIP_FRAMES", 4)
+    monkeypatch.setattr(UF, "TEMPORAL_SEG_FRAMES", 9)          # 24 frames: 3 segments with win = 3 halo rows
+    monkeypatch.setattr(UF, "FRAME_CHUNK", 7)
+    seg = unet.forward_with_cond_scale(*args, cond=T(h["cond"]).cuda(), cond_scale=1.0)
+    assert log("tiny_unet_T24_long_clip_segments_vs_whole", seg, whole.cpu()) < 5e-6
+    assert log("tiny_unet_T24_long_clip_segments", seg, T(h["y"])) < 2e-5
+
+
 def test_tiny_ddim_golden(tiny):
     g, sd = tiny
     d = load_golden("ddim_tiny.npz")

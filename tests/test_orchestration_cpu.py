@@ -78,6 +78,24 @@ def test_unet_orchestration_fused_and_unfused_routes_agree(tiny):
     torch.testing.assert_close(outs[0], outs[1], atol=2e-5, rtol=1e-5)
 
 
+def test_long_clip_segmentation_of_the_unfused_attention_levels(tiny, monkeypatch):
+    """Clips longer than LONG_CLIP_FRAMES build the (rows, 768) qkv tensors of the unfused levels per frame segment (temporal: query
+    segments on row windows with win halo rows; spatial: frame chunks): same result as the whole-clip form."""
+    from dawn_pytorch_amd import unet_forward as UF
+    g, sd = tiny
+    ops = RefOps()
+    P = pack_unet(sd, win=3, device="cpu")
+    x = T(g["x"])[0]
+    cs = build_clip_state(ops, P, x[3:, 0].contiguous(), T(g["cond"])[0])
+    whole = unet_forward(ops, P, cs, x[:3].contiguous(), int(g["time"][0]))
+    monkeypatch.setattr(UF, "LONG_CLIP_FRAMES", 4)
+    monkeypatch.setattr(UF, "TEMPORAL_SEG_FRAMES", 5)          # 12 frames: segments [0,5) [5,10) [10,12) with 3 halo rows
+    monkeypatch.setattr(UF, "FRAME_CHUNK", 7)
+    seg = unet_forward(ops, P, cs, x[:3].contiguous(), int(g["time"][0]))
+    torch.testing.assert_close(seg, whole, atol=2e-6, rtol=1e-6)
+    torch.testing.assert_close(seg, T(g["y"])[0], atol=3e-5, rtol=1e-5)
+
+
 def test_module_api_with_ref_ops(tiny):
     g, sd = tiny
     unet = D.DynamicNfUnet3D(default_num_frames=12, **TINY_KW)

@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""GPU: where does the allocator peak of one UNet evaluation on the long-clip path occur?  Wraps HipOps.empty, records the allocated
+bytes and the call stack at every allocation, prints the top moments."""
+import os, sys, traceback
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench
+from dawn_pytorch_amd.unet_forward import unet_forward
+dev = torch.device("cuda", 0)
+T, h = int(sys.argv[1]) if len(sys.argv) > 1 else 320, 64
+unet, diff = bench.build_model(200, h, 50, dev)
+ops, P = unet._ops(), unet.packed()
+fea, bbox, cond = bench.synthetic_inputs(T, h, dev)
+cs = unet.build_clip(torch.cat((fea, bbox), 1)[0].contiguous(), cond[0].contiguous())
+x0 = torch.randn(3, T, h, h, device=dev)
+unet_forward(ops, P, cs, x0, 500)
+torch.cuda.synchronize()
+base = torch.cuda.memory_allocated()
+log = []
+orig = type(ops).empty
+def empty(self, *a, **k):
+    t = orig(self, *a, **k)
+    st = [f"{f.name}:{f.lineno}" for f in traceback.extract_stack()[-6:-1]]
+    log.append((torch.cuda.memory_allocated() - base, t.numel() * 4, " < ".join(reversed(st))))
+    return t
+type(ops).empty = empty
+unet_forward(ops, P, cs, x0, 500)
+torch.cuda.synchronize()
+frame_mb = T * h * h * 64 * 4 / 1e6
+print(f"T={T}: one level-0 tensor = {frame_mb:.0f} MB; baseline (weights, clip tables, x) {base / 1e6:.0f} MB")
+for i, (tot, sz, st) in sorted(enumerate(log), key=lambda kv: -kv[1][0])[:8]:
+    print(f"alloc #{i}: live {tot / 1e6:8.0f} MB = {tot / 1e6 / frame_mb:5.2f} level-0 tensors  (+{sz / 1e6:.0f} MB)  {st}")
