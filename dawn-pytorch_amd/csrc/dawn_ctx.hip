@@ -216,6 +216,8 @@ int rel_pos_bucket(int rel) {
 // ---------------------------------------------------------------------------------------------------------
 // evaluation state: the ops of ops.py on raw pointers
 
+constexpr int LONG_CLIP_FRAMES = 256;   // unet_forward.LONG_CLIP_FRAMES: above this the unfused attention levels build qkv per frame segment
+
 struct T2 {                       // (rows, C) activation, contiguous
     float* p = nullptr;
     long rows = 0;
@@ -606,6 +608,27 @@ struct Eval {
             }
             return o;
         }
+        if (Fr > LONG_CLIP_FRAMES) {
+            // long clips: the (rows, 768) qkv tensor per segment of 200 query frames on the row window [a - win, b + win)
+            // (unet_forward._temporal: it was the memory peak of the evaluation)
+            o = t2(x.rows, a.C);
+            for (int fa = 0; fa < Fr; fa += 200) {
+                const int fb = fa + 200 < Fr ? fa + 200 : Fr;
+                const int ea = fa - win > 0 ? fa - win : 0, eb = fb + win < Fr ? fb + win : Fr;
+                T2 xv;
+                xv.p = x.p + (size_t)ea * HW * a.C; xv.rows = (long)(eb - ea) * HW; xv.C = a.C;
+                T2 qkv = ln_gemm(xv, nullptr, a.wqkv, 768, a.wqkv_s, eb - ea, H, W);
+                T2 at = t2((long)(fb - fa) * HW, 256);
+                LAUNCH(dawn_temporal_attn(qkv.p, eb - ea, HW, fa - ea, fb - fa, win, clipf(L.rcos), clipf(L.rsin), clipf(L.band), at.p, cur));
+                rel(qkv);
+                ConvArgs g;
+                g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.N = a.C; g.Fr = fb - fa; g.Hi = H; g.Wi = W;
+                g.res = x.p + (size_t)fa * HW * a.C; g.ld_res = a.C; g.out = o.p + (size_t)fa * HW * a.C; g.ld_out = a.C;
+                conv(g);
+                rel(at);
+            }
+            return o;
+        }
         T2 qkv = ln_gemm(x, nullptr, a.wqkv, 768, a.wqkv_s, Fr, H, W);
         T2 at = t2(x.rows, 256);
         LAUNCH(dawn_temporal_attn(qkv.p, Fr, HW, 0, Fr, win, clipf(L.rcos), clipf(L.rsin), clipf(L.band), at.p, cur));
@@ -628,32 +651,36 @@ struct Eval {
             A.free(ws);
             return o;
         }
-        T2 qkv = ln_gemm(x, nullptr, a.wqkv, 768, a.wqkv_s, Fr, H, W);
-        float* ctx = falloc((size_t)Fr * 8 * 32 * 32);
-        T2 at = t2(x.rows, 256);
-        LAUNCH(dawn_sla_context(qkv.p, Fr, HW, ctx, cur));
-        LAUNCH(dawn_sla_apply(qkv.p, ctx, Fr, HW, at.p, cur));
-        A.free(ctx);
-        rel(qkv);
-        o = t2(x.rows, a.C);
-        ConvArgs g;
-        g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.bias = a.bout; g.N = a.C; g.Fr = Fr; g.Hi = H; g.Wi = W;
-        g.res = x.p; g.ld_res = a.C; g.out = o.p; g.ld_out = a.C;
-        conv(g);
-        rel(at);
-        return o;
+        return per_frame_attention(a, x, Fr, H, W, true);
     }
-    T2 mid_spatial(const AT& a, const T2& x, int Fr, int H, int W) {
-        T2 qkv = ln_gemm(x, nullptr, a.wqkv, 768, a.wqkv_s, Fr, H, W);
-        T2 at = t2(x.rows, 256);
-        LAUNCH(dawn_frame_attn(qkv.p, Fr, H * W, at.p, cur));
-        rel(qkv);
+    T2 mid_spatial(const AT& a, const T2& x, int Fr, int H, int W) { return per_frame_attention(a, x, Fr, H, W, false); }
+    // x + to_out(core(to_qkv(LayerNorm(x)))) for a frame-local attention core (linear: MT:611-627; full per frame: MT mid block); long
+    // clips in chunks of 256 frames so that the (rows, 768) qkv tensor stays bounded (unet_forward._per_frame_attention)
+    T2 per_frame_attention(const AT& a, const T2& x, int Fr, int H, int W, bool linear) {
+        const int HW = H * W;
         T2 o = t2(x.rows, a.C);
-        ConvArgs g;
-        g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.N = a.C; g.Fr = Fr; g.Hi = H; g.Wi = W;
-        g.res = x.p; g.ld_res = a.C; g.out = o.p; g.ld_out = a.C;
-        conv(g);
-        rel(at);
+        const int step = Fr > LONG_CLIP_FRAMES ? 256 : Fr;
+        for (int fa = 0; fa < Fr; fa += step) {
+            const int fb = fa + step < Fr ? fa + step : Fr, Fc = fb - fa;
+            T2 xv;
+            xv.p = x.p + (size_t)fa * HW * a.C; xv.rows = (long)Fc * HW; xv.C = a.C;
+            T2 qkv = ln_gemm(xv, nullptr, a.wqkv, 768, a.wqkv_s, Fc, H, W);
+            T2 at = t2(xv.rows, 256);
+            if (linear) {
+                float* ctx = falloc((size_t)Fc * 8 * 32 * 32);
+                LAUNCH(dawn_sla_context(qkv.p, Fc, HW, ctx, cur));
+                LAUNCH(dawn_sla_apply(qkv.p, ctx, Fc, HW, at.p, cur));
+                A.free(ctx);
+            } else {
+                LAUNCH(dawn_frame_attn(qkv.p, Fc, HW, at.p, cur));
+            }
+            rel(qkv);
+            ConvArgs g;
+            g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.bias = linear ? a.bout : nullptr; g.N = a.C;
+            g.Fr = Fc; g.Hi = H; g.Wi = W; g.res = xv.p; g.ld_res = a.C; g.out = o.p + (size_t)fa * HW * a.C; g.ld_out = a.C;
+            conv(g);
+            rel(at);
+        }
         return o;
     }
 

@@ -38,7 +38,7 @@ def test_ctx_tiny_forward_golden_and_bit_identical(tiny):
     assert log("ctx_tiny_unet_own_rotary", got2[None], T(g["y"])) < 2e-5
 
 
-@pytest.mark.parametrize("Tn,h", [(16, 32), (5, 16), (232, 8)])
+@pytest.mark.parametrize("Tn,h", [(16, 32), (5, 16), (232, 8), (460, 8)])     # 460 > 256: the long-clip segmentation of the unfused levels
 def test_ctx_forward_equals_python_path(Tn, h):
     """Full DAWN architecture: every kernel family / fallback of the evaluation, bit-identical between the two hosts."""
     from fullsize_cases import KW, build_inputs
