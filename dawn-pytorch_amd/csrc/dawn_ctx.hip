@@ -708,6 +708,9 @@ struct Eval {
         T2 r = t2((long)F * H * W, dim);
         LAUNCH(dawn_init_conv_x(x3, c->w3, clipf(L.fea_pre), F, H, W, dim, r.p, cur));
         T2 x = temporal(c->init_tattn, r, F, H, W);
+        // long clips: the heads' skip is recomputed at the end (0.8 % of an evaluation) instead of held through it (unet_forward)
+        const bool lean = !sc && F > LONG_CLIP_FRAMES;
+        if (lean) rel(r);
         struct Skip { T2 t; int H, W; };
         std::vector<Skip> skips;
         for (size_t l = 0; l < c->downs.size(); ++l) {
@@ -757,11 +760,24 @@ struct Eval {
                 H *= 2; W *= 2;
             }
         }
-        T2 hg = resblock(c->head_g, x, &r, F, H, W, film);            // torch.cat((x, r)) MT:955
-        T2 ho = resblock(c->head_o, x, &r, F, H, W, film);
-        rel(x); rel(r);
-        LAUNCH(dawn_head_out(hg.p, ho.p, c->wg, c->bg, c->wo, c->bo, (long)F * H * W, hg.C, eps_out, cur));
-        rel(hg); rel(ho);
+        if (lean) {
+            // ... and the heads run one after the other, each projected to its rows of eps and dropped before the other one runs
+            r = t2((long)F * H * W, dim);
+            LAUNCH(dawn_init_conv_x(x3, c->w3, clipf(L.fea_pre), F, H, W, dim, r.p, cur));
+            T2 hg = resblock(c->head_g, x, &r, F, H, W, film);
+            LAUNCH(dawn_head_out(hg.p, nullptr, c->wg, c->bg, c->wo, c->bo, (long)F * H * W, hg.C, eps_out, cur));
+            rel(hg);
+            T2 ho = resblock(c->head_o, x, &r, F, H, W, film);
+            rel(x); rel(r);
+            LAUNCH(dawn_head_out(nullptr, ho.p, c->wg, c->bg, c->wo, c->bo, (long)F * H * W, ho.C, eps_out, cur));
+            rel(ho);
+        } else {
+            T2 hg = resblock(c->head_g, x, &r, F, H, W, film);            // torch.cat((x, r)) MT:955
+            T2 ho = resblock(c->head_o, x, &r, F, H, W, film);
+            rel(x); rel(r);
+            LAUNCH(dawn_head_out(hg.p, ho.p, c->wg, c->bg, c->wo, c->bo, (long)F * H * W, hg.C, eps_out, cur));
+            rel(hg); rel(ho);
+        }
         A.free(film);
         if (sk_ws) { A.free(sk_ws); sk_ws = nullptr; }
     }

@@ -115,7 +115,8 @@ __global__ __launch_bounds__(256) void init_conv_x_mfma_kernel(const float* __re
 }
 
 // heads (MT:863, 876, 956): eps[0:2] = Wg.hg + bg ; eps[2] = Wo.ho + bo ; output layout (3, rows)
-// 16 lanes per row.
+// 16 lanes per row.  hg or ho may be NULL: only the other head's rows of eps are written (long clips compute the heads one after the
+// other so that both head tensors are never alive together).
 __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__ hg, const float* __restrict__ ho,
                                                        const float* __restrict__ wg, const float* __restrict__ bg,
                                                        const float* __restrict__ wo, const float* __restrict__ bo,
@@ -125,21 +126,27 @@ __global__ __launch_bounds__(256) void head_out_kernel(const float* __restrict__
     float a0 = 0.f, a1 = 0.f, a2 = 0.f;
     if (row < rows) {
         for (int c = sub * 4; c < Co; c += 64) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(hg + row * Co + c);
-            const f32x4 o = *reinterpret_cast<const f32x4*>(ho + row * Co + c);
-            const f32x4 w0 = *reinterpret_cast<const f32x4*>(wg + c);
-            const f32x4 w1 = *reinterpret_cast<const f32x4*>(wg + Co + c);
-            const f32x4 w2 = *reinterpret_cast<const f32x4*>(wo + c);
-            a0 += g.x * w0.x + g.y * w0.y + g.z * w0.z + g.w * w0.w;
-            a1 += g.x * w1.x + g.y * w1.y + g.z * w1.z + g.w * w1.w;
-            a2 += o.x * w2.x + o.y * w2.y + o.z * w2.z + o.w * w2.w;
+            if (hg) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(hg + row * Co + c);
+                const f32x4 w0 = *reinterpret_cast<const f32x4*>(wg + c);
+                const f32x4 w1 = *reinterpret_cast<const f32x4*>(wg + Co + c);
+                a0 += g.x * w0.x + g.y * w0.y + g.z * w0.z + g.w * w0.w;
+                a1 += g.x * w1.x + g.y * w1.y + g.z * w1.z + g.w * w1.w;
+            }
+            if (ho) {
+                const f32x4 o = *reinterpret_cast<const f32x4*>(ho + row * Co + c);
+                const f32x4 w2 = *reinterpret_cast<const f32x4*>(wo + c);
+                a2 += o.x * w2.x + o.y * w2.y + o.z * w2.z + o.w * w2.w;
+            }
         }
     }
     a0 = wave_sum(a0, 16); a1 = wave_sum(a1, 16); a2 = wave_sum(a2, 16);
     if (row < rows && sub == 0) {
-        eps_out[row] = a0 + bg[0];
-        eps_out[rows + row] = a1 + bg[1];
-        eps_out[2 * rows + row] = a2 + bo[0];
+        if (hg) {
+            eps_out[row] = a0 + bg[0];
+            eps_out[rows + row] = a1 + bg[1];
+        }
+        if (ho) eps_out[2 * rows + row] = a2 + bo[0];
     }
 }
 

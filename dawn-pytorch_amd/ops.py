@@ -444,10 +444,15 @@ class HipOps:
                                          self._stream()), "dawn_init_conv_x")
         return out
 
-    def head_out(self, hg: Tensor, ho: Tensor, wg: Tensor, bg: Tensor, wo: Tensor, bo: Tensor) -> Tensor:
-        rows, Co = hg.shape
-        assert hg.is_contiguous() and ho.is_contiguous()
-        out = self.empty(3, rows, like=hg)
+    def head_out(self, hg: Optional[Tensor], ho: Optional[Tensor], wg: Tensor, bg: Tensor, wo: Tensor, bo: Tensor,
+                 out: Optional[Tensor] = None) -> Tensor:
+        """eps (3, rows): rows 0-1 from hg, row 2 from ho.  One of them may be None: only the other head's rows of `out` are written
+        (long clips run the heads one after the other)."""
+        ref = hg if hg is not None else ho
+        rows, Co = ref.shape
+        assert (hg is None or hg.is_contiguous()) and (ho is None or ho.is_contiguous()) and (out is not None or (hg is not None and ho is not None))
+        if out is None:
+            out = self.empty(3, rows, like=ref)
         check(self.L.dawn_head_out(_p(hg), _p(ho), _p(wg), _p(bg), _p(wo), _p(bo), rows, Co, _p(out),
                                    self._stream()), "dawn_head_out")
         return out

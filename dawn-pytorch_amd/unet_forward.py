@@ -342,6 +342,8 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
     else:
         r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
         x = _temporal(ops, P.init_tattn, r, F, H, W, cs)
+        if F > LONG_CLIP_FRAMES:
+            r = None                 # long clips: the heads' skip is recomputed at the end (0.8 % of an evaluation) instead of held through it
     skips: List[Tuple[Tensor, int, int]] = []
     sharded = cs.comm is not None and hasattr(cs.comm, "own_view")
 
@@ -376,6 +378,17 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
             wu, bu, wus = lvl["up"]
             x = ops.conv_gemm(x, wu, x.shape[1], F=F, Hi=H, Wi=W, Ho=2 * H, Wo=2 * W, KH=2, KW=2, mode=1, bias=bu, w_bf3=wus)
             H, W = 2 * H, 2 * W
+    if r is None:
+        # long clips: recompute the skip, and run the heads one after the other (each head's tensor is projected to its rows of eps and
+        # dropped before the other head runs): 4 level-0 tensors at the peak instead of 5
+        r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
+        hg = _resblock(ops, P.head_g, x, r, F, H, W, film_all, cs)
+        eps = ops.empty(3, F * H * W, like=hg)
+        ops.head_out(hg, None, P.wg, P.bg, P.wo, P.bo, out=eps)
+        del hg
+        ho = _resblock(ops, P.head_o, x, r, F, H, W, film_all, cs)
+        ops.head_out(None, ho, P.wg, P.bg, P.wo, P.bo, out=eps)
+        return eps.reshape(3, F, H, W)
     hg = _resblock(ops, P.head_g, x, r, F, H, W, film_all, cs)               # torch.cat((x, r)) MT:955
     ho = _resblock(ops, P.head_o, x, r, F, H, W, film_all, cs)
     eps = ops.head_out(hg, ho, P.wg, P.bg, P.wo, P.bo)                        # (3, rows)

@@ -206,7 +206,8 @@ int dawn_init_conv_x_ex(const float* x, long plane_stride, const float* w3, cons
                         float* out, void* stream);
 int dawn_init_conv_x(const float* x, const float* w3, const float* fea_pre, int F, int h, int w, int Co,
                      float* out, void* stream);
-/* ---- A13 heads: two 1x1 convs (Co->2, Co->1) + concat, written as (3,F,h,w) (MT:863,876,956) ------ */
+/* ---- A13 heads: two 1x1 convs (Co->2, Co->1) + concat, written as (3,F,h,w) (MT:863,876,956); hg or ho may be NULL: only the
+ * other head's rows of eps_out are written ------ */
 int dawn_head_out(const float* hg, const float* ho, const float* wg, const float* bg, const float* wo,
                   const float* bo, long rows, int Co, float* eps_out, void* stream);
 

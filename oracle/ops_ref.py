@@ -323,8 +323,16 @@ class RefOps:
             return out
         return y
 
-    def head_out(self, hg, ho, wg, bg, wo, bo):
-        return torch.cat((hg @ wg.t() + bg, ho @ wo.t() + bo), dim=1).t().contiguous()
+    def head_out(self, hg, ho, wg, bg, wo, bo, out=None):
+        if hg is not None and ho is not None and out is None:
+            return torch.cat((hg @ wg.t() + bg, ho @ wo.t() + bo), dim=1).t().contiguous()
+        if out is None:
+            out = torch.empty(3, (hg if hg is not None else ho).shape[0])
+        if hg is not None:
+            out[:2] = (hg @ wg.t() + bg).t()
+        if ho is not None:
+            out[2:] = (ho @ wo.t() + bo).t()
+        return out
 
     def linear(self, x, W, bias, act_in=0, out=None):
         if act_in == 1:
