@@ -13,6 +13,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=256)
 ap.add_argument("--probe", default="200,400,800")
 ap.add_argument("--try-frames", type=int, default=0, help="0 = 85 %% of the extrapolated limit")
+ap.add_argument("--host", choices=["python", "ctx"], default="python",
+                help="ctx = the C-side evaluator (dawn_sampler_run): two caller-owned allocations, no caching-allocator fragmentation")
 a = ap.parse_args()
 dev = torch.device("cuda", 0)
 h = a.res // 4
@@ -25,13 +27,20 @@ def one_step(T):
     fea, bbox, cond = bench.synthetic_inputs(T, h, dev)
     ops = unet._ops()
     P = unet.packed()
-    cs = unet.build_clip(torch.cat((fea, bbox), 1)[0].contiguous(), cond[0].contiguous())
+    cs = None if a.host == "ctx" else unet.build_clip(torch.cat((fea, bbox), 1)[0].contiguous(), cond[0].contiguous())
     steps = ddim_step_scalars({k: getattr(diff, k) for k in ("alphas_cumprod_prev", "sqrt_recip_alphas_cumprod",
                                                               "sqrt_recipm1_alphas_cumprod")}, 50, 1.0)[:1]
     x0 = ops.philox_normal(3, T, 0, T, h * h, 1, 0, dev).reshape(3, T, h, h)
     torch.cuda.synchronize(); torch.cuda.reset_peak_memory_stats()
     t0 = time.time()
-    out = ddim_sample_clip(ops, P, cs, x0, steps, lambda i: ops.philox_normal(3, T, 0, T, h * h, 1, i + 1, dev).reshape(3, T, h, h))
+    if a.host == "ctx":
+        ev = unet.ctx_evaluator()
+        fea272 = torch.cat((fea, bbox), 1)[0].contiguous()
+        clip = ev.prepare_clip(fea272, cond[0].contiguous())
+        out = ev.sample(clip, x0, steps, seed=1)
+        del clip, ev
+    else:
+        out = ddim_sample_clip(ops, P, cs, x0, steps, lambda i: ops.philox_normal(3, T, 0, T, h * h, 1, i + 1, dev).reshape(3, T, h, h))
     torch.cuda.synchronize()
     dt = time.time() - t0
     assert torch.isfinite(out).all()
