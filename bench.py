@@ -175,12 +175,12 @@ def shard_sim(unet, diff, T, h, device, single_ms, world=8, rank=3, rccl=False):
                     "the unsharded clip of the same length"}
 
 
-def max_clip_frames(unet, diff, h, device, world, win=40, probes=(1600, 3200)):
+def max_clip_frames(unet, diff, h, device, world, win=40, probes=(4800, 6400)):
     """Second half of BASELINE's metric ("max clip length in HBM"): peak allocator bytes of one full DDIM step (UNet
     evaluation + dynamic threshold + update) at two probe lengths on the long-clip kernel path (> 200 frames: the fused
     64-channel temporal layers run as 120-query segments on overlapping row windows), a linear fit of bytes/frame, and the largest T with fixed + T * per_frame
-    <= 97 % of this GPU's HBM (probes long enough for the peak to sit where it sits on long clips: with 320 / 480 frames the
-    constant-size segment buffers moved it and the slope came out 15 % low).  T-sharded over N GPUs every rank holds its T/N frames plus 2*win halo frames at the
+    <= 97 % of this GPU's HBM.  Probes above unet_forward.LONG_CLIP_FRAMES (4096): clips that long run the memory-lean form of an
+    evaluation (qkv of the unfused attention levels per frame segment, the heads' skip recomputed, the heads one after the other).  T-sharded over N GPUs every rank holds its T/N frames plus 2*win halo frames at the
     attention inputs, so the clip limit grows as N * (per_gpu - 2*win).  (tools/max_clip_length.py additionally
     PROVES a length by running it: profiles/r1_max_clip_length.log, 12,070 frames.)"""
     from dawn_pytorch_amd.sampler import ddim_sample_clip, ddim_step_scalars
@@ -209,8 +209,9 @@ def max_clip_frames(unet, diff, h, device, world, win=40, probes=(1600, 3200)):
     return {"per_gpu": per_gpu, "total": per_gpu if world == 1 else world * (per_gpu - 2 * win), "n_gpus": world,
             "bytes_per_frame": per_frame, "fixed_bytes": fixed, "hbm_bytes": total,
             "probes": [{"frames": T, "peak_bytes": p} for T, p in pts],
-            "method": "linear fit of the peak allocator bytes of one DDIM step at the two probe lengths (long-clip kernel path: segmented "
-                      "fused temporal layers); largest T with "
+            "method": "linear fit of the peak allocator bytes of one DDIM step at the two probe lengths (memory-lean long-clip path of clips "
+                      "> 4096 frames: segmented fused temporal layers, qkv of the unfused levels per frame segment, heads' skip recomputed); "
+                      "proved by running: 52,000 frames with this host, 58,000 through the C-side evaluator (profiles/r3_max_clip_length.log); largest T with "
                       "fixed + T*bytes_per_frame <= 0.97*HBM; T-sharded total = n_gpus*(per_gpu - 2*win halo frames)"}
 
 

@@ -137,6 +137,7 @@ struct dawn_ctx {
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int conv_policy = 0, temporal_flags = 0, overlap = 1;
+    int long_clip_frames = 4096;    // unet_forward.LONG_CLIP_FRAMES: clips longer than this run the memory-lean form (DAWN_OPT_LONG_CLIP_FRAMES)
     Arena arena;
     // profiling of conv launches (bench.py roofline): optional
     bool prof_on = false;
@@ -216,7 +217,6 @@ int rel_pos_bucket(int rel) {
 // ---------------------------------------------------------------------------------------------------------
 // evaluation state: the ops of ops.py on raw pointers
 
-constexpr int LONG_CLIP_FRAMES = 256;   // unet_forward.LONG_CLIP_FRAMES: above this the unfused attention levels build qkv per frame segment
 
 struct T2 {                       // (rows, C) activation, contiguous
     float* p = nullptr;
@@ -608,7 +608,7 @@ struct Eval {
             }
             return o;
         }
-        if (Fr > LONG_CLIP_FRAMES) {
+        if (Fr > c->long_clip_frames) {
             // long clips: the (rows, 768) qkv tensor per segment of 200 query frames on the row window [a - win, b + win)
             // (unet_forward._temporal: it was the memory peak of the evaluation)
             o = t2(x.rows, a.C);
@@ -659,7 +659,7 @@ struct Eval {
     T2 per_frame_attention(const AT& a, const T2& x, int Fr, int H, int W, bool linear) {
         const int HW = H * W;
         T2 o = t2(x.rows, a.C);
-        const int step = Fr > LONG_CLIP_FRAMES ? 256 : Fr;
+        const int step = Fr > c->long_clip_frames ? 256 : Fr;
         for (int fa = 0; fa < Fr; fa += step) {
             const int fb = fa + step < Fr ? fa + step : Fr, Fc = fb - fa;
             T2 xv;
@@ -709,7 +709,7 @@ struct Eval {
         LAUNCH(dawn_init_conv_x(x3, c->w3, clipf(L.fea_pre), F, H, W, dim, r.p, cur));
         T2 x = temporal(c->init_tattn, r, F, H, W);
         // long clips: the heads' skip is recomputed at the end (0.8 % of an evaluation) instead of held through it (unet_forward)
-        const bool lean = !sc && F > LONG_CLIP_FRAMES;
+        const bool lean = !sc && F > c->long_clip_frames;
         if (lean) rel(r);
         struct Skip { T2 t; int H, W; };
         std::vector<Skip> skips;
@@ -885,6 +885,7 @@ extern "C" int dawn_ctx_set_option(dawn_ctx* c, int option, int value) {
         case DAWN_OPT_CONV_POLICY: c->conv_policy = value; return 0;
         case DAWN_OPT_TEMPORAL_FLAGS: c->temporal_flags = value; return 0;
         case DAWN_OPT_OVERLAP: c->overlap = value ? 1 : 0; return 0;
+        case DAWN_OPT_LONG_CLIP_FRAMES: c->long_clip_frames = value > 0 ? value : 4096; return 0;
         case DAWN_OPT_PROFILE:
             c->prof_on = value != 0;
             return 0;

@@ -33,7 +33,7 @@ class DdimStep(C.Structure):
                 ("sqrt_alpha_next", C.c_float), ("c", C.c_float), ("sigma", C.c_float)]
 
 
-OPT_CONV_POLICY, OPT_TEMPORAL_FLAGS, OPT_OVERLAP, OPT_PROFILE = 1, 2, 3, 4
+OPT_CONV_POLICY, OPT_TEMPORAL_FLAGS, OPT_OVERLAP, OPT_PROFILE, OPT_LONG_CLIP_FRAMES = 1, 2, 3, 4, 5
 
 # ---- T-shard callbacks (include/dawn_hip.h: dawn_shard_comm)
 HALO_BEGIN_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_long, C.c_void_p)

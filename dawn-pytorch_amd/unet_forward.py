@@ -285,7 +285,8 @@ def _spatial_then_temporal(ops, sp, tattn: PackedAttn, x: Tensor, F: int, H: int
     return _temporal(ops, tattn, own, F, H, W, cs, hx)
 
 
-LONG_CLIP_FRAMES = 256      # above this the unfused attention levels build their qkv tensor per frame segment (peak memory) ...
+LONG_CLIP_FRAMES = 4096     # clips longer than this run the memory-lean form of an evaluation (4.8 instead of 8.4 MB per frame at 256x256, ~3 %
+                            # slower): the unfused attention levels build their qkv tensor per frame segment ...
 TEMPORAL_SEG_FRAMES = 200   # ... of this many query frames (+ win halo rows on either side) for the temporal attention,
 FRAME_CHUNK = 256           # ... of this many frames for the frame-local (spatial) ones
 

@@ -38,10 +38,15 @@ def test_ctx_tiny_forward_golden_and_bit_identical(tiny):
     assert log("ctx_tiny_unet_own_rotary", got2[None], T(g["y"])) < 2e-5
 
 
-@pytest.mark.parametrize("Tn,h", [(16, 32), (5, 16), (232, 8), (460, 8)])     # 460 > 256: the long-clip segmentation of the unfused levels
-def test_ctx_forward_equals_python_path(Tn, h):
+@pytest.mark.parametrize("Tn,h", [(16, 32), (5, 16), (232, 8), (460, 8)])     # 460: the memory-lean long-clip form
+def test_ctx_forward_equals_python_path(Tn, h, monkeypatch):
     """Full DAWN architecture: every kernel family / fallback of the evaluation, bit-identical between the two hosts."""
     from fullsize_cases import KW, build_inputs
+    from dawn_pytorch_amd import unet_forward as UF
+    from dawn_pytorch_amd.ctx import OPT_LONG_CLIP_FRAMES
+    lean = Tn == 460                # the memory-lean form of long clips (default above 4096 frames), switched on at 256 in both hosts
+    if lean:
+        monkeypatch.setattr(UF, "LONG_CLIP_FRAMES", 256)
     unet = D.DynamicNfUnet3D(default_num_frames=Tn, **KW, init_seed=0).cuda()
     ops, P = unet._ops(), unet.packed()
     fea272, cond, x3 = build_inputs(Tn, h)
@@ -49,6 +54,8 @@ def test_ctx_forward_equals_python_path(Tn, h):
     cs = unet.build_clip(fea272, cond)
     want = unet_forward(ops, P, cs, x3, 500)
     ev = CtxEvaluator(P)
+    if lean:
+        ev.set_option(OPT_LONG_CLIP_FRAMES, 256)
     clip = ev.prepare_clip(fea272, cond, cs.rcos, cs.rsin)
     got = ev.forward(clip, x3, 500.0)
     assert torch.equal(got, want), float((got - want).abs().max())

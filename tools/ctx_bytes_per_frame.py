@@ -11,7 +11,7 @@ unet, diff = bench.build_model(200, 64, 50, dev)
 ev = unet.ctx_evaluator()
 L, h = ev.L, ev.h
 rows = []
-for T in (200, 400, 1600, 3200, 6400):
+for T in (200, 400, 1600, 4800, 6400):
     rows.append((T, int(L.dawn_workspace_bytes(h, T, 64, 64)), int(L.dawn_clip_bytes(h, T, 64, 64))))
     print(f"T={T}: workspace {rows[-1][1] / 1e6:9.1f} MB  clip tables {rows[-1][2] / 1e6:8.1f} MB")
 (t1, w1, c1), (t2, w2, c2) = rows[-2], rows[-1]

@@ -11,7 +11,7 @@ from dawn_pytorch_amd.sampler import ddim_sample_clip, ddim_step_scalars
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--res", type=int, default=256)
-ap.add_argument("--probe", default="200,400,800")
+ap.add_argument("--probe", default="4800,6400", help="above unet_forward.LONG_CLIP_FRAMES: the memory-lean form of long clips")
 ap.add_argument("--try-frames", type=int, default=0, help="0 = 85 %% of the extrapolated limit")
 ap.add_argument("--host", choices=["python", "ctx"], default="python",
                 help="ctx = the C-side evaluator (dawn_sampler_run): two caller-owned allocations, no caching-allocator fragmentation")
