@@ -243,6 +243,20 @@ def _temporal_sharded(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs:
         comm.halo_end(hx)
         return ops.temporal_layer_c64(xe, Fext, HW, q0, F, win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
                                       wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp)
+    if F > LONG_CLIP_FRAMES:
+        # long shards: qkv per query segment on row windows of the extended buffer (as in _temporal; the projection of the own rows no
+        # longer overlaps the transfer -- the transfer of 2 * win frames is a 1 % matter at this length)
+        comm.halo_end(hx)
+        out = ops.empty(F * HW, a.C, like=x)
+        for fa, fb in _chunks(q0, q0 + F, TEMPORAL_SEG_FRAMES):
+            ea, eb = max(0, fa - win), min(Fext, fb + win)
+            qkv = _ln_gemm(ops, xe[ea * HW:eb * HW], None, a.wqkv, 768, a.wqkv_s, F=eb - ea, Hi=H, Wi=W)
+            o = ops.temporal_attn(qkv, eb - ea, HW, fa - ea, fb - fa, win, cs.rcos, cs.rsin, cs.band)
+            del qkv
+            ops.conv_gemm(o, a.wout, a.C, res=x[(fa - q0) * HW:(fb - q0) * HW], F=fb - fa, Hi=H, Wi=W, w_bf3=a.wout_s,
+                          out=out[(fa - q0) * HW:(fb - q0) * HW])
+            del o
+        return out
     # unfused levels: LayerNorm + qkv projection are row-local -> the own rows are projected during the transfer
     qkv = ops.empty(Fext * HW, 768, like=x)
     _ln_gemm(ops, xe[q0 * HW:(q0 + F) * HW], None, a.wqkv, 768, a.wqkv_s, F=F, Hi=H, Wi=W, out=qkv[q0 * HW:(q0 + F) * HW])
@@ -252,6 +266,7 @@ def _temporal_sharded(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs:
     if hx.hh:
         _ln_gemm(ops, xe[(q0 + F) * HW:], None, a.wqkv, 768, a.wqkv_s, F=hx.hh, Hi=H, Wi=W, out=qkv[(q0 + F) * HW:])
     o = ops.temporal_attn(qkv, Fext, HW, q0, F, win, cs.rcos, cs.rsin, cs.band)
+    del qkv
     return ops.conv_gemm(o, a.wout, a.C, res=x, F=F, Hi=H, Wi=W, w_bf3=a.wout_s)
 
 

@@ -44,11 +44,20 @@ def _inputs():
             torch.randn(1, TT, 32, generator=g))
 
 
-def _worker(rank, world, port, out_path, win=3, dim=16):
+def _lean(on):
+    """The memory-lean long-clip form (default above 4096 frames) switched on for the 6..24-frame test clips."""
+    if on:
+        sys.path.insert(0, ROOT)
+        from dawn_pytorch_amd import unet_forward as UF
+        UF.LONG_CLIP_FRAMES, UF.TEMPORAL_SEG_FRAMES, UF.FRAME_CHUNK = 4, 5, 7
+
+
+def _worker(rank, world, port, out_path, win=3, dim=16, lean=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT)
+    _lean(lean)
     from dawn_pytorch_amd.tshard import TShardComm
     F = TT // world
     diff = _build(F, win, dim)
@@ -62,17 +71,18 @@ def _worker(rank, world, port, out_path, win=3, dim=16):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,win,dim", [(2, 3, 16), (3, 3, 16), (3, 8, 16), (4, 6, 16), (4, 9, 16), (2, 3, 64), (3, 8, 64)],
+@pytest.mark.parametrize("world,win,dim,lean", [(2, 3, 16, False), (3, 3, 16, False), (3, 8, 16, False), (4, 6, 16, False), (4, 9, 16, False),
+                                                (2, 3, 64, False), (3, 8, 64, False), (2, 3, 16, True)],
                          ids=["w2", "w3-two-neighbours", "w3-F==win", "w4-F==win", "w4-F<win-multi-hop",
-                              "w2-dim64-fused-interior-first", "w3-dim64-F==win"])
-def test_tshard_equals_unsharded(tmp_path, world, win, dim):
+                              "w2-dim64-fused-interior-first", "w3-dim64-F==win", "w2-long-clip-lean-form"])
+def test_tshard_equals_unsharded(tmp_path, world, win, dim, lean):
     """24 frames over `world` ranks (F = 12 / 8 / 6 frames per rank): window 3 (one neighbour per side), F == win (the halo
     is the neighbour's whole shard) and F < win (the halo spans two ranks on each side)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out_path = str(tmp_path / "shard")
-    mp.spawn(_worker, args=(world, port, out_path, win, dim), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out_path, win, dim, lean), nprocs=world, join=True)
     parts = [torch.load(f"{out_path}.{r}") for r in range(world)]
     diff = _build(TT, win, dim)
     fea, bbox, cond = _inputs()
