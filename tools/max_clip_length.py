@@ -3,6 +3,11 @@
 Measures peak allocator memory of one full DDIM step (UNet evaluation + threshold + update) at a few clip
 lengths, fits bytes/frame, then PROVES a long clip by actually running one step at `--try-frames`."""
 import argparse, json, os, sys, time
+# the caching allocator's default block splitting fragments the pool on clips this long (52,000 frames pass, 56,000 fail with 55 GiB
+# reserved-but-unallocated); without splitting of blocks > 2 GiB 62,000 frames run (expandable segments are not supported on ROCm).
+# Must be in the environment before the allocator initialises; an explicit setting of the caller wins.
+os.environ.setdefault("PYTORCH_HIP_ALLOC_CONF", "max_split_size_mb:2048")
+os.environ.setdefault("PYTORCH_CUDA_ALLOC_CONF", os.environ["PYTORCH_HIP_ALLOC_CONF"])
 import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
