@@ -818,7 +818,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
         if constexpr (EXT) {
             // every outstanding request of this wave has landed before its registers are read (explicit, with the registers pinned
             // behind the wait: with the requests conditional on the work-item count the automatic counter placement let the second
-            // item of the last K wave be read early -- a timing-dependent wrong K tile, tools/dbg_ta.py)
+            // item of the last K wave be read early -- a timing-dependent wrong K tile on buffers of 8+ row tiles: test_temporal_attn[280-64-40-200-40])
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(kvr[0][0]), "+v"(kvr[0][1]), "+v"(kvr[0][2]), "+v"(kvr[0][3]), "+v"(kvr[0][4]), "+v"(kvr[0][5]), "+v"(kvr[0][6]), "+v"(kvr[0][7]), "+v"(kvr[0][8]), "+v"(kvr[0][9]), "+v"(kvr[0][10]), "+v"(kvr[0][11]), "+v"(kvr[0][12]), "+v"(kvr[0][13]), "+v"(kvr[0][14]), "+v"(kvr[0][15]) :: "memory");
             asm volatile("" : "+v"(kvr[1][0]), "+v"(kvr[1][1]), "+v"(kvr[1][2]), "+v"(kvr[1][3]), "+v"(kvr[1][4]), "+v"(kvr[1][5]), "+v"(kvr[1][6]), "+v"(kvr[1][7]), "+v"(kvr[1][8]), "+v"(kvr[1][9]), "+v"(kvr[1][10]), "+v"(kvr[1][11]), "+v"(kvr[1][12]), "+v"(kvr[1][13]), "+v"(kvr[1][14]), "+v"(kvr[1][15]) :: "memory");
 #pragma unroll
