@@ -358,8 +358,9 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
     else:
         r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
         x = _temporal(ops, P.init_tattn, r, F, H, W, cs)
-        if F > LONG_CLIP_FRAMES:
-            r = None                 # long clips: the heads' skip is recomputed at the end (0.8 % of an evaluation) instead of held through it
+    if F > LONG_CLIP_FRAMES:
+        r = None                     # long clips / shards: the heads' skip is recomputed at the end (0.8 % of an evaluation; frame-local, so
+                                     # no halo is involved) instead of held through the evaluation
     skips: List[Tuple[Tensor, int, int]] = []
     sharded = cs.comm is not None and hasattr(cs.comm, "own_view")
 
