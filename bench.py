@@ -7,7 +7,9 @@ A "step" is one pass of the hot path over one batch of synthetic input = ONE who
 (`GaussianDiffusion.sample`: 50 DDIM steps x one UNet evaluation each + dynamic-threshold quantile + DDIM
 update) of a 200-frame 256x256 clip (BASELINE.json configs[2], 64x64 latent).  Inputs (random-init
 weights of the real DAWN_256 architecture, fea / bbox / cond / Philox noise) are resident in HBM before
-the timed region.  N > 1 (launched by torch.distributed.run, one rank per GPU):
+the timed region.  N > 1: one rank per GPU -- started by torch.distributed.run (the driver's form), or by bench.py itself when
+`python bench.py --gpus N` is called plainly (launch_plan); a request that cannot be honoured exits non-zero, it never prints
+an `n_gpus: 1` line for `--gpus 8`:
   --mode tshard  (default): ONE clip of 200*N frames sharded along T, RCCL halo exchange + tiny
                  GroupNorm / quantile all-reduces (BASELINE configs[3] shape per GPU) -- weak scaling;
   --mode replica: N independent 200-frame clips, no collective (configs[4]) -- weak scaling.
@@ -215,6 +217,83 @@ def max_clip_frames(unet, diff, h, device, world, win=40, probes=(4800, 6400)):
                       "fixed + T*bytes_per_frame <= 0.97*HBM; T-sharded total = n_gpus*(per_gpu - 2*win halo frames)"}
 
 
+def other_configs(unet, device, S, which=((128, 400, 3, "BASELINE configs[1]: 128x128, 400-frame clip"),
+                                          (256, 1600, 1, "BASELINE configs[3]'s clip UNSHARDED on one GPU: 256x256, 1600 frames"))):
+    """OUTSIDE the timed region, N = 1: the other single-GPU-runnable workloads of BASELINE.json with the same weights (the architecture
+    does not depend on resolution or clip length), so that the driver's bench line carries them too.  Each: one short warm-up clip
+    (2 DDIM steps: allocator, per-shape buffers), then `clips` whole clips of S DDIM steps timed together, HIP-synchronised on both sides."""
+    import dawn_pytorch_amd as D
+    out = []
+    for res, T, clips, what in which:
+        h = res // 4
+        try:
+            unet.update_num_frames(T)
+            fea, bbox, cond = synthetic_inputs(T, h, device)
+            for steps in (2, S):
+                diff = D.DynamicNfGaussianDiffusion(default_num_frames=T, denoise_fn=unet, num_frames=T, image_size=h, sampling_timesteps=steps,
+                                                    timesteps=1000, loss_type='l2', use_dynamic_thres=True, null_cond_prob=0.1,
+                                                    ddim_sampling_eta=1.0).to(device)
+                diff.noise_seed = 1234
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(1 if steps == 2 else clips):
+                    o = diff.sample(fea, bbox, cond=cond, cond_scale=1.0)
+                torch.cuda.synchronize()
+                dt = time.perf_counter() - t0
+            assert torch.isfinite(o).all()
+            alg = algorithmic_flops_per_forward(T, h) * S * clips
+            out.append({"workload": f"{what}, {S} DDIM steps, window 40, eta 1.0, cond_scale 1.0", "frames_per_s": T * clips / dt, "clips": clips,
+                        "ms_per_clip": dt / clips * 1e3, "whole_path_algorithmic_tflops": alg / dt / 1e12})
+            del o, fea, bbox, cond
+            torch.cuda.empty_cache()
+        except Exception as e:                                # noqa: BLE001  (a report, never the metric)
+            out.append({"workload": what, "error": f"{type(e).__name__}: {str(e)[:200]}"})
+    return out
+
+
+class LaunchError(SystemExit):
+    """bench.py refuses to run rather than report a GPU count it did not use (exit code 2, message on stderr)."""
+
+    def __init__(self, msg):
+        print(f"bench.py: {msg}", file=sys.stderr, flush=True)
+        super().__init__(2)
+
+
+def launch_plan(gpus: int, env, device_count: int, argv):
+    """Who runs the ranks?  Returns ("run", None) when THIS process is a rank (a 1-GPU run, or a rank that torch.distributed.run started:
+    WORLD_SIZE in the environment and equal to --gpus), ("spawn", cmd) when `python bench.py --gpus N` was called plainly with N > 1 --
+    the driver's form -- and bench.py has to start the N ranks itself, and raises LaunchError for every request that cannot be honoured
+    (fewer visible devices than --gpus, a WORLD_SIZE that contradicts --gpus): a `--gpus 8` request must never end as an `n_gpus: 1` line."""
+    if gpus < 1:
+        raise LaunchError(f"--gpus {gpus}: need at least one GPU")
+    ws = env.get("WORLD_SIZE")
+    if ws is not None:
+        if int(ws) != gpus:
+            raise LaunchError(f"WORLD_SIZE={ws} in the environment but --gpus {gpus}: the launcher's rank count and the request disagree")
+        return "run", None
+    if gpus == 1:
+        return "run", None
+    if device_count < gpus:
+        raise LaunchError(f"--gpus {gpus} requested but only {device_count} HIP device(s) are visible")
+    import socket
+    with socket.socket() as sk:                        # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__), *argv]
+    return "spawn", cmd
+
+
+def device_identity(device) -> str:
+    """Something that distinguishes physical GPUs (the ranks all-gather it: N ranks on fewer than N devices is an error, not a line)."""
+    p = torch.cuda.get_device_properties(device)
+    for k in ("uuid", "pci_bus_id"):
+        v = getattr(p, k, None)
+        if v is not None:
+            return f"{k}:{v}:{getattr(p, 'pci_domain_id', 0)}:{getattr(p, 'pci_device_id', 0)}"
+    return f"index:{torch.cuda.current_device()}"
+
+
 def tshard_preflight(dist, rank, world, device) -> bool:
     """Tiny T-sharded sample over RCCL (halo send/recv + fp64 / int32 all-reduces).  Any failure on any rank
     makes every rank fall back to replica mode instead of losing the whole scaling run."""
@@ -262,6 +341,8 @@ def main():
     ap.add_argument("--shard-sim-rccl", action="store_true",
                     help="shard_sim: run its all-reduces on a world-size-1 RCCL communicator (RCCL prints a banner on stdout at "
                          "init, so this is opt-in; default: the all-reduces are skipped)")
+    ap.add_argument("--no-other-configs", action="store_true",
+                    help="skip the (untimed) runs of BASELINE configs[1] and of the unsharded 1600-frame clip reported as `other_configs`")
     ap.add_argument("--no-shard-sim", action="store_true",
                     help="skip the (untimed) single-GPU measurement of one interior T-shard rank's workload")
     ap.add_argument("--event-every", type=int, default=5,
@@ -285,17 +366,34 @@ def main():
                     help="with graphs: every n-th DDIM step runs eagerly so HIP events sample the conv kernel live")
     args = ap.parse_args()
 
+    what, cmd = launch_plan(args.gpus, os.environ, torch.cuda.device_count(), sys.argv[1:])
+    if what == "spawn":
+        # `python bench.py --gpus N` called plainly: start the N ranks (one process per GPU, RCCL rendezvous on 127.0.0.1) and hand
+        # their exit code on; rank 0 of that job prints the JSON line
+        import subprocess
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        sys.exit(subprocess.call(cmd, env=env))
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    assert world == args.gpus or world == 1, f"WORLD_SIZE={world} but --gpus {args.gpus}"
+    if local_rank >= torch.cuda.device_count():
+        raise LaunchError(f"LOCAL_RANK={local_rank} but only {torch.cuda.device_count()} HIP device(s) are visible")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
+    ranks_seen, devices_seen = 1, 1
     if world > 1 or os.environ.get("DAWN_FORCE_DIST") == "1":
         import datetime
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
+        # the rank count RCCL actually formed, and the physical devices behind it (never trusted from the environment)
+        ranks_seen = dist.get_world_size()
+        ids = [None] * ranks_seen
+        dist.all_gather_object(ids, device_identity(device))
+        devices_seen = len(set(ids))
+        if ranks_seen != args.gpus or devices_seen != ranks_seen:
+            dist.destroy_process_group()
+            raise LaunchError(f"--gpus {args.gpus} but the communicator has {ranks_seen} rank(s) on {devices_seen} distinct device(s)")
 
     T, h, S = args.frames, args.res // 4, args.ddim_steps
     comm, mode = None, "single"
@@ -355,13 +453,16 @@ def main():
         dt = float(tt.item())
     assert torch.isfinite(out).all(), "non-finite output"
 
+    per_rank = None
+    if dist is not None:
+        per_rank = [None] * ranks_seen
+        dist.all_gather_object(per_rank, dict(comm.stats() if comm is not None else {"rank": rank, "world": ranks_seen},
+                                              device=device_identity(device), ms_per_clip=clip_ms[len(clip_ms) // 2]))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
         return
-    n_gpus = world
-    if dist is not None and world == 1:
-        mode = {"tshard": "tshard", "replica": "replica"}[mode]
+    n_gpus = ranks_seen          # what the communicator reported (== --gpus, checked above), not what the environment claimed
     frames_total = T * n_gpus * args.steps
     value = frames_total / dt
     result = {
@@ -503,13 +604,19 @@ def main():
             result["shard_sim"] = shard_sim(unet, diff, T, h, device, clip_ms[len(clip_ms) // 2], rccl=args.shard_sim_rccl)
         except Exception as e:                                # noqa: BLE001  (a report, never the metric)
             result["shard_sim"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+    if n_gpus == 1 and mode == "single" and not args.no_other_configs and (args.res, T, S) == (256, 200, 50):
+        result["other_configs"] = other_configs(unet, device, S)
+        unet.update_num_frames(T)
     if not args.no_max_clip:
         try:
             result["max_clip_frames"] = max_clip_frames(unet, diff, h, device, n_gpus)
         except Exception as e:                                # noqa: BLE001  (a report, never the metric)
             result["max_clip_frames"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
-    if comm is not None:
-        result["comm"] = comm.stats()
+    if dist is not None:
+        result["comm"] = {"backend": "nccl (RCCL)", "world": ranks_seen, "distinct_devices": devices_seen, "mode": mode,
+                          **(comm.stats() if comm is not None else {"halo_exchanges": 0, "all_reduces": 0,
+                                                                   "note": "replica mode: no data-path collective"}),
+                          "per_rank": per_rank}
     if not args.no_cpu_baseline and n_gpus == 1:
         sd = {"denoise_fn." + k: v.detach().cpu() for k, v in unet.state_dict().items()}
         result["cpu_baseline"] = cpu_baseline(h, S, args.cpu_sample_frames, sd)

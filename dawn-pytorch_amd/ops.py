@@ -47,13 +47,15 @@ class HipOps:
         self.temporal_attn_flags = 0  # dawn_temporal_attn_ex flags (1 = the fp32-MFMA attention core; A/B and tests)
         self.stream_k = True         # supply the stream-K scratch when conv_policy selects that kernel (bit 0x400; opt-in)
         self.fuse_h1 = True          # cross-attention kernels write h1 = SiLU(GN(c1)) + h_cond themselves (False: A/B, two-stream form)
-        self._sk_ws = {}             # device index -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
-        self._sel_ws = {}            # device index -> scratch of the threshold selection (histograms, state)
+        self._sk_ws = {}             # (device index, stream) -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
+        self._sel_ws = {}            # (device index, stream) -> scratch of the threshold selection (histograms, state)
+        # (keyed by stream as well: the dicts are shared by every with_comm() copy, and two samplers on one device -- in-process
+        # ranks, concurrent clips -- run on different streams and must not share histograms / hand-off flags)
 
     def sk_workspace(self, like: Tensor) -> Tensor:
         """Scratch of the persistent stream-K 3x3 kernel (dawn_conv_desc.sk_ws): one per device, flag header zeroed once.
-        All 3x3 convs of an evaluation run on ONE stream (unet_forward), so one buffer serves them all."""
-        key = like.device.index
+        All 3x3 convs of an evaluation run on ONE stream (unet_forward), so one buffer per (device, stream) serves them all."""
+        key = (like.device.index, self._stream())
         ws = self._sk_ws.get(key)
         if ws is None:
             ws = torch.empty(int(self.L.dawn_conv_sk_workspace_bytes()), device=like.device, dtype=torch.uint8)
@@ -434,7 +436,7 @@ class HipOps:
     def init_conv_x(self, x: Tensor, w3: Tensor, fea_pre: Tensor, F: int, h: int, w: int, Co: int,
                     frames: Optional[Tuple[int, int]] = None, out: Optional[Tensor] = None) -> Tensor:
         """frames = (fa, fb): only that frame range of the (3, F, h, w) latent -> ((fb - fa)*h*w, Co) rows (T-shard: edge frames first)."""
-        assert x.is_contiguous() and x.shape == (3, F, h, w)
+        assert x.is_contiguous() and x.shape == (3, F, h, w) and x.dtype == torch.float32     # (the frame offset below is in fp32 elements)
         self._require(x, w3, fea_pre, out)
         fa, fb = frames if frames is not None else (0, F)
         if out is None:
@@ -480,11 +482,12 @@ class HipOps:
         n = x.numel()
         assert x.is_contiguous() and eps.is_contiguous()
         x0 = torch.empty_like(x)
-        # selection scratch [hist1 2048 | hist2 1024 | hist3 1024 | state 4 | hmin 4]: ONE buffer per device, reset by two
+        # selection scratch [hist1 2048 | hist2 1024 | hist3 1024 | state 4 | hmin 4]: ONE buffer per (device, stream), reset by two
         # stream-ordered fills per step (no allocation, no torch fill kernels inside the DDIM loop)
-        ws = self._sel_ws.get(x.device.index)
+        key = (x.device.index, self._stream())
+        ws = self._sel_ws.get(key)
         if ws is None:
-            ws = self._sel_ws[x.device.index] = torch.empty(2048 + 1024 + 1024 + 8, device=x.device, dtype=torch.int32)
+            ws = self._sel_ws[key] = torch.empty(2048 + 1024 + 1024 + 8, device=x.device, dtype=torch.int32)
         check(self.L.dawn_select_ws_reset(_p(ws), self._stream()), "dawn_select_ws_reset")
         hist = ws[:2048]
         check(self.L.dawn_ddim_x0(_p(x), _p(eps), recip, recipm1, n, _p(x0), _p(hist), self._stream()), "dawn_ddim_x0")
@@ -512,7 +515,7 @@ class HipOps:
         lo, weight = self.quantile_rank(n_total, q)
         s = self._stream()
         n = x0.numel()
-        ws = self._sel_ws.get(x0.device.index)
+        ws = self._sel_ws.get((x0.device.index, s))
         if ws is None or hist1.data_ptr() != ws.data_ptr():          # histogram from elsewhere (tests): private scratch
             ws = torch.empty(2048 + 1024 + 1024 + 8, device=x0.device, dtype=torch.int32)
             check(self.L.dawn_select_ws_reset(_p(ws), s), "dawn_select_ws_reset")

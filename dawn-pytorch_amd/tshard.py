@@ -51,11 +51,12 @@ class TShardComm:
         self._bufs = {}
         self._win = 0                 # attention window of the exchanges (set by halo_begin / set_window)
         self.n_halo = self.n_allreduce = 0
+        self.n_halo_edge_first = 0    # exchanges posted by the PRODUCER of the layer input (unet_forward._edge_first), own rows in place
         self.halo_bytes_sent = self.halo_bytes_recv = self.allreduce_bytes = 0
 
     def stats(self) -> dict:
         """Counters since construction (bench.py reports them per rank: RCCL participation is checkable from the JSON)."""
-        return {"rank": self.rank, "world": self.world, "halo_exchanges": self.n_halo,
+        return {"rank": self.rank, "world": self.world, "halo_exchanges": self.n_halo, "halo_exchanges_edge_first": self.n_halo_edge_first,
                 "halo_bytes_sent": self.halo_bytes_sent, "halo_bytes_received": self.halo_bytes_recv,
                 "all_reduces": self.n_allreduce, "all_reduce_bytes": self.allreduce_bytes}
 
@@ -104,7 +105,8 @@ class TShardComm:
         communicator (the three 64-channel level-0 layers share one); callers consume it before the next exchange (stream
         order).  `release_buffers()` drops the cache between clips."""
         F = x.shape[0] // HW
-        assert F == self.F, (F, self.F)
+        if F != self.F or x.shape[0] != F * HW:
+            raise ValueError(f"halo_begin: {x.shape[0]} rows of {HW} pixels are not this rank's {self.F} frames")
         C = x.shape[1]
         lo_g, hi_g = max(0, self.f0 - win), min(self.Ttotal, self.f0 + F + win)     # global frame range of the buffer
         hl, hh = self.f0 - lo_g, hi_g - (self.f0 + F)
@@ -118,8 +120,12 @@ class TShardComm:
         """Post the sends / receives for an extended buffer whose own frames are in place: xe = [hl | F | hh] frames of
         frame_floats floats (any 2-D / 1-D contiguous float view).  Returns the outstanding requests (halo_end waits for them).
         Also the body of the C evaluator's halo_begin callback (ctx.ShardCallbacks.from_tshard), after set_window(win)."""
-        assert F == self.F, (F, self.F)
-        assert self._win >= max(hl, hh), "halo_post: set_window(win) first"
+        if F != self.F:
+            raise ValueError(f"halo_post: {F} own frames, but this rank holds {self.F}")
+        if self._win < max(hl, hh):
+            raise ValueError("halo_post: set_window(win) first (the window tells what the neighbours need from this rank)")
+        if xe.numel() != (hl + F + hh) * frame_floats:
+            raise ValueError(f"halo_post: buffer of {xe.numel()} floats is not [{hl} | {F} | {hh}] frames of {frame_floats}")
         xe = xe.reshape(hl + F + hh, frame_floats)
         lo_g, hi_g = self.f0 - hl, self.f0 + F + hh
         d = self.dist

@@ -286,6 +286,7 @@ def _edge_first(ops, cs: ClipState, F: int, H: int, W: int, C: int, like: Tensor
     produce(0, win, own[:win * HW])
     produce(F - win, F, own[(F - win) * HW:])
     hx = comm.halo_begin(own, HW, win)
+    comm.n_halo_edge_first = getattr(comm, "n_halo_edge_first", 0) + 1
     produce(win, F - win, own[win * HW:(F - win) * HW])
     return own, hx
 

@@ -5,13 +5,12 @@ what a non-Python host would drive a rank with.  The three exchanges are host ca
   * world 2 on ONE GPU: two evaluators in two host threads, the callbacks hand frames / sums to each other through a barrier
     (no RCCL, no gloo) -- the concatenated result equals the unsharded clip (evaluation and a DDIM trajectory with the
     counter-based noise, whose streams are keyed by the global element index)."""
-import threading
-
 import pytest
 import torch
 
 from conftest import load_golden
 from test_hip_end2end import tiny_unet, T, log
+from inproc_shard import Exchange as _Exchange, run_ranks as _run_ranks
 import dawn_pytorch_amd as D
 from dawn_pytorch_amd.ctx import CtxEvaluator, ShardCallbacks
 from dawn_pytorch_amd.sampler import ddim_step_scalars
@@ -49,72 +48,6 @@ def test_ctx_sharded_world1_bit_identical_to_python_sharded_path(tiny):
     broken.c.allreduce_sum_f64 = type(broken.c.allreduce_sum_f64)()
     with pytest.raises(DawnHipError):
         ev.forward(clip, x3, t, shard=broken)
-
-
-class _Exchange:
-    """What RCCL would do, between two host threads on one GPU."""
-
-    def __init__(self, world):
-        self.world = world
-        self.barrier = threading.Barrier(world)
-        self.slots = [None] * world
-
-    def callbacks(self, rank):
-        ex, world = self, self.world
-
-        def sync():
-            torch.cuda.current_stream().synchronize()
-
-        def halo_begin(xe, hl, F, hh, frame_floats):
-            sync()                                             # this rank's own frames are complete
-            v = xe.view(hl + F + hh, frame_floats)
-            ex.slots[rank] = (v, hl, F)
-            ex.barrier.wait(timeout=60)
-            if hl:
-                src, shl, sF = ex.slots[rank - 1]
-                v[:hl].copy_(src[shl + sF - hl:shl + sF])
-            if hh:
-                src, shl, sF = ex.slots[rank + 1]
-                v[hl + F:].copy_(src[shl:shl + hh])
-            sync()
-            ex.barrier.wait(timeout=60)                                  # nobody moves on (and reuses its buffer) before the copies are done
-
-        def reduce(op):
-            def f(t):
-                sync()
-                ex.slots[rank] = t.clone()
-                ex.barrier.wait(timeout=60)
-                tot = ex.slots[0].clone()
-                for r in range(1, world):
-                    tot = op(tot, ex.slots[r])
-                ex.barrier.wait(timeout=60)
-                t.copy_(tot)
-                sync()
-            return f
-
-        return ShardCallbacks(rank, world, halo_begin, lambda: None, reduce(torch.add), reduce(torch.add), reduce(torch.minimum))
-
-
-def _run_ranks(world, fn):
-    out, err = [None] * world, [None] * world
-
-    def body(r):
-        try:
-            with torch.cuda.stream(torch.cuda.Stream()):
-                out[r] = fn(r)
-                torch.cuda.current_stream().synchronize()
-        except BaseException as e:                              # noqa: BLE001
-            err[r] = e
-    th = [threading.Thread(target=body, args=(r,), daemon=True) for r in range(world)]
-    for t_ in th:
-        t_.start()
-    for t_ in th:
-        t_.join(timeout=120)
-    for e in err:
-        if e is not None:
-            raise e
-    assert all(o is not None for o in out), "a rank thread did not finish"
-    return out
 
 
 @pytest.mark.parametrize("world", [2, 3])

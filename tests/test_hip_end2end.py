@@ -311,16 +311,16 @@ def test_video_generator_pipeline_on_gpu(tmp_path):
 
 def test_tshard_rank_paths_agree_at_benchmark_length():
     """One interior T-shard rank's workload (tshard.SimulatedInteriorShard: 200 own frames + 2 x 40 halo frames, full DAWN
-    architecture, small latent): the edge-first schedule (producer writes the edge frames, posts the exchange, computes the interior;
-    the fused temporal layers then run as two balanced 100-query launches on the 280-row buffer) == the interior-first schedule
-    (exchange posted by the temporal layer, 120 interior queries first, two 40-query edge launches): same arithmetic per query, so the
-    two evaluations agree to fp32 rounding; and both == the unsharded evaluation of the 280-frame clip [halo | own | halo] on the
-    own frames whose window stays inside that clip... which needs the same GroupNorm statistics, so that comparison is made with
-    the statistics pass disabled: it is covered by tests/test_tshard_cpu.py (gloo, world 2-4) instead."""
+    architecture, 32 x 32 latent -- large enough for unet_forward._edge_first to take its early-post branch on the level-0 layers;
+    at 8 x 8 both settings ran the same interior-first code): the edge-first schedule (producer writes the edge frames into
+    comm.own_view, posts the exchange, computes the interior; the fused temporal layers then run as two balanced 100-query launches on
+    the 280-row buffer) == the interior-first schedule (exchange posted by the temporal layer, 120 interior queries first, two 40-query
+    edge launches): same arithmetic per query, so the two evaluations agree to fp32 rounding.  (Sharded == UNSHARDED is the business of
+    tests/test_hip_shard_fullsize.py -- 8 in-process ranks at configs[3]'s full size -- and of tests/test_tshard_cpu.py over gloo.)"""
     from fullsize_cases import KW, build_inputs
     from dawn_pytorch_amd.tshard import SimulatedInteriorShard
     from dawn_pytorch_amd.unet_forward import unet_forward
-    Tn, h = 200, 8
+    Tn, h = 200, 32
     unet = D.DynamicNfUnet3D(default_num_frames=Tn, **KW, init_seed=0).cuda()
     ops, P = unet._ops(), unet.packed()
     fea272, cond, x3 = build_inputs(Tn, h)
@@ -332,6 +332,8 @@ def test_tshard_rank_paths_agree_at_benchmark_length():
         cs = unet.build_clip(fea272, cond, comm=comm, Ttotal=comm.Ttotal, f0=comm.f0)
         outs[edge_first] = unet_forward(ops.with_comm(comm), P, cs, x3, 500)
         assert comm.n_halo == 10
+        # init layer + the level-0 down / up layers (64 channels at 32 x 32) post early; the 16 x 16 level-1 up layer does not
+        assert comm.n_halo_edge_first == (3 if edge_first else 0), comm.n_halo_edge_first
     torch.cuda.synchronize()
     assert torch.isfinite(outs[True]).all()
     err = log("tshard_rank_edge_first_vs_interior_first", outs[True], outs[False])

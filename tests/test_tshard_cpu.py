@@ -19,7 +19,7 @@ TINY_KW = dict(dim=16, cond_dim=32, cond_aud=24, cond_pose=6, cond_eye=2, num_fr
 TT, S = 24, 3
 
 
-def _build(T, win=3, dim=16):
+def _build(T, win=3, dim=16, h=8):
     sys.path.insert(0, ROOT)
     import dawn_pytorch_amd as D
     from oracle.ops_ref import RefOps
@@ -30,7 +30,7 @@ def _build(T, win=3, dim=16):
         unet.load_state_dict(sd)            # the reference-golden weights; dim 64: deterministic random init (the fused
                                             # 64-channel temporal / spatial layers and their sharded, segmented form)
     unet.ops = RefOps()
-    diff = D.DynamicNfGaussianDiffusion(default_num_frames=T, denoise_fn=unet, num_frames=T, image_size=8,
+    diff = D.DynamicNfGaussianDiffusion(default_num_frames=T, denoise_fn=unet, num_frames=T, image_size=h,
                                         sampling_timesteps=S, use_dynamic_thres=True, ddim_sampling_eta=1.0)
     diff.update_num_frames(T)
     unet.update_num_frames(T)
@@ -38,9 +38,9 @@ def _build(T, win=3, dim=16):
     return diff
 
 
-def _inputs():
+def _inputs(h=8):
     g = torch.Generator().manual_seed(9)
-    return (torch.randn(1, 12, 8, 8, generator=g), torch.randn(1, 4, 8, 8, generator=g),
+    return (torch.randn(1, 12, h, h, generator=g), torch.randn(1, 4, h, h, generator=g),
             torch.randn(1, TT, 32, generator=g))
 
 
@@ -52,7 +52,7 @@ def _lean(on):
         UF.LONG_CLIP_FRAMES, UF.TEMPORAL_SEG_FRAMES, UF.FRAME_CHUNK = 4, 5, 7
 
 
-def _worker(rank, world, port, out_path, win=3, dim=16, lean=False):
+def _worker(rank, world, port, out_path, win=3, dim=16, lean=False, h=8):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -60,8 +60,8 @@ def _worker(rank, world, port, out_path, win=3, dim=16, lean=False):
     _lean(lean)
     from dawn_pytorch_amd.tshard import TShardComm
     F = TT // world
-    diff = _build(F, win, dim)
-    fea, bbox, cond = _inputs()
+    diff = _build(F, win, dim, h)
+    fea, bbox, cond = _inputs(h)
     comm = TShardComm(dist, rank, world, TT, rank * F, F)
     out = diff.sample(fea, bbox, cond=cond[:, rank * F:(rank + 1) * F].contiguous(), cond_scale=1.0, comm=comm,
                       trace=True)
@@ -71,21 +71,23 @@ def _worker(rank, world, port, out_path, win=3, dim=16, lean=False):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,win,dim,lean", [(2, 3, 16, False), (3, 3, 16, False), (3, 8, 16, False), (4, 6, 16, False), (4, 9, 16, False),
-                                                (2, 3, 64, False), (3, 8, 64, False), (2, 3, 16, True)],
+@pytest.mark.parametrize("world,win,dim,lean,h", [(2, 3, 16, False, 8), (3, 3, 16, False, 8), (3, 8, 16, False, 8), (4, 6, 16, False, 8),
+                                                  (4, 9, 16, False, 8), (2, 3, 64, False, 8), (3, 8, 64, False, 8), (2, 3, 16, True, 8),
+                                                  (3, 3, 64, False, 32)],
                          ids=["w2", "w3-two-neighbours", "w3-F==win", "w4-F==win", "w4-F<win-multi-hop",
-                              "w2-dim64-fused-interior-first", "w3-dim64-F==win", "w2-long-clip-lean-form"])
-def test_tshard_equals_unsharded(tmp_path, world, win, dim, lean):
+                              "w2-dim64-fused-interior-first", "w3-dim64-F==win", "w2-long-clip-lean-form",
+                              "w3-dim64-32x32-edge-first"])
+def test_tshard_equals_unsharded(tmp_path, world, win, dim, lean, h):
     """24 frames over `world` ranks (F = 12 / 8 / 6 frames per rank): window 3 (one neighbour per side), F == win (the halo
     is the neighbour's whole shard) and F < win (the halo spans two ranks on each side)."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     out_path = str(tmp_path / "shard")
-    mp.spawn(_worker, args=(world, port, out_path, win, dim, lean), nprocs=world, join=True)
+    mp.spawn(_worker, args=(world, port, out_path, win, dim, lean, h), nprocs=world, join=True)
     parts = [torch.load(f"{out_path}.{r}") for r in range(world)]
-    diff = _build(TT, win, dim)
-    fea, bbox, cond = _inputs()
+    diff = _build(TT, win, dim, h)
+    fea, bbox, cond = _inputs(h)
     full = diff.sample(fea, bbox, cond=cond, cond_scale=1.0, trace=True)
     qs = torch.stack([tr["s"][1] for tr in diff.last_trace[0]])
     got = torch.cat([p["out"] for p in parts], dim=2)
@@ -103,3 +105,7 @@ def test_tshard_equals_unsharded(tmp_path, world, win, dim, lean):
     inner = st[1]                                      # a rank with neighbours on both sides
     assert inner["halo_bytes_received"] == inner["halo_bytes_sent"] or world == 2 or win > F
     assert all(s_["all_reduces"] > 0 for s_ in st)
+    # the multi-GPU default schedule: on 64-channel levels of >= 32 x 32 pixels the PRODUCER of a temporal layer's input
+    # writes the edge frames into the extended buffer, posts the exchange and computes the interior behind it (unet_forward._edge_first:
+    # init conv, spatial attention of the down / up level 0 = 3 of the 6 layers); elsewhere the temporal layer posts it
+    assert all(s_["halo_exchanges_edge_first"] == (3 * S if (dim == 64 and h * h >= 1024 and TT // world > 2 * win) else 0) for s_ in st)

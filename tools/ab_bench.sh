@@ -16,7 +16,7 @@ mkdir -p gpurun_out
 for round in 1 2; do
     for side in old new; do
         dir=$([ $side = old ] && echo ab_old || echo .)
-        v=$(cd $dir && timeout 600 python bench.py --no-cpu-baseline --no-max-clip --no-decode --no-kernel-events "$@" 2>/dev/null | tail -1 |
+        v=$(cd $dir && timeout 600 python bench.py --no-cpu-baseline --no-max-clip --no-decode --no-kernel-events $(grep -q -- --no-other-configs bench.py && echo --no-other-configs) "$@" 2>/dev/null | tail -1 |
             python -c "import sys, json; d = json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])")
         echo "round $round $side: $v" | tee -a gpurun_out/ab_bench.txt
     done

@@ -5,7 +5,7 @@
 TAG=${1:-r2}
 R=/root/repo; O=$R/gpurun_out; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-B="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-decode --no-max-clip --no-kernel-events --no-shard-sim"
+B="python $R/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-decode --no-max-clip --no-kernel-events --no-shard-sim --no-other-configs"
 timeout 400 rocprofv3 --kernel-trace --stats -d $O/${TAG}_prof -o t -- $B > $O/${TAG}_prof.log 2>&1
 DB=$(find $O/${TAG}_prof -name "*.db" | head -1)
 python $R/tools/rocpd_summary.py $DB > $O/${TAG}_kernel_trace_summary.md 2>&1
