@@ -40,6 +40,7 @@ class ConvDesc(C.Structure):
         ("policy", _i),
         ("ln_eps", _f),
         ("sk_ws", c_f), ("sk_ws_bytes", C.c_size_t),
+        ("w_wino", c_f),
     ]
 
 

@@ -37,14 +37,16 @@ namespace {
 // the chip is power-limited in these kernels (profiles/r3_conv_power_by_data.txt, r3_mfma_power_ubench.txt), so cycles saved by
 // the schedule come back as a lower clock for everything that follows.
 // 0x1000000 (shipped): conv3x3_bf16_v2_kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction).
+// 0x2000000: the Winograd F(2x2,3x3) form of the split 3x3 conv (conv3x3_wino.hip) where the caller supplies dawn_conv_desc.w_wino and
+// the geometry fits (image width <= 64, even sides): 2.25x fewer matrix-pipe flops.
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
 // split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
 constexpr int DAWN_CONV_POLICY_DEFAULT = 0x100580D;
 #ifdef DAWN_ABLATION
-constexpr int DAWN_CONV_POLICY_MASK = 0x010FFFFF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x030FFFFF;
 #else
-constexpr int DAWN_CONV_POLICY_MASK = 0x01F3FFCF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x03F3FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
@@ -2492,6 +2494,7 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 }  // namespace
 
 int dawn_conv3x3_sk_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows);   // conv3x3_sk.hip
+int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows); // conv3x3_wino.hip
 
 #ifdef DAWN_ABLATION
 extern "C" int dawn_conv_set_debug(void* p) {
@@ -2554,6 +2557,14 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         d.Ho == d.Hi && d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool nine = (policy_of(d) & 0x2000) != 0;
         bool ok = false;
+        if ((policy_of(d) & 0x2000000) && !nine && d.w_wino) {   // Winograd F(2x2,3x3) form (conv3x3_wino.hip)
+            int rows = 0;
+            if (dawn_conv3x3_wino_try(d, M, policy_of(d), s, &rows)) {
+                if (d.gn_rows) *d.gn_rows = rows;
+                DAWN_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         if ((policy_of(d) & 0x400) && !nine && d.sk_ws) {   // persistent stream-K kernel (conv3x3_sk.hip)
             int rows = 0;
             if (dawn_conv3x3_sk_try(d, M, policy_of(d), s, &rows)) {

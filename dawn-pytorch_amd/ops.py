@@ -128,7 +128,8 @@ class HipOps:
                   row_stats: Optional[Tuple[Tensor, Tensor]] = None, ch_ab: Optional[Tuple[Tensor, Tensor]] = None,
                   pro_act: int = 0, pro_add: Optional[Tensor] = None, res: Optional[Tensor] = None,
                   tr: Optional[Tuple[Tensor, Tensor, Tensor]] = None, out: Optional[Tensor] = None,
-                  gn_part: Optional[Tensor] = None, w_bf3: Optional[Tensor] = None, ln_eps: float = 0.0) -> Tensor:
+                  gn_part: Optional[Tensor] = None, w_bf3: Optional[Tensor] = None, ln_eps: float = 0.0,
+                  w_wino: Optional[Tensor] = None) -> Tensor:
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
         rows_out = F * Ho * Wo
@@ -154,6 +155,7 @@ class HipOps:
         d.out, d.ld_out = _p(out), _ld(out)
         d.gn_part = _p(gn_part)
         d.w_bf3 = _p(w_bf3)
+        d.w_wino = _p(w_wino)
         d.policy = self.conv_policy
         d.ln_eps = ln_eps
         if self.stream_k and (self.conv_policy & 0x400) and w_bf3 is not None and KH == 3 and KW == 3 and stride == 1 and mode == 0:

@@ -39,6 +39,38 @@ def pack_bf3(w_kn: Tensor) -> Tensor:
     return planes.reshape(3, K // 16, 2, 8, N).permute(1, 0, 2, 4, 3).contiguous()
 
 
+def pack_wino_bf3(w5: Tensor) -> Tensor:
+    """Conv3d weight (Co, Ci, 1, 3, 3) -> the Winograd F(2x2, 3x3) image the split-operand kernel conv3x3_wino_kernel consumes:
+    U = G g G^T per (co, ci) in fp64 (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], Lavin & Gray), split into three bf16 planes
+    u = u1 + u2 + u3 (round-to-nearest at every level, residuals exact in fp64: ~26 significant bits), laid out as MFMA A-operand
+    fragments of v_mfma_f32_16x16x32_bf16 in lane order:
+        [Ci/16 chunks][16 positions p = 4 xi + nu][Co/16 blocks][2: W1 = [u1|u2], W2 = [u3|u1]][64 lanes][8] int16,
+    lane = 16 kg + l15 -> output channel 16 cb + l15, input channels 16 chunk + 8 (kg & 1) + 0..7 of plane (kg < 2 ? first : second)."""
+    Co, Ci = w5.shape[0], w5.shape[1]
+    assert w5.shape[2:] == (1, 3, 3) and Ci % 16 == 0 and Co % 16 == 0, tuple(w5.shape)
+    g = w5[:, :, 0].double()                                                        # (Co, Ci, 3, 3)
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    U = torch.einsum("xk,oikl,nl->oixn", G, g, G)                                   # (Co, Ci, xi, nu)
+    u1 = U.float().to(torch.bfloat16)
+    r1 = U - u1.double()
+    u2 = r1.float().to(torch.bfloat16)
+    r2 = r1 - u2.double()
+    u3 = r2.float().to(torch.bfloat16)
+    planes = torch.stack((u1, u2, u3), 0).view(torch.int16)                         # (3, Co, Ci, 4, 4)
+    # -> (3, chunk, kh, e, cb, l15, pos)
+    pl = planes.reshape(3, Co // 16, 16, Ci // 16, 2, 8, 16).permute(0, 3, 4, 5, 1, 2, 6)
+    sel = ((0, 1), (2, 0))                                                          # planes of the two k-halves of W1 / W2
+    frags = []
+    for f in range(2):
+        halves = [pl[sel[f][hh]] for hh in range(2)]                                # each (chunk, kh, e, cb, l15, pos)
+        fr = torch.stack(halves, 0)                                                 # (hh, chunk, kh, e, cb, l15, pos)
+        frags.append(fr)
+    fr = torch.stack(frags, 0)                                                      # (f, hh, chunk, kh, e, cb, l15, pos)
+    # target [chunk][pos][cb][f][kg = 2 hh + kh][l15][e]
+    out = fr.permute(2, 7, 5, 0, 1, 3, 6, 4).contiguous()
+    return out.reshape(Ci // 16, 16, Co // 16, 2, 64, 8)
+
+
 def pack_bf3_temporal_out(w_kn: Tensor) -> Tensor:
     """to_out of the temporal attention, (256, C) with k = head*32 + d, as the 3-way bf16 split image the all-bf16-pipe
     fused layer (temporal_layer.hip, WMODE 3) consumes: within every head the rows are permuted to the accumulator order

@@ -66,6 +66,11 @@ typedef struct dawn_conv_desc {
                                                       3x3 convs with w_bf3 and policy bit 0x400 (not in the shipped default) then run on the persistent stream-K kernel, which hands
                                                       partial tiles between workgroups through it.  One workspace per concurrently running launch;
                                                       NULL = the one-tile-per-workgroup kernels */
+    const void* w_wino;                            /* optional (3x3/s1/p1 convs): the Winograd F(2x2,3x3) image of the weights, U = G g G^T computed in
+                                                      fp64 and split into three bf16 planes, in the fragment order of conv3x3_wino_kernel:
+                                                      [(C0+C1)/16][16 positions][N/16][2][64 lanes][8] (pack.pack_wino_bf3).  With policy bit
+                                                      0x2000000 such convs run in the Winograd form (2.25x fewer matrix-pipe flops, fp32 results to
+                                                      fp32-Winograd accuracy); NULL or other shapes = the direct split kernel */
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;

@@ -195,6 +195,105 @@ def test_conv3x3_stream_k(hip, ref, case):
     finally:
         hip.conv_policy = 0
 
+# ---------------------------------------------------------------------------------------------- Winograd F(2x2,3x3) split conv
+WINO = 0x580D | 0x1000000 | 0x2000000              # shipped policy + the Winograd form where w_wino is supplied
+WINO_CASES = [
+    # name, F, H, W, C0, C1, N, extras
+    ("L0_64x64_4rows", 3, 64, 64, 64, 0, 64, {"bias": True, "gn": True}),                  # tile = 4 rows: 2 x 32 Winograd tiles
+    ("L0_cat_64p64_N64", 2, 64, 64, 64, 64, 64, {"bias": True, "gn": True}),               # two sources (skip concat), 8 chunks
+    ("L0_one_chunk", 1, 64, 64, 16, 0, 64, {"bias": True}),                                # a single 16-channel chunk
+    ("L1_32x32_N128", 5, 32, 32, 64, 0, 128, {"bias": True, "gn": True}),                  # 8 rows: 4 x 16 tiles, two channel tiles
+    ("L1_32x32_res", 3, 32, 32, 32, 0, 64, {"res": True}),
+    ("L2_16x16_N256_gn", 7, 16, 16, 128, 0, 256, {"bias": True, "gn": True}),              # one frame per workgroup: 8 x 8 tiles
+    ("L2_16x16_cat_N128", 4, 16, 16, 128, 128, 128, {"bias": True, "gn": True}),
+    ("L3_8x8_four_frames", 12, 8, 8, 256, 0, 512, {"bias": True, "gn": True}),             # 4 whole frames per workgroup
+    ("L3_8x8_cat_deepK", 8, 8, 8, 512, 512, 256, {"bias": True, "gn": True}),
+    ("clip_edges_1frame", 1, 64, 64, 32, 0, 64, {"bias": True}),
+    ("H_not_square_32x64", 2, 32, 64, 32, 0, 64, {"bias": True, "gn": True}),
+]
+
+
+def _w5_from_packed(w, Cin, N):
+    """packed [K/4][N][4] (k = tap*Cin + c) -> Conv3d layout (N, Cin, 1, 3, 3)."""
+    from dawn_pytorch_amd.pack import unpack_kn
+    return unpack_kn(w).reshape(3, 3, Cin, N).permute(3, 2, 0, 1)[:, :, None].contiguous()
+
+
+@pytest.mark.parametrize("case", WINO_CASES, ids=[c[0] for c in WINO_CASES])
+def test_conv3x3_winograd(hip, ref, case):
+    """conv3x3_wino_kernel (Winograd F(2x2,3x3) on the bf16 pipe with exactly split operands) == the torch conv, == the direct
+    split kernel to fp32 rounding, bit-deterministic; GroupNorm sums from its epilogue == a statistics pass over its output."""
+    from dawn_pytorch_amd.pack import pack_bf3, pack_wino_bf3, unpack_kn
+    name, F, H, W, C0, C1, N, ex = case
+    rows = F * H * W
+    in0 = rnd(rows, C0, seed=1)
+    in1 = rnd(rows, C1, seed=2) if C1 else None
+    w = packw(9 * (C0 + C1), N, seed=3)
+    kw = dict(F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1)
+    if ex.get("bias"):
+        kw["bias"] = rnd(N, seed=4)
+    if ex.get("res"):
+        kw["res"] = rnd(rows, N, seed=8)
+    want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
+    gkw = {k_: (v.cuda() if torch.is_tensor(v) else v) for k_, v in kw.items()}
+    gkw["w_bf3"] = pack_bf3(unpack_kn(w)).cuda()
+    gkw["w_wino"] = pack_wino_bf3(_w5_from_packed(w, C0 + C1, N)).cuda()
+    x0g, x1g, wg = in0.cuda(), None if in1 is None else in1.cuda(), w.cuda()
+    try:
+        outs = []
+        for variant in (WINO, 0x580D | 0x1000000):
+            hip.conv_policy = variant
+            part = hip.conv_gn_part(rows, N, x0g) if ex.get("gn") else None
+            got = hip.conv_gemm(x0g, wg, N, in1=x1g, gn_part=part, **gkw)
+            torch.cuda.synchronize()
+            check(f"conv3x3_wino/{name}/v{variant:#x}", got, want)
+            outs.append(got)
+            if part is not None:
+                gamma, beta = rnd(N, seed=14).cuda() * 0.2 + 1, rnd(N, seed=15).cuda() * 0.2
+                a1, b1 = hip.gn_coeffs(got, gamma, beta, None, rows, part=part)
+                a2, b2 = hip.gn_coeffs(got, gamma, beta, None, rows)
+                check(f"conv3x3_wino/{name}/gn_a/v{variant:#x}", a1, a2, 1e-5)
+                check(f"conv3x3_wino/{name}/gn_b/v{variant:#x}", b1, b2, 1e-5)
+        hip.conv_policy = WINO
+        again = hip.conv_gemm(x0g, wg, N, in1=x1g, **gkw)
+        assert torch.equal(again, outs[0])                                    # fixed summation order
+        scale = max(1.0, float(want.abs().max()))
+        assert float((outs[0] - outs[1]).abs().max()) <= 2e-5 * scale         # vs the direct split kernel: fp32 rounding only
+        assert not torch.equal(outs[0], outs[1])                              # (the Winograd kernel really ran: different rounding)
+    finally:
+        hip.conv_policy = 0
+
+
+def test_conv_wino_is_fp32_accurate(hip, ref):
+    """Against an fp64 convolution the Winograd split kernel's error is that of an fp32 Winograd F(2x2,3x3): within 3x the direct
+    split kernel's on N(0,1) data with entries spread over 10 decades (the transform adds values of different magnitude in fp32,
+    which the direct form never does -- that, not the bf16 pipe, is what the factor pays for)."""
+    import torch.nn.functional as F_
+    from dawn_pytorch_amd.pack import pack_bf3, pack_wino_bf3, unpack_kn
+    F, H, W, Cc, N = 4, 32, 32, 128, 128
+    rows = F * H * W
+    errs = {}
+    for tag, spread in (("n01", False), ("spread", True)):
+        x, w = rnd(rows, Cc, seed=1), packw(9 * Cc, N, seed=2)
+        if spread:
+            x[::7, ::5] *= 1.0e4
+            x[::11, ::3] *= 1.0e-6
+        wkn = unpack_kn(w).double()
+        w4 = wkn.reshape(3, 3, Cc, N).permute(3, 2, 0, 1)
+        want = F_.conv2d(x.double().reshape(F, H, W, Cc).permute(0, 3, 1, 2), w4, padding=1).permute(0, 2, 3, 1).reshape(rows, N)
+        ws, ww = pack_bf3(unpack_kn(w)).cuda(), pack_wino_bf3(_w5_from_packed(w, Cc, N)).cuda()
+        for variant in (2061, 0x580D | 0x1000000, WINO):
+            hip.conv_policy = variant
+            got = hip.conv_gemm(x.cuda(), w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, w_bf3=ws, w_wino=ww)
+            torch.cuda.synchronize()
+            errs[(tag, variant)] = float((got.cpu().double() - want).abs().max() / want.abs().max())
+    hip.conv_policy = 0
+    with open(LOG, "a") as f:
+        f.write(json.dumps({"op": "conv_wino/rel_err_vs_fp64", **{f"{t}/{v:#x}": e for (t, v), e in errs.items()}}) + "\n")
+    for tag in ("n01", "spread"):
+        assert errs[(tag, WINO)] <= 3.0 * errs[(tag, 0x580D | 0x1000000)] + 1e-7, errs
+
+
 
 @pytest.mark.parametrize("F,H,W,C0,N", [(3, 16, 16, 64, 64), (2, 8, 8, 128, 256), (5, 8, 8, 16, 16), (1, 40, 37, 32, 128),
                                        (12, 8, 8, 16, 32), (12, 4, 4, 64, 32), (12, 8, 8, 48, 16)])

@@ -1,0 +1,62 @@
+"""GPU box: the Winograd split 3x3 conv against the direct split kernel at the benchmark's shapes (HIP events, alternating).
+    python tools/bench_wino.py [--iters 20]"""
+import argparse
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from dawn_pytorch_amd.ops import HipOps                                      # noqa: E402
+from dawn_pytorch_amd.pack import pack_bf3, pack_kn, pack_wino_bf3, conv_w_kn  # noqa: E402
+
+SHAPES = [  # F, H, W, C0, C1, N      (BASELINE configs[2]: T = 200, 64 x 64 latent)
+    (200, 64, 64, 64, 0, 64), (200, 64, 64, 64, 64, 64),
+    (200, 32, 32, 64, 0, 128), (200, 32, 32, 128, 0, 128), (200, 32, 32, 128, 128, 64), (200, 32, 32, 64, 0, 64),
+    (200, 16, 16, 128, 0, 256), (200, 16, 16, 256, 0, 256), (200, 16, 16, 256, 256, 128), (200, 16, 16, 128, 0, 128),
+    (200, 8, 8, 256, 0, 512), (200, 8, 8, 512, 0, 512), (200, 8, 8, 512, 512, 256), (200, 8, 8, 256, 0, 256),
+]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--data", default="randn")
+    a = ap.parse_args()
+    ops = HipOps()
+    dev = torch.device("cuda")
+    DIRECT, WINO = 0x580D | 0x1000000, 0x580D | 0x1000000 | 0x2000000
+    for F, H, W, C0, C1, N in SHAPES:
+        Cin = C0 + C1
+        g = torch.Generator().manual_seed(1)
+        w5 = torch.randn(N, Cin, 1, 3, 3, generator=g) * (9 * Cin) ** -0.5
+        wkn = conv_w_kn(w5)
+        w, ws, ww = pack_kn(wkn).to(dev), pack_bf3(wkn).to(dev), pack_wino_bf3(w5).to(dev)
+        rows = F * H * W
+        mk = (lambda *s: torch.randn(*s, device=dev)) if a.data == "randn" else (lambda *s: torch.zeros(*s, device=dev))
+        x0 = mk(rows, C0)
+        x1 = mk(rows, C1) if C1 else None
+        bias = torch.randn(N, device=dev)
+        out = torch.empty(rows, N, device=dev)
+        res = {}
+        for rnd_ in range(2):
+            for name, pol in (("direct", DIRECT), ("wino", WINO)):
+                ops.conv_policy = pol
+                part = ops.conv_gn_part(rows, N, x0)
+                for _ in range(3):
+                    ops.conv_gemm(x0, w, N, in1=x1, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=bias, gn_part=part, w_bf3=ws, w_wino=ww, out=out)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.iters):
+                    ops.conv_gemm(x0, w, N, in1=x1, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=bias, gn_part=part, w_bf3=ws, w_wino=ww, out=out)
+                e1.record()
+                torch.cuda.synchronize()
+                res.setdefault(name, []).append(e0.elapsed_time(e1) / a.iters * 1e3)
+        d, wn = min(res["direct"]), min(res["wino"])
+        fl = 2.0 * rows * N * 9 * Cin
+        print(f"M={rows} N={N} K={9 * Cin} ({H}x{W})   direct {d:8.1f} us ({fl / d / 1e6:6.1f} alg TF/s)   winograd {wn:8.1f} us ({fl / wn / 1e6:6.1f} alg TF/s)   "
+              f"{(wn / d - 1) * 100:+.1f} %", flush=True)
+
+
+if __name__ == "__main__":
+    main()
