@@ -12,10 +12,17 @@
 //   * output:  A^T M A (coefficients +-1) in fp32.
 // Error vs an fp64 convolution: that of an fp32 Winograd F(2x2,3x3) (tests/test_hip_ops.py::test_conv_wino_is_fp32_accurate).
 //
-// Workgroup = 256 output pixels (64 Winograd tiles: TR rows x W columns of one frame, or nf whole small frames) x 64 output
-// channels, 8 waves.  Per 16-channel chunk:
-//   raw patch  (TR+2) x (W+2) x 16 fp32, global -> LDS by LDS-DMA (zero padding = out-of-range buffer offsets), channel-quad
-//              planes [cq][pixel][16 B], double-buffered;
+// Tile = 256 output pixels (64 Winograd tiles: TR rows x W columns of one frame, or nf whole small frames) x 64 output
+// channels, 8 waves, ONE workgroup per CU (148 KB of LDS, 2 x 256 registers per SIMD).  The grid is PERSISTENT: a workgroup walks a
+// contiguous range of tiles and the (tile, chunk) loop is flat -- the next tile's first patch, first transform and first weight
+// fragments ride in the last chunk of the current one, so a tile has no prologue and its stores drain behind the next tile's MFMAs
+// (measured on the one-tile-per-workgroup form: 12 us of launch + first-fetch + drain per tile against 3.4 us per chunk).
+// Per 16-channel chunk:
+//   raw patch  (TR+2) x (W+2) x 16 fp32, global -> LDS by LDS-DMA (zero padding = out-of-range buffer offsets; the hardware writes the
+//              zeros), pixel-major [pixel][64 B]: the four lanes of a pixel fetch its four channel quads = one 64-byte sector (a
+//              channel-quad-major layout costs 4x the texture-address cycles: 16 B from 64 different rows per instruction -- measured
+//              -23 % on the whole kernel); the quads of a pixel are XOR-swizzled by its patch column (source side: LDS-DMA writes
+//              lane-linearly) so that the transform's reads -- tiles two pixels apart -- stay at 2-way bank conflicts; double-buffered;
 //   transform  thread = (tile, channel quad, column position nu): 8 ds_read_b128, 32 adds, 4 quad splits, 12 ds_write_b64 into
 //              D~ = [nu_l][xi][plane][k-half][tile][16 B] -- each transformed element is produced ONCE per workgroup;
 //   MFMA       wave = (row position xi, 32-channel half): positions (xi, nu) for its 64 tiles x 32 channels; pixel fragments from D~
@@ -25,9 +32,11 @@
 // group A of chunk c they transform group B of chunk c, then multiply B while transforming A of chunk c+1 -- VALU work rides in
 // the matrix pipe's shadow, one barrier per 48 MFMAs per wave.
 // Epilogue: the nu half of A^T M A in registers (4 accumulators -> 2), the xi half across the four row-position waves through
-// LDS (8 values per (tile, channel) instead of 16), then bias (+ residual), 16-byte row-segment stores and GroupNorm(8) partials.
+// LDS (8 values per (tile, channel) instead of 16; one 32-channel half at a time in the D~ region + raw buffer the next tile does not
+// need yet), then bias (+ residual), 16-byte row-segment stores and GroupNorm(8) partials (one gn_part row per tile).
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
+#include <cstdlib>
 
 namespace {
 
@@ -35,7 +44,8 @@ typedef dawn_bf16x8 bf16x8;
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int DTG = 8 * 6 * 1024;            // bytes of one D~ region: [nu_l 2][xi 4][plane 3][k-half 2][tile 64][16 B]
-constexpr int EXROW = 64 * 4 + 16;           // exchange row of the epilogue: 64 channels fp32 + 16 B (bank rotation)
+constexpr int EXROW = 32 * 4 + 16;           // exchange row of the epilogue: 32 channels fp32 + 16 B (bank rotation)
+constexpr int EXHALF = 8 * 64 * EXROW;       // one 32-channel half of the exchange: [xi 4][zb 2][tile 64][EXROW]
 constexpr unsigned OOB = 0x80000000u;
 
 // exact truncation split of 4 fp32 values into three bf16 quads (dawn_split3_oct's scheme, see dawn_common.h)
@@ -59,24 +69,24 @@ __device__ __forceinline__ void split3q(const f32x4 v, uint2& p1, uint2& p2, uin
 
 struct wino_thread {
     // transform role
-    int rbase;          // byte offset of this thread's (tile, channel quad) in a raw buffer: cq * RPS + patch pixel (i = 0, j = 0) * 16
     int rowb;           // bytes per patch row
-    int colA[2], colB[2];   // per position group: byte offsets of the two columns combined into this thread's nu
-    float sgn[2];       // ... and the sign of the second one
+    int colA[2], colB[2];   // per position group: byte offsets, in a raw buffer ([pixel][64 B]), of patch row 0 of the two columns combined into this thread's nu
+    float sgn0;         // ... and the sign of the second one in group 0 (nu = 0: d0 - d2, nu = 1: d1 + d2; group 1 always subtracts)
     int wbase;          // byte offset of this thread's slot in a D~ region: position (nu_l, xi = 0), plane 0
     // MFMA role
     int xo1, xo2;       // byte offsets of this lane's X1 = [v1 | v2] / X2 = [v3 | v1] fragments in a D~ region (nu_l = 0, tile block 0)
 };
 
 // ---- transform of one position group (G = 0: nu in {0,1}, G = 1: nu in {2,3}) of one 16-channel chunk: raw patch -> D~ region
+// (prologue only: in the main loop the transform is interleaved with the MFMAs, wino_phase)
 template <int G>
 __device__ __forceinline__ void wino_transform(const wino_thread& t, const unsigned char* raw, unsigned char* dt) {
     f32x4 v[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        const f32x4 a = *reinterpret_cast<const f32x4*>(raw + t.rbase + i * t.rowb + t.colA[G]);
-        const f32x4 b = *reinterpret_cast<const f32x4*>(raw + t.rbase + i * t.rowb + t.colB[G]);
-        v[i] = a + t.sgn[G] * b;
+        const f32x4 a = *reinterpret_cast<const f32x4*>(raw + i * t.rowb + t.colA[G]);
+        const f32x4 b = *reinterpret_cast<const f32x4*>(raw + i * t.rowb + t.colB[G]);
+        v[i] = G ? a - b : a + t.sgn0 * b;
     }
     const f32x4 D[4] = {v[0] - v[2], v[1] + v[2], v[2] - v[1], v[1] - v[3]};       // B^T rows: xi = 0..3
 #pragma unroll
@@ -90,107 +100,172 @@ __device__ __forceinline__ void wino_transform(const wino_thread& t, const unsig
     }
 }
 
-// ---- the MFMAs of one position group for this wave: positions (xi, 2G + nl), 4 tile blocks x 2 channel blocks
-template <int G>
-__device__ __forceinline__ void wino_mma(const wino_thread& t, const unsigned char* dt, const bf16x8 (&w)[2][2][2],
-                                         f32x4 (&acc)[4][4][2]) {
+// ---- one phase of the main loop: the MFMAs of position group G for this wave (positions (xi, 2G + nl), 4 tile blocks x 2 channel
+// blocks, fragments read from `dtr`) with the transform of the OTHER group (raw patch `raw` -> region `dtw`) cut into slices
+// between them: raw reads up front, the column / row combinations behind the first two tile blocks, one row position's split +
+// stores behind each of the next four.  The three LDS regions are distinct (restrict: the scheduler may move the stores across the
+// fragment reads).
+template <int G, int ABL, typename MidLoad>
+__device__ __forceinline__ void wino_phase(const wino_thread& t, const unsigned char* __restrict__ dtr, unsigned char* __restrict__ dtw,
+                                           const unsigned char* __restrict__ raw, bf16x8 (&w0)[2][2], const bf16x8 (&w1)[2][2],
+                                           f32x4 (&acc)[4][4][2], MidLoad mid_load) {
+    constexpr int GT = G ^ 1;
+    f32x4 ra[2], rb[2], v[4], D[4];                    // (patch rows two at a time: 16 registers in flight instead of 32)
+    auto load_rows = [&](int i0) {
 #pragma unroll
-    for (int nl = 0; nl < 2; ++nl) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(dt + t.xo1 + nl * 4 * 6 * 1024 + b * 256);
-            const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(dt + t.xo2 + nl * 4 * 6 * 1024 + b * 256);
-#pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                f32x4 a = acc[2 * G + nl][b][cb];
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nl][cb][0], x2, a, 0, 0, 0);     // [u1|u2].[v3|v1] = u1 v3 + u2 v1
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nl][cb][1], x1, a, 0, 0, 0);     // [u3|u1].[v1|v2] = u3 v1 + u1 v2
-                a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[nl][cb][0], x1, a, 0, 0, 0);     // [u1|u2].[v1|v2] = u1 v1 + u2 v2
-                acc[2 * G + nl][b][cb] = a;
-            }
+        for (int i = 0; i < 2; ++i) {
+            if (ABL & 2) { ra[i] = f32x4{0.f, 0.f, 0.f, 0.f}; rb[i] = ra[i]; continue; }
+            ra[i] = *reinterpret_cast<const f32x4*>(raw + (i0 + i) * t.rowb + t.colA[GT]);
+            rb[i] = *reinterpret_cast<const f32x4*>(raw + (i0 + i) * t.rowb + t.colB[GT]);
         }
+    };
+    load_rows(0);
+    bf16x8 x1 = *reinterpret_cast<const bf16x8*>(dtr + t.xo1);
+    bf16x8 x2 = *reinterpret_cast<const bf16x8*>(dtr + t.xo2);
+#pragma unroll
+    for (int blk = 0; blk < 8; ++blk) {
+        const int nl = blk >> 2, b = blk & 3;
+        bf16x8 nx1 = x1, nx2 = x2;
+        if (blk < 7) {
+            const int nb = blk + 1;
+            nx1 = *reinterpret_cast<const bf16x8*>(dtr + t.xo1 + (nb >> 2) * 4 * 6 * 1024 + (nb & 3) * 256);
+            nx2 = *reinterpret_cast<const bf16x8*>(dtr + t.xo2 + (nb >> 2) * 4 * 6 * 1024 + (nb & 3) * 256);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb) {
+            f32x4 a = acc[2 * G + nl][b][cb];
+            const bf16x8 wa = nl ? w1[cb][0] : w0[cb][0], wb = nl ? w1[cb][1] : w0[cb][1];
+            if (ABL & 4) { a = a + __builtin_bit_cast(f32x4, wa) + __builtin_bit_cast(f32x4, x2) + __builtin_bit_cast(f32x4, wb) + __builtin_bit_cast(f32x4, x1); acc[2 * G + nl][b][cb] = a; continue; }
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, x2, a, 0, 0, 0);     // [u1|u2].[v3|v1] = u1 v3 + u2 v1
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wb, x1, a, 0, 0, 0);     // [u3|u1].[v1|v2] = u3 v1 + u1 v2
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, x1, a, 0, 0, 0);     // [u1|u2].[v1|v2] = u1 v1 + u2 v2
+            acc[2 * G + nl][b][cb] = a;
+        }
+        if (blk == 3) mid_load();           // the first position's weights are dead: their registers take the next phase's first position
+        if (ABL & 2) {
+        } else if (blk == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) v[i] = GT ? ra[i] - rb[i] : ra[i] + t.sgn0 * rb[i];
+            load_rows(2);
+        } else if (blk == 1) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) v[2 + i] = GT ? ra[i] - rb[i] : ra[i] + t.sgn0 * rb[i];
+            D[0] = v[0] - v[2]; D[1] = v[1] + v[2]; D[2] = v[2] - v[1]; D[3] = v[1] - v[3];       // B^T rows: xi = 0..3
+        } else if (blk < 6) {
+            const int xi = blk - 2;
+            uint2 p1, p2, p3;
+            split3q(D[xi], p1, p2, p3);
+            unsigned char* dst = dtw + t.wbase + xi * 6 * 1024;
+            *reinterpret_cast<uint2*>(dst) = p1;
+            *reinterpret_cast<uint2*>(dst + 2048) = p2;
+            *reinterpret_cast<uint2*>(dst + 4096) = p3;
+        }
+        x1 = nx1; x2 = nx2;
     }
 }
 
-__global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_desc d, const int xcd_remap, const int TR, const int nf,
-                                                              const int PI) {
+template <int ABL>
+__global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_desc d, const int ntiles, const int TR, const int nf,
+                                                              const int PI, const int rawb, const int stagger) {
 #if __HIP_DEVICE_COMPILE__
+    if (stagger > 0) {
+        // de-phase the workgroups: identical work in lockstep makes every CU hit HBM at the same instant (patch fetch of a new tile,
+        // output stores of a finished one) and then wait out the burst together
+        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
+        const unsigned long long dt = (unsigned long long)(((blockIdx.x * 157u) & 255u) * (unsigned)stagger) >> 8;
+        while (__builtin_amdgcn_s_memtime() - t0 < dt) __builtin_amdgcn_s_sleep(32);
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    const int RPS = PI * 1024 + 16;                    // bytes of one channel-quad plane of a raw buffer (+16: odd quads 4 banks on)
-    const int RAWB = 4 * RPS;
-    unsigned char* dtbuf = smem_b;                     // [2 groups][DTG]
-    unsigned char* rawbuf = smem_b + 2 * DTG;          // [2][4 cq][RPS]
+    const int RAWB = rawb;                             // bytes of one raw buffer: >= PI KB ([pixel][64 B], PI 16-pixel DMA segments)
+    // [D~ A | raw 0 | D~ B | raw 1 | wsum]: the epilogue's exchange lives in D~ B + raw 1 (both idle then: the number of chunks is
+    // even, so a tile's last chunk sits in raw 1 and the next tile's first one goes to raw 0)
+    unsigned char* dtA = smem_b;
+    unsigned char* raw0 = smem_b + DTG;
+    unsigned char* dtB = smem_b + DTG + RAWB;
+    unsigned char* raw1 = smem_b + 2 * DTG + RAWB;
     float* wsum = reinterpret_cast<float*>(smem_b + 2 * DTG + 2 * RAWB);      // [8 waves][8 subgroups][sum, sumsq]
+    unsigned char* junk = smem_b + 2 * DTG + 2 * RAWB + 512;                   // 1 KB: destination of DMA slots past the end of the patch
+    unsigned char* ex = dtB;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l15 = lane & 15, kg = lane >> 4;
     const int xi_w = wave >> 1, coh = wave & 1;
+    int tix = 0;                                       // s_memtime stamps of the instrumented build (ABL bit 6), written over the output
+#define WSTAMP()                                                                                                        \
+    do {                                                                                                                \
+        if ((ABL & 64) && tid == 0 && tix < 96)                                                                         \
+            reinterpret_cast<unsigned long long*>(d.out)[(size_t)blockIdx.x * 96 + tix++] = __builtin_amdgcn_s_memtime(); \
+    } while (0)
     const int H = d.Hi, W = d.Wi, PW = W + 2, PP = (TR + 2) * PW;
     const int Cin = d.C0 + d.C1;
     const int nC = Cin >> 4;
     const int nNt = d.N >> 6;
-    int bid = blockIdx.x;
-    if (xcd_remap) {
-        const int nwg = gridDim.x;
-        const int xcd = bid & 7, idx = bid >> 3;
-        const int q = nwg >> 3, r = nwg & 7;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
-    const int mt = bid / nNt, nt = bid - mt * nNt;
-    const int n0 = nt * 64;
-    const int grow0 = mt * (256 / W);                  // first image row of the tile, counted over all frames
-    const int f0 = grow0 / H;
-    const int y0 = grow0 - f0 * H;
+    const int nCB = d.N >> 4;
     const int TX = W >> 1, TPF = TX * (TR >> 1);       // Winograd tiles per row / per frame part
+    const int t_begin = (int)((long)blockIdx.x * ntiles / gridDim.x), t_end = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
+    if (t_begin >= t_end) return;
 
-    // ---- buffer descriptors: the patch window of each source (first pixel = row y0-1 of frame f0), the packed weights
-    const long pb = ((long)f0 * H + y0 - 1) * W;
-    const int ext = nf * H * W + (nf > 1 ? 2 * W : (TR + 2) * W - H * W);      // pixels spanned by the window
-    const __amdgpu_buffer_rsrc_t rs0 =
-        __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + pb * d.ld0), 0, ext * d.ld0 * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs1 = __builtin_amdgcn_make_buffer_rsrc(
-        (void*)((d.in1 ? d.in1 : d.in0) + pb * (d.in1 ? d.ld1 : d.ld0)), 0, ext * (d.in1 ? d.ld1 : d.ld0) * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsw =
-        __builtin_amdgcn_make_buffer_rsrc((void*)d.w_wino, 0, nC * 16 * (d.N >> 4) * 2 * 1024, 0x00020000);
-
-    // ---- raw-patch DMA slots of this wave: slot s = wave + 8 i -> (channel quad, 64-pixel segment); lane = pixel
-    int relpix[4];
-    int rdst[4];
+    // ---- raw-patch DMA slots of this wave: slot s = wave + 8 i -> (channel quad, 64-pixel segment); lane = pixel.  The patch geometry
+    // is the same for every tile; which of its rows fall outside the image depends on the tile's first row y0
+    // slot s = wave + 8 i -> 16-pixel segment; lane = (pixel l >> 2, LDS quad slot l & 3), fetching source quad (l & 3) ^ swizzle(column).
+    // One register per slot: [31] invalid | [30:24] patch row | [23:22] source quad | [21:0] pixel offset in the window (pyy * W + x)
+    // (kept in LDS, 4 B per thread and slot: read back when a piece is issued -- the main loop has no register to spare)
+    unsigned* dtab = reinterpret_cast<unsigned*>(smem_b + 2 * DTG + 2 * RAWB + 512 + 1024);       // [4 slots][512 threads]
+    int ddst[4];                                       // (wave-uniform) LDS byte offset of the slot in a raw buffer; past-the-patch slots -> junk
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int s = wave + 8 * i;
-        const int cq = s / PI, seg = s - cq * PI;
-        const int pos = seg * 64 + lane;
-        int r = -1;
-        if (s < 4 * PI && pos < nf * PP) {
+        const int pos = s * 16 + (lane >> 2);
+        unsigned v = 0x80000000u;
+        if (s < PI && pos < nf * PP) {
             const int fi = pos / PP;
             const int rem = pos - fi * PP;
             const int pyy = rem / PW, pxx = rem - pyy * PW;
-            const int y = y0 + pyy - 1, x = pxx - 1;
-            if (y >= 0 && y < H && x >= 0 && x < W) r = fi * H * W + pyy * W + x;
+            const int x = pxx - 1;
+            if (x >= 0 && x < W)
+                v = ((unsigned)pyy << 24) | ((unsigned)((lane & 3) ^ ((pxx >> 2) & 3)) << 22) | (unsigned)(fi * H * W + pyy * W + x);
         }
-        relpix[i] = r;
-        rdst[i] = s < 4 * PI ? cq * RPS + seg * 1024 : -1;
+        dtab[i * 512 + tid] = v;
+        ddst[i] = s < PI ? s * 1024 : -1;
     }
-    auto issue_raw = [&](int cc, int buf) {
+    const int ext = nf * H * W + (nf > 1 ? 2 * W : (TR + 2) * W - H * W);      // pixels spanned by a tile's patch window
+    const __amdgpu_buffer_rsrc_t rsw =
+        __builtin_amdgcn_make_buffer_rsrc((void*)d.w_wino, 0, nC * 16 * nCB * 2 * 1024, 0x00020000);
+
+    struct tile_t { int f0, y0, n0, valid; };          // scalars only: descriptors and lane offsets are rebuilt at issue time
+    auto setup = [&](int tile, bool valid, tile_t& T) {
+        const int mt = tile / nNt, nt = tile - mt * nNt;
+        const int grow0 = mt * (256 / W);              // first image row of the tile, counted over all frames
+        T.n0 = nt * 64;
+        T.f0 = grow0 / H;
+        T.y0 = grow0 - T.f0 * H;
+        T.valid = valid ? 1 : 0;
+    };
+    // A patch fetch is issued in pieces right behind the weight fetches of a phase (see the main loop): an HBM-missing patch streams at
+    // ~11 B/clk per CU, and a wave that issues its whole share at once sits at the issue port for that long (measured: +1.6..8 k cycles
+    // on the phase) -- the MFMAs behind it wait.  `fetch_t` = what a piece needs, prepared outside the phases
+    struct fetch_t { __amdgpu_buffer_rsrc_t rs; int ldb, soff, y0; };
+    auto fetch_of = [&](const tile_t& T, int cc, fetch_t& Fd) {
         const int cbase = cc * 16;
         const bool src1 = cbase >= d.C0;
-        const int ldb = (src1 ? d.ld1 : d.ld0) * 4;
-        const int soff = (src1 ? cbase - d.C0 : cbase) * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int s = wave + 8 * i;
-            if (s < 4 * PI) {
-                const int cq = s / PI;
-                const unsigned voff = relpix[i] < 0 ? OOB : (unsigned)(relpix[i] * ldb + cq * 16);
-                __attribute__((address_space(3))) void* dst =
-                    (__attribute__((address_space(3))) void*)(rawbuf + (size_t)buf * RAWB + rdst[i]);
-                if (src1) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs1, dst, 16, voff, soff, 0, 0);
-                else __builtin_amdgcn_raw_ptr_buffer_load_lds(rs0, dst, 16, voff, soff, 0, 0);
-            }
-        }
+        const float* src = src1 ? d.in1 : d.in0;
+        const int ld = src1 ? d.ld1 : d.ld0;
+        const long pb = ((long)T.f0 * H + T.y0 - 1) * W;          // first pixel of the window = row y0 - 1 of frame f0
+        Fd.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + pb * ld), 0, T.valid ? ext * ld * 4 : 0, 0x00020000);
+        Fd.ldb = ld * 4;
+        Fd.soff = (src1 ? cbase - d.C0 : cbase) * 4;
+        Fd.y0 = T.y0;
+    };
+    auto issue_slot = [&](const fetch_t& Fd, unsigned char* rawdst, int i) {      // (branch-free: it sits inside a scheduling region)
+        const unsigned v = dtab[i * 512 + tid];
+        const unsigned row = (unsigned)Fd.y0 + ((v >> 24) & 127u) - 1u;           // image row of the lane's pixel (wraps below 0)
+        const unsigned bad = (v >> 31) | (unsigned)(row >= (unsigned)H);
+        const unsigned off = (v & 0x3fffffu) * (unsigned)Fd.ldb + ((v >> 22) & 3u) * 16u;
+        const unsigned voff = bad ? OOB : off;
+        unsigned char* dp = ddst[i] >= 0 ? rawdst + ddst[i] : junk;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(Fd.rs, (__attribute__((address_space(3))) void*)dp, 16, voff, Fd.soff, 0, 0);
     };
 
     // ---- this thread's transform unit: tile tt, channel quad cq = 2 kh + h8, column position nu_l of the group
@@ -200,30 +275,30 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
         const int fi = tt / TPF;
         const int rem = tt - fi * TPF;
         const int ty2 = rem / TX, tx2 = rem - ty2 * TX;
-        t.rbase = (2 * kh + h8) * RPS + (fi * PP + 2 * ty2 * PW + 2 * tx2) * 16;
-        t.rowb = PW * 16;
-        // B columns: nu 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3
-        t.colA[0] = nul ? 16 : 0;   t.colB[0] = 32;             t.sgn[0] = nul ? 1.f : -1.f;       // group 0: nu = 0 / 1
-        t.colA[1] = nul ? 16 : 32;  t.colB[1] = nul ? 48 : 16;  t.sgn[1] = -1.f;                   // group 1: nu = 2 / 3
+        const int cq = 2 * kh + h8, px0 = 2 * tx2;
+        const int rbase = (fi * PP + 2 * ty2 * PW + px0) * 64;
+        t.rowb = PW * 64;
+        // B columns: nu 0: d0 - d2, 1: d1 + d2, 2: d2 - d1, 3: d1 - d3; byte offset of column j = j pixels + this quad's swizzled slot
+        auto col = [&](int j) { return rbase + j * 64 + ((cq ^ (((px0 + j) >> 2) & 3)) * 16); };
+        t.colA[0] = nul ? col(1) : col(0);  t.colB[0] = col(2);                  t.sgn0 = nul ? 1.f : -1.f;       // group 0: nu = 0 / 1
+        t.colA[1] = nul ? col(1) : col(2);  t.colB[1] = nul ? col(3) : col(1);                                    // group 1: nu = 2 / 3
         t.wbase = (nul * 4 * 6 + kh) * 1024 + tt * 16 + h8 * 8;
         t.xo1 = (xi_w * 6 + kg) * 1024 + l15 * 16;
         t.xo2 = (xi_w * 6 + (kg < 2 ? kg + 4 : kg - 2)) * 1024 + l15 * 16;
     }
+    const int eq = tid & 7;                            // epilogue unit: Winograd tile tid >> 3, 4-channel quad eq of the 32-channel half
 
-    // ---- weight fragments: [chunk][position 16][channel block N/16][W1 = [u1|u2], W2 = [u3|u1]][lane][16 B]
-    const int nCB = d.N >> 4;
-    const int cbg0 = (n0 >> 4) + coh * 2;
-    auto load_w = [&](int cc, int g, bf16x8 (&w)[2][2][2]) {
+    // ---- weight fragments: [chunk][position 16][channel block N/16][W1 = [u1|u2], W2 = [u3|u1]][lane][16 B]; an out-of-range chunk
+    // (past the last tile) reads zeros
+    auto load_w = [&](int n0, int cc, int g, int nl, bf16x8 (&w)[2][2]) {      // the fragments of position (xi_w, 2 g + nl) of chunk cc
 #pragma unroll
-        for (int nl = 0; nl < 2; ++nl)
+        for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-                for (int f = 0; f < 2; ++f) {
-                    const int fidx = (((cc * 16 + xi_w * 4 + 2 * g + nl) * nCB + cbg0 + cb) * 2 + f);
-                    const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsw, lane * 16, fidx * 1024, 0);
-                    w[nl][cb][f] = __builtin_bit_cast(bf16x8, v);
-                }
+            for (int f = 0; f < 2; ++f) {
+                const int fidx = (((cc * 16 + xi_w * 4 + 2 * g + nl) * nCB + (n0 >> 4) + coh * 2 + cb) * 2 + f);
+                const i32x4 v = __builtin_amdgcn_raw_buffer_load_b128(rsw, lane * 16, fidx * 1024, 0);
+                w[cb][f] = __builtin_bit_cast(bf16x8, v);
+            }
     };
 
     f32x4 acc[4][4][2];
@@ -234,99 +309,151 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
 #pragma unroll
             for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // zero both raw buffers once: padding positions are the same in every chunk, and an out-of-range DMA lane must find zeros there
-    // whether or not the hardware writes its (zero) result
-    for (int o = tid * 16; o < 2 * RAWB; o += 512 * 16) *reinterpret_cast<uint4*>(rawbuf + o) = make_uint4(0u, 0u, 0u, 0u);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    bf16x8 wA[2][2][2], wB[2][2][2];
-    issue_raw(0, 0);
-    load_w(0, 0, wA);
+    // weight fragments: one position = 4 fragments (16 registers), TWO positions live: w0 serves tile blocks 0..3 of a phase, w1 blocks
+    // 4..7; the next phase's w0 is fetched into w0's registers once it is dead (after block 3), the next phase's w1 at the top of that
+    // phase -- half a phase of latency budget each, in flight across the barrier (counted vmcnt waits: only the patch DMA, older than
+    // both, has to have landed there)
+    bf16x8 w0[2][2], w1[2][2];
+    tile_t cur, nxt;
+    setup(t_begin, true, cur);
+    setup(t_begin + 1 < t_end ? t_begin + 1 : t_begin, t_begin + 1 < t_end, nxt);
+    fetch_t fn, ff;                                    // the patch of the next unit / of the unit after it
+    fetch_of(cur, 0, fn);
+    fetch_of(cur, 1, ff);                              // (nC >= 2)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) issue_slot(fn, raw0, i);
+    issue_slot(ff, raw1, 0);
+    issue_slot(ff, raw1, 1);
+    load_w(cur.n0, 0, 0, 0, w0);
+    load_w(cur.n0, 0, 0, 1, w1);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    wino_transform<0>(t, rawbuf, dtbuf);
+    wino_transform<0>(t, raw0, dtA);
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    for (int cc = 0; cc < nC; ++cc) {
-        const bool more = cc + 1 < nC;
-        const unsigned char* rawc = rawbuf + (size_t)(cc & 1) * RAWB;
-        const unsigned char* rawn = rawbuf + (size_t)((cc + 1) & 1) * RAWB;
-        // phase A: multiply group A of this chunk; transform group B of this chunk; fetch the next chunk's patch, group B's weights
-        if (more) issue_raw(cc + 1, (cc + 1) & 1);
-        load_w(cc, 1, wB);
-        wino_mma<0>(t, dtbuf, wA, acc);
-        wino_transform<1>(t, rawc, dtbuf + DTG);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        // phase B: multiply group B; transform group A of the next chunk; fetch its weights
-        if (more) load_w(cc + 1, 0, wA);
-        wino_mma<1>(t, dtbuf + DTG, wB, acc);
-        if (more) wino_transform<0>(t, rawn, dtbuf);
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-    }
+    // Patch fetch of unit u (= chunk, flat across tiles) -- needed from phase B(u-1) on, its buffer free from phase B(u-2) on -- in
+    // three pieces: slot 0 at the top of phase B(u-2), slot 1 in its middle, slots 2..3 at the top of phase A(u-1), each right behind
+    // a weight fetch: VMEM returns in order, so a patch piece has to land before the next YOUNGER weight fetch is waited for, which
+    // is one phase later at these positions
+    for (int tile = t_begin; tile < t_end; ++tile) {
+        WSTAMP();   // tile start
+        const bool has_next = tile + 1 < t_end;
+        for (int cc = 0; cc < nC; ++cc) {
+            const bool last = cc == nC - 1;
+            unsigned char* rawc = (cc & 1) ? raw1 : raw0;
+            unsigned char* rawn = (cc & 1) ? raw0 : raw1;
+            // phase A: multiply group A of this chunk; transform group B of this chunk; the rest of the next unit's patch
+            fn = ff;
+            issue_slot(fn, rawn, 2);
+            issue_slot(fn, rawn, 3);
+            __builtin_amdgcn_sched_barrier(0);
+            wino_phase<0, ABL>(t, dtA, dtB, rawc, w0, w1, acc, [&]() { load_w(cur.n0, cc, 1, 0, w0); });
+            if (cc + 2 >= nC) fetch_of(nxt, cc + 2 - nC, ff);                // (descriptor of the unit after next -- it may belong to the
+            else fetch_of(cur, cc + 2, ff);                                  //  next tile --, prepared in the shadow of the barrier)
+            WSTAMP();   // phase A issued
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");      // the next unit's patch has landed; w0 (the 4 youngest loads) may still fly
+            WSTAMP();   // ... its loads landed
+            __builtin_amdgcn_s_barrier();
+            WSTAMP();   // ... barrier passed
+            load_w(cur.n0, cc, 1, 1, w1);
+            // phase B: multiply group B; transform group A of the next unit; fetch its weights and the first pieces of the patch of the
+            // unit after it (past the last tile: zeros nobody reads)
+            const int ncc = last ? (has_next ? 0 : nC) : cc + 1;
+            const int nn0 = last ? nxt.n0 : cur.n0;
+            issue_slot(ff, rawc, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            wino_phase<1, ABL>(t, dtB, dtA, rawn, w0, w1, acc, [&]() { load_w(nn0, ncc, 0, 0, w0); issue_slot(ff, rawc, 1); });
+            WSTAMP();   // phase B issued
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (no VMEM wait: patch pieces and w0 stay in flight)
+            __builtin_amdgcn_s_barrier();
+            WSTAMP();   // ... barrier passed
+            load_w(nn0, ncc, 0, 1, w1);
+        }
 
-    // ---- epilogue.  Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  nu half in registers: Z[zb] over this wave's 4 column positions
-    unsigned char* ex = smem_b;                        // [xi 4][zb 2][tile 64][EXROW]
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-            const f32x4 z0 = (acc[0][b][cb] + acc[1][b][cb]) + acc[2][b][cb];
-            const f32x4 z1 = (acc[1][b][cb] - acc[2][b][cb]) - acc[3][b][cb];
-            unsigned char* dst = ex + (size_t)((xi_w * 2) * 64 + b * 16 + l15) * EXROW + (coh * 32 + cb * 16 + 4 * kg) * 4;
-            *reinterpret_cast<f32x4*>(dst) = z0;
-            *reinterpret_cast<f32x4*>(dst + 64 * EXROW) = z1;
+        // ---- epilogue of the tile.  Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  nu half in registers: Z[zb] over this wave's 4 column
+        // positions; xi half through LDS, one 32-channel half (the waves with coh == h) at a time
+        float sv[2], sq[2];
+        int epix, eoff;                                // pixel (a = 0, zb = 0) relative to the tile's first row; byte offset in an exchange plane
+        {
+            const int et = tid >> 3;
+            const int efi = et / TPF, erem = et - efi * TPF;
+            const int ety2 = erem / TX, etx2 = erem - ety2 * TX;
+            epix = (efi * H + 2 * ety2) * W + 2 * etx2;
+            eoff = et * EXROW + eq * 16;
         }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    // xi half + stores: thread = (tile, 4-channel quad), two units per thread (same quad)
-    const int q = tid & 15;
-    const int n = n0 + 4 * q;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
-    float sv = 0.f, sq = 0.f;
+        const bool never = d.F < 0;                    // (ablation builds: work kept alive behind a condition that is never true)
+        if ((ABL & 1) && never) {
+            f32x4 sa = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-        const int tt = (tid >> 4) + 32 * k;
-        const int fi = tt / TPF;
-        const int rem = tt - fi * TPF;
-        const int ty2 = rem / TX, tx2 = rem - ty2 * TX;
-        f32x4 z[4][2];
+            for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi)
+                for (int j = 0; j < 4; ++j)
 #pragma unroll
-            for (int zb = 0; zb < 2; ++zb)
-                z[xi][zb] = *reinterpret_cast<const f32x4*>(ex + (size_t)((xi * 2 + zb) * 64 + tt) * EXROW + q * 16);
+                    for (int k = 0; k < 2; ++k) sa = sa + acc[i][j][k];
+            *reinterpret_cast<f32x4*>(d.out + tid * 4) = sa;
+        }
 #pragma unroll
-        for (int zb = 0; zb < 2; ++zb) {
-            const f32x4 ya[2] = {(z[0][zb] + z[1][zb]) + z[2][zb], (z[1][zb] - z[2][zb]) - z[3][zb]};
+        for (int h = 0; h < ((ABL & 1) ? 0 : 2); ++h) {
+            if (coh == h) {
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
-                const long m = ((long)(f0 + fi) * H + y0 + 2 * ty2 + a) * W + 2 * tx2 + zb;
-                f32x4 o = ya[a] + bv;
-                if (d.res) o = o + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
-                *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n) = o;
-                sv += (o.x + o.y) + (o.z + o.w);
-                sq += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                for (int b = 0; b < 4; ++b)
+#pragma unroll
+                    for (int cb = 0; cb < 2; ++cb) {
+                        const f32x4 z0 = (acc[0][b][cb] + acc[1][b][cb]) + acc[2][b][cb];
+                        const f32x4 z1 = (acc[1][b][cb] - acc[2][b][cb]) - acc[3][b][cb];
+                        unsigned char* dst = ex + (size_t)((xi_w * 2) * 64 + b * 16 + l15) * EXROW + (cb * 16 + 4 * kg) * 4;
+                        *reinterpret_cast<f32x4*>(dst) = z0;
+                        *reinterpret_cast<f32x4*>(dst + 64 * EXROW) = z1;
+                    }
             }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int n = cur.n0 + 32 * h + 4 * eq;
+            f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+            if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
+            float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+            for (int zb = 0; zb < 2; ++zb) {
+                f32x4 z[4];
+#pragma unroll
+                for (int xi = 0; xi < 4; ++xi) z[xi] = *reinterpret_cast<const f32x4*>(ex + (xi * 2 + zb) * 64 * EXROW + eoff);
+                const f32x4 ya[2] = {(z[0] + z[1]) + z[2], (z[1] - z[2]) - z[3]};
+#pragma unroll
+                for (int a = 0; a < 2; ++a) {
+                    const long m = ((long)cur.f0 * H + cur.y0) * W + epix + a * W + zb;
+                    f32x4 o = ya[a] + bv;
+                    if (d.res) o = o + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
+                    if (!(ABL & (16 | 64)) || never) *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n) = o;
+                    s1 += (o.x + o.y) + (o.z + o.w);
+                    s2 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
+                }
+            }
+            sv[h] = s1;
+            sq[h] = s2;
+            if (h == 1 && d.gn_part) {
+                // lanes with the same quad: lane bits 3..5; quads 2j, 2j+1 form an 8-channel subgroup: 4 h + j of the tile's 64 channels
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    float a1 = sv[hh], a2 = sq[hh];
+                    a1 += __shfl_xor(a1, 8, 64);   a2 += __shfl_xor(a2, 8, 64);
+                    a1 += __shfl_xor(a1, 16, 64);  a2 += __shfl_xor(a2, 16, 64);
+                    a1 += __shfl_xor(a1, 32, 64);  a2 += __shfl_xor(a2, 32, 64);
+                    a1 += __shfl_xor(a1, 1, 64);   a2 += __shfl_xor(a2, 1, 64);
+                    if (lane < 8 && !(lane & 1)) {
+                        wsum[wave * 16 + (4 * hh + (lane >> 1)) * 2] = a1;
+                        wsum[wave * 16 + (4 * hh + (lane >> 1)) * 2 + 1] = a2;
+                    }
+                }
+            }
+            WSTAMP();   // epilogue half: stores issued
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();               // the exchange may be overwritten (next half / next tile's phase A)
+            WSTAMP();   // epilogue half done
         }
-    }
-    if (d.gn_part) {
-        // lanes with the same quad: l, l^16, l^32, l^48; quads 2j, 2j+1 form the 8-channel subgroup j of the tile's 64 channels
-        sv += __shfl_xor(sv, 16, 64);  sq += __shfl_xor(sq, 16, 64);
-        sv += __shfl_xor(sv, 32, 64);  sq += __shfl_xor(sq, 32, 64);
-        sv += __shfl_xor(sv, 1, 64);   sq += __shfl_xor(sq, 1, 64);
-        if (lane < 16 && !(lane & 1)) {
-            wsum[wave * 16 + (lane >> 1) * 2] = sv;
-            wsum[wave * 16 + (lane >> 1) * 2 + 1] = sq;
-        }
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (tid < 16) {
+        if (d.gn_part && tid < 16) {
             const int which = tid & 1;
             const int cpg = d.N >> 3;
-            const int lo = (tid >> 1) * cpg - n0, hi = lo + cpg;             // this group's channel range relative to the tile
+            const int lo = (tid >> 1) * cpg - cur.n0, hi = lo + cpg;         // this group's channel range relative to the tile
             double a = 0.0;
 #pragma unroll
             for (int w = 0; w < 8; ++w)
@@ -335,19 +462,40 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
                     const int c = 8 * jg;
                     if (c >= lo && c < hi) a += (double)wsum[w * 16 + jg * 2 + which];
                 }
-            d.gn_part[(long)blockIdx.x * 16 + tid] = a;
+            d.gn_part[(long)tile * 16 + tid] = a;
         }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        cur = nxt;
+        setup(tile + 2 < t_end ? tile + 2 : tile, tile + 2 < t_end, nxt);
     }
 #endif
 }
 
 }  // namespace
 
-// host-side geometry test + launch; false = the shape does not fit (the caller falls back to the direct split kernel)
+static int wino_ncu() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        hipDeviceProp_t p;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&p, dev) == hipSuccess) n = p.multiProcessorCount;
+        if (n <= 0) n = 256;
+    }
+    return n;
+}
+
+// host-side geometry test + launch; 0 = the shape does not fit (the caller falls back to the direct split kernel)
 int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows) {
+    (void)policy;
     const int H = d.Hi, W = d.Wi;
     if (!d.w_wino || d.tr || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.mode != 0) return 0;
     if (W > 64 || (W & 1) || (H & 1) || 256 % W != 0 || M % 256 != 0 || d.C0 % 16 != 0 || d.C1 % 16 != 0 || d.N % 64 != 0) return 0;
+    if ((d.C0 + d.C1) % 32 != 0) return 0;                     // an even number of 16-channel chunks (raw-buffer parity, see the kernel)
     if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) ||
         (long)128 * (d.C0 + d.C1) * d.N >= (1L << 31) || (long)d.F * H >= (1L << 31))
         return 0;
@@ -355,13 +503,37 @@ int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream
     if (TR <= H) { if (H % TR != 0) return 0; }
     else { if (TR % H != 0) return 0; nf = TR / H; TR = H; if (d.F % nf != 0) return 0; }
     const int P = nf * (TR + 2) * (W + 2);
-    const int PI = (P + 63) / 64;
-    const size_t lds = (size_t)2 * DTG + (size_t)2 * 4 * (PI * 1024 + 16) + 512;
-    if (PI > 7 || lds > 160 * 1024 || lds < (size_t)8 * 64 * EXROW) return 0;
-    const int nwg = (int)(M / 256) * (d.N / 64);
-    const int remap = ((policy & 4) && nwg >= 64 && H * W >= 1024) ? 1 : 0;
-    (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(conv3x3_wino_kernel, dim3(nwg), dim3(512), lds, s, d, remap, TR, nf, PI);
-    if (nrows) *nrows = nwg;
+    const int PI = (P + 15) / 16;                              // 16-pixel DMA segments of a patch
+    int RAWB = PI * 1024;
+    if (DTG + RAWB < EXHALF) RAWB = EXHALF - DTG;              // (the epilogue's exchange lives in one D~ region + one raw buffer)
+    const size_t lds = (size_t)2 * DTG + (size_t)2 * RAWB + 512 + 1024 + 8192;
+    if (PI > 32 || lds > 160 * 1024) return 0;
+    const int ntiles = (int)(M / 256) * (d.N / 64);
+    const int grid = ntiles < wino_ncu() ? ntiles : wino_ncu();
+    static const int stagger = getenv("DAWN_WINO_STAGGER") ? atoi(getenv("DAWN_WINO_STAGGER")) : 0;
+#define WINO_LAUNCH(A)                                                                                                      \
+    do {                                                                                                                    \
+        (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+        hipLaunchKernelGGL(conv3x3_wino_kernel<A>, dim3(grid), dim3(512), lds, s, d, ntiles, TR, nf, PI, RAWB, stagger);                  \
+    } while (0)
+#ifdef DAWN_ABLATION
+    static const int abl = getenv("DAWN_WINO_ABL") ? atoi(getenv("DAWN_WINO_ABL")) : 0;     // perf ablations (wrong results by design)
+    if (abl == 1) WINO_LAUNCH(1);
+    else if (abl == 2) WINO_LAUNCH(2);
+    else if (abl == 4) WINO_LAUNCH(4);
+    else if (abl == 6) WINO_LAUNCH(6);
+    else if (abl == 8) WINO_LAUNCH(8);
+    else if (abl == 7) WINO_LAUNCH(7);
+    else if (abl == 16) WINO_LAUNCH(16);
+    else if (abl == 9) WINO_LAUNCH(9);
+    else if (abl == 24) WINO_LAUNCH(24);
+    else if (abl == 64) WINO_LAUNCH(64);
+    else if (abl == 72) WINO_LAUNCH(72);
+    else if (abl == 66) WINO_LAUNCH(66);
+    else
+#endif
+    WINO_LAUNCH(0);
+#undef WINO_LAUNCH
+    if (nrows) *nrows = ntiles;
     return 1;
 }

@@ -144,6 +144,8 @@ class PackedResBlock:
     br: Optional[Tensor] = None
     w1s: Optional[Tensor] = None          # pack_bf3 images of w1 / w2 (split-operand bf16 MFMA path)
     w2s: Optional[Tensor] = None
+    w1w: Optional[Tensor] = None          # pack_wino_bf3 images of w1 / w2 (Winograd F(2x2,3x3) form of the split-operand conv)
+    w2w: Optional[Tensor] = None
     wrs: Optional[Tensor] = None          # ... of the 1x1 res_conv, of to_q and of the three to_out projections
     wqs: Optional[Tensor] = None
     wos: Optional[List[Tensor]] = None
@@ -274,6 +276,10 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
         if Cin % 16 == 0 and Co % 16 == 0:
             rb.w1s = pack_bf3(conv_w_kn(w1)).to(device)
             rb.w2s = pack_bf3(conv_w_kn(g(p + "block2.proj.weight"))).to(device)
+        if Cin % 32 == 0 and Co % 64 == 0:          # (what conv3x3_wino_kernel takes: an even number of 16-channel chunks, 64-column tiles)
+            rb.w1w = pack_wino_bf3(w1).to(device)
+        if Co % 64 == 0:
+            rb.w2w = pack_wino_bf3(g(p + "block2.proj.weight")).to(device)
         if has(p + "res_conv.weight"):
             rb.wr = dev(pack_kn(conv_w_kn(g(p + "res_conv.weight"))))
             rb.br = dev(g(p + "res_conv.bias"))

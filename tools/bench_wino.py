@@ -22,11 +22,16 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--data", default="randn")
+    ap.add_argument("--only", type=int, nargs="*", default=None, help="indices into SHAPES")
+    ap.add_argument("--wino-only", action="store_true")
+    ap.add_argument("--stamps", action="store_true", help="instrumented build (DAWN_WINO_ABL=64): print the s_memtime timeline of a few workgroups")
     a = ap.parse_args()
     ops = HipOps()
     dev = torch.device("cuda")
     DIRECT, WINO = 0x580D | 0x1000000, 0x580D | 0x1000000 | 0x2000000
-    for F, H, W, C0, C1, N in SHAPES:
+    for si, (F, H, W, C0, C1, N) in enumerate(SHAPES):
+        if a.only is not None and si not in a.only:
+            continue
         Cin = C0 + C1
         g = torch.Generator().manual_seed(1)
         w5 = torch.randn(N, Cin, 1, 3, 3, generator=g) * (9 * Cin) ** -0.5
@@ -38,9 +43,27 @@ def main():
         x1 = mk(rows, C1) if C1 else None
         bias = torch.randn(N, device=dev)
         out = torch.empty(rows, N, device=dev)
+        if a.stamps:
+            import numpy as np
+            ops.conv_policy = WINO
+            for _ in range(3):
+                out.zero_()
+                ops.conv_gemm(x0, w, N, in1=x1, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=bias, w_bf3=ws, w_wino=ww, out=out)
+            torch.cuda.synchronize()
+            st = out.reshape(-1).view(torch.int64)[:256 * 96].reshape(256, 96).cpu().numpy()
+            nC = Cin // 16
+            per_tile = 1 + 5 * nC + 4
+            for g in (0, 100, 255):
+                row = st[g]
+                n = int((row != 0).sum())
+                d_ = np.diff(row[:n])
+                print(f"shape {si} wg {g}: {n} stamps; per tile {per_tile}: [tile start | per chunk: A issued, A landed, A barrier, B issued, B barrier | 2 x (stores issued, half done)]")
+                for k in range(0, min(n - 1, 3 * per_tile), per_tile):
+                    print("   ", " ".join(f"{int(v):6d}" for v in d_[k:k + per_tile]))
+            continue
         res = {}
         for rnd_ in range(2):
-            for name, pol in (("direct", DIRECT), ("wino", WINO)):
+            for name, pol in ((("wino", WINO),) if a.wino_only else (("direct", DIRECT), ("wino", WINO))):
                 ops.conv_policy = pol
                 part = ops.conv_gn_part(rows, N, x0)
                 for _ in range(3):
@@ -52,7 +75,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 res.setdefault(name, []).append(e0.elapsed_time(e1) / a.iters * 1e3)
-        d, wn = min(res["direct"]), min(res["wino"])
+        wn = min(res["wino"])
+        d = min(res["direct"]) if "direct" in res else wn
         fl = 2.0 * rows * N * 9 * Cin
         print(f"M={rows} N={N} K={9 * Cin} ({H}x{W})   direct {d:8.1f} us ({fl / d / 1e6:6.1f} alg TF/s)   winograd {wn:8.1f} us ({fl / wn / 1e6:6.1f} alg TF/s)   "
               f"{(wn / d - 1) * 100:+.1f} %", flush=True)
