@@ -48,6 +48,7 @@ class ConvDesc(C.Structure):
 SIGNATURES = {
     "dawn_conv_gemm": [C.POINTER(ConvDesc), c_f],
     "dawn_conv_gemm_nblocks": [_l, _i],
+    "dawn_conv3x3_wino_ok": [_i, _i, _i, _i, _i, _i],
     "dawn_conv_sk_workspace_bytes": [],
     "dawn_conv_sk_workspace_init": [c_f, c_f],
     "dawn_conv_sk_check": [c_f, c_f],

@@ -166,15 +166,8 @@ __device__ __forceinline__ void wino_phase(const wino_thread& t, const unsigned 
 
 template <int ABL>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_desc d, const int ntiles, const int TR, const int nf,
-                                                              const int PI, const int rawb, const int stagger) {
+                                                              const int PI, const int rawb) {
 #if __HIP_DEVICE_COMPILE__
-    if (stagger > 0) {
-        // de-phase the workgroups: identical work in lockstep makes every CU hit HBM at the same instant (patch fetch of a new tile,
-        // output stores of a finished one) and then wait out the burst together
-        const unsigned long long t0 = __builtin_amdgcn_s_memtime();
-        const unsigned long long dt = (unsigned long long)(((blockIdx.x * 157u) & 255u) * (unsigned)stagger) >> 8;
-        while (__builtin_amdgcn_s_memtime() - t0 < dt) __builtin_amdgcn_s_sleep(32);
-    }
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int RAWB = rawb;                             // bytes of one raw buffer: >= PI KB ([pixel][64 B], PI 16-pixel DMA segments)
     // [D~ A | raw 0 | D~ B | raw 1 | wsum]: the epilogue's exchange lives in D~ B + raw 1 (both idle then: the number of chunks is
@@ -489,44 +482,55 @@ static int wino_ncu() {
     return n;
 }
 
-// host-side geometry test + launch; 0 = the shape does not fit (the caller falls back to the direct split kernel)
-int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows) {
-    (void)policy;
-    const int H = d.Hi, W = d.Wi;
-    if (!d.w_wino || d.tr || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.mode != 0) return 0;
-    if (W > 64 || (W & 1) || (H & 1) || 256 % W != 0 || M % 256 != 0 || d.C0 % 16 != 0 || d.C1 % 16 != 0 || d.N % 64 != 0) return 0;
-    if ((d.C0 + d.C1) % 32 != 0) return 0;                     // an even number of 16-channel chunks (raw-buffer parity, see the kernel)
-    if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3)) ||
-        (long)128 * (d.C0 + d.C1) * d.N >= (1L << 31) || (long)d.F * H >= (1L << 31))
-        return 0;
+// geometry of a launch: what the kernel needs besides the descriptor; false = the shape does not fit
+struct wino_geom { int TR, nf, PI, RAWB, ntiles; size_t lds; };
+static bool wino_geometry(int F, int H, int W, int C0, int C1, int N, wino_geom& g) {
+    const long M = (long)F * H * W;
+    if (W > 64 || W < 2 || (W & (W - 1)) || (H & 1) || M % 256 != 0 || C0 % 16 != 0 || C1 % 16 != 0 || N % 64 != 0) return false;
+    if ((C0 + C1) % 32 != 0) return false;                     // an even number of 16-channel chunks (raw-buffer parity, see the kernel)
+    if ((long)128 * (C0 + C1) * N >= (1L << 31) || (long)F * H >= (1L << 31)) return false;
     int TR = 256 / W, nf = 1;
-    if (TR <= H) { if (H % TR != 0) return 0; }
-    else { if (TR % H != 0) return 0; nf = TR / H; TR = H; if (d.F % nf != 0) return 0; }
+    if (TR <= H) { if (H % TR != 0) return false; }
+    else { if (TR % H != 0) return false; nf = TR / H; TR = H; if (F % nf != 0) return false; }
     const int P = nf * (TR + 2) * (W + 2);
     const int PI = (P + 15) / 16;                              // 16-pixel DMA segments of a patch
     int RAWB = PI * 1024;
     if (DTG + RAWB < EXHALF) RAWB = EXHALF - DTG;              // (the epilogue's exchange lives in one D~ region + one raw buffer)
     const size_t lds = (size_t)2 * DTG + (size_t)2 * RAWB + 512 + 1024 + 8192;
-    if (PI > 32 || lds > 160 * 1024) return 0;
-    const int ntiles = (int)(M / 256) * (d.N / 64);
+    if (PI > 32 || lds > 160 * 1024) return false;
+    g.TR = TR; g.nf = nf; g.PI = PI; g.RAWB = RAWB; g.lds = lds;
+    g.ntiles = (int)(M / 256) * (N / 64);
+    return true;
+}
+
+/* 1 when a 3x3 / stride 1 / pad 1 conv of this shape (F frames of H x W pixels, C0 + C1 input channels, N output channels) runs in the
+ * Winograd form once dawn_conv_desc.w_wino is supplied and policy bit 0x2000000 is set (the shipped default has it) */
+extern "C" int dawn_conv3x3_wino_ok(int F, int H, int W, int C0, int C1, int N) {
+    wino_geom g;
+    return wino_geometry(F, H, W, C0, C1, N, g) ? 1 : 0;
+}
+
+// host-side geometry test + launch; 0 = the shape does not fit (the caller falls back to the direct split kernel)
+int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows) {
+    (void)policy; (void)M;
+    if (!d.w_wino || d.tr || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.mode != 0) return 0;
+    if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3))) return 0;
+    wino_geom g;
+    if (!wino_geometry(d.F, d.Hi, d.Wi, d.C0, d.C1, d.N, g)) return 0;
+    const int ntiles = g.ntiles, TR = g.TR, nf = g.nf, PI = g.PI, RAWB = g.RAWB;
+    const size_t lds = g.lds;
     const int grid = ntiles < wino_ncu() ? ntiles : wino_ncu();
-    static const int stagger = getenv("DAWN_WINO_STAGGER") ? atoi(getenv("DAWN_WINO_STAGGER")) : 0;
 #define WINO_LAUNCH(A)                                                                                                      \
     do {                                                                                                                    \
         (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(conv3x3_wino_kernel<A>, dim3(grid), dim3(512), lds, s, d, ntiles, TR, nf, PI, RAWB, stagger);                  \
+        hipLaunchKernelGGL(conv3x3_wino_kernel<A>, dim3(grid), dim3(512), lds, s, d, ntiles, TR, nf, PI, RAWB);             \
     } while (0)
 #ifdef DAWN_ABLATION
-    static const int abl = getenv("DAWN_WINO_ABL") ? atoi(getenv("DAWN_WINO_ABL")) : 0;     // perf ablations (wrong results by design)
+    static const int abl = getenv("DAWN_WINO_ABL") ? atoi(getenv("DAWN_WINO_ABL")) : 0;     // perf ablations / s_memtime build (wrong results by design)
     if (abl == 1) WINO_LAUNCH(1);
     else if (abl == 2) WINO_LAUNCH(2);
-    else if (abl == 4) WINO_LAUNCH(4);
-    else if (abl == 6) WINO_LAUNCH(6);
     else if (abl == 8) WINO_LAUNCH(8);
-    else if (abl == 7) WINO_LAUNCH(7);
     else if (abl == 16) WINO_LAUNCH(16);
-    else if (abl == 9) WINO_LAUNCH(9);
-    else if (abl == 24) WINO_LAUNCH(24);
     else if (abl == 64) WINO_LAUNCH(64);
     else if (abl == 72) WINO_LAUNCH(72);
     else if (abl == 66) WINO_LAUNCH(66);

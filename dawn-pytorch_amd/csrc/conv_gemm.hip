@@ -42,7 +42,7 @@ namespace {
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
 // split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
-constexpr int DAWN_CONV_POLICY_DEFAULT = 0x100580D;
+constexpr int DAWN_CONV_POLICY_DEFAULT = 0x300580D;
 #ifdef DAWN_ABLATION
 constexpr int DAWN_CONV_POLICY_MASK = 0x030FFFFF;
 #else

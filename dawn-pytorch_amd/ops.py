@@ -176,7 +176,8 @@ class HipOps:
                               f"M={rows_gemm} N={N} K={KH * KW * (d.C0 + d.C1)} k={KH}x{KW} s={stride} mode={mode} "
                               f"pro={'r' if row_stats else ('n' if ln_eps else '')}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}"
                               + (" split-bf16" if self._runs_split_kernel(w_bf3, KH, KW, stride, mode, rows_out, N, d.C0, d.C1, tr,
-                                                                          gn_part) else ""),
+                                                                          gn_part) else "")
+                              + (" winograd" if self._runs_winograd(w_wino, KH, KW, stride, mode, F, Hi, Wi, N, d.C0, d.C1, tr) else ""),
                               4.0 * (F * Hi * Wi * (d.C0 + d.C1) + rows_out * N + KH * KW * (d.C0 + d.C1) * N * (4 if mode else 1))))
             return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
@@ -196,6 +197,13 @@ class HipOps:
         if KH == 3 and KW == 3:
             return True
         return KH == 1 and KW == 1 and gn_part is None and self.split_gemm_ok(rows, N, C0, C1)
+
+    def _runs_winograd(self, w_wino, KH, KW, stride, mode, F, H, W, N, C0, C1, tr) -> bool:
+        """Profiling label only: does this 3x3 launch take the Winograd form (the library's own predicate + the policy bit)?"""
+        pol = self.conv_policy or 0x300580D
+        if w_wino is None or tr is not None or not (pol & 0x2000000) or not (pol & 0x1000) or (pol & 0x2000):
+            return False
+        return KH == 3 and KW == 3 and stride == 1 and mode == 0 and bool(self.L.dawn_conv3x3_wino_ok(F, H, W, C0, C1, N))
 
     def ln_inline_ok(self, rows: int, N: int, C0: int, C1: int = 0) -> bool:
         """May the projection compute the LayerNorm of its input rows itself (conv_gemm(ln_eps=...): the row-stationary

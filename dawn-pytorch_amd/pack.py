@@ -49,7 +49,7 @@ def pack_wino_bf3(w5: Tensor) -> Tensor:
     Co, Ci = w5.shape[0], w5.shape[1]
     assert w5.shape[2:] == (1, 3, 3) and Ci % 16 == 0 and Co % 16 == 0, tuple(w5.shape)
     g = w5[:, :, 0].double()                                                        # (Co, Ci, 3, 3)
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64)
+    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w5.device)
     U = torch.einsum("xk,oikl,nl->oixn", G, g, G)                                   # (Co, Ci, xi, nu)
     u1 = U.float().to(torch.bfloat16)
     r1 = U - u1.double()

@@ -73,6 +73,10 @@ typedef struct dawn_conv_desc {
                                                       fp32-Winograd accuracy); NULL or other shapes = the direct split kernel */
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
+/* 1 when a 3x3 / stride 1 / pad 1 conv of this shape (F frames of H x W pixels, C0 + C1 input channels, N output channels) runs in the
+ * Winograd F(2x2,3x3) form once dawn_conv_desc.w_wino is supplied (policy bit 0x2000000, in the shipped default): image width a power
+ * of two <= 64, even height, 256-pixel tiles, an even number of 16-channel chunks, N a multiple of 64 */
+int dawn_conv3x3_wino_ok(int F, int H, int W, int C0, int C1, int N);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;
  * the launch reports the exact count through dawn_conv_desc.gn_rows */
 int dawn_conv_gemm_nblocks(long M, int N);
@@ -82,11 +86,11 @@ int dawn_conv_gemm_nblocks(long M, int N);
 size_t dawn_conv_sk_workspace_bytes(void);
 int dawn_conv_sk_workspace_init(void* ws, void* stream);
 int dawn_conv_sk_check(const void* ws, void* stream);
-/* dawn_conv_desc.policy bits (0 = shipped policy 0x100580D; per call, no process-global state): bit0 BK=32 tiles,
+/* dawn_conv_desc.policy bits (0 = shipped policy 0x300580D; per call, no process-global state): bit0 BK=32 tiles,
  * bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel,
  * 0x1000 split-operand (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000
  * second-generation split 3x3 kernel, 0x1000000 that kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction: less energy per
- * flop on a power-limited chip), 0x400 its persistent stream-K variant (opt-in; needs dawn_conv_desc.sk_ws).  Every combination computes the same function (tests run the kernel families
+ * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops), 0x400 its persistent stream-K variant (opt-in; needs dawn_conv_desc.sk_ws).  Every combination computes the same function (tests run the kernel families
  * against each other); perf-ablation / s_memtime builds exist only under -DDAWN_ABLATION (tools/build_timing_lib.sh). */
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --

@@ -50,6 +50,15 @@ def main():
                 out.zero_()
                 ops.conv_gemm(x0, w, N, in1=x1, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=bias, w_bf3=ws, w_wino=ww, out=out)
             torch.cuda.synchronize()
+            if os.environ.get("DAWN_WINO_ABL") == "128":            # per-wave stamps of workgroup 5: same points as below, all 8 waves
+                st8 = out.reshape(-1).view(torch.int64)[:32 * 8 * 96].reshape(32, 8, 96).cpu().numpy()[5]
+                nC = Cin // 16
+                per_tile = 1 + 5 * nC + 4
+                base = st8[:, 0].min()
+                print(f"shape {si} wg 5, second tile, per wave: absolute stamps (ticks since the workgroup's first stamp), per_tile {per_tile}")
+                for w_ in range(8):
+                    print(f"  wave {w_}:", " ".join(f"{int(v - base):7d}" for v in st8[w_, per_tile:2 * per_tile + 1]))
+                continue
             st = out.reshape(-1).view(torch.int64)[:256 * 96].reshape(256, 96).cpu().numpy()
             nC = Cin // 16
             per_tile = 1 + 5 * nC + 4
