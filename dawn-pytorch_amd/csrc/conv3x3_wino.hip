@@ -170,8 +170,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int RAWB = rawb;                             // bytes of one raw buffer: >= PI KB ([pixel][64 B], PI 16-pixel DMA segments)
-    // [D~ A | raw 0 | D~ B | raw 1 | wsum]: the epilogue's exchange lives in D~ B + raw 1 (both idle then: the number of chunks is
-    // even, so a tile's last chunk sits in raw 1 and the next tile's first one goes to raw 0)
+    // [D~ A | raw 0 | D~ B | raw 1 | wsum | junk | slot table]: the epilogue's exchange lives in D~ B + raw 1 (both idle then: the number
+    // of chunks is even, so a tile's last chunk sits in raw 1, the next tile's first one goes to raw 0 and its second one is not fetched
+    // before the epilogue is over)
     unsigned char* dtA = smem_b;
     unsigned char* raw0 = smem_b + DTG;
     unsigned char* dtB = smem_b + DTG + RAWB;
@@ -251,13 +252,14 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
         Fd.soff = (src1 ? cbase - d.C0 : cbase) * 4;
         Fd.y0 = T.y0;
     };
-    auto issue_slot = [&](const fetch_t& Fd, unsigned char* rawdst, int i) {      // (branch-free: it sits inside a scheduling region)
+    // `live` (wave-uniform) = false: nothing is fetched and the (zero) result goes to the junk area
+    auto issue_slot = [&](const fetch_t& Fd, unsigned char* rawdst, int i, bool live = true) {      // (branch-free: it sits inside a scheduling region)
         const unsigned v = dtab[i * 512 + tid];
         const unsigned row = (unsigned)Fd.y0 + ((v >> 24) & 127u) - 1u;           // image row of the lane's pixel (wraps below 0)
-        const unsigned bad = (v >> 31) | (unsigned)(row >= (unsigned)H);
+        const unsigned bad = (v >> 31) | (unsigned)(row >= (unsigned)H) | (live ? 0u : 1u);
         const unsigned off = (v & 0x3fffffu) * (unsigned)Fd.ldb + ((v >> 22) & 3u) * 16u;
         const unsigned voff = bad ? OOB : off;
-        unsigned char* dp = ddst[i] >= 0 ? rawdst + ddst[i] : junk;
+        unsigned char* dp = (live && ddst[i] >= 0) ? rawdst + ddst[i] : junk;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(Fd.rs, (__attribute__((address_space(3))) void*)dp, 16, voff, Fd.soff, 0, 0);
     };
 
@@ -337,6 +339,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             unsigned char* rawn = (cc & 1) ? raw0 : raw1;
             // phase A: multiply group A of this chunk; transform group B of this chunk; the rest of the next unit's patch
             fn = ff;
+            if (cc == 0 && tile != t_begin) {          // (held back over the previous tile's epilogue, see phase B below)
+                issue_slot(fn, rawn, 0);
+                issue_slot(fn, rawn, 1);
+            }
             issue_slot(fn, rawn, 2);
             issue_slot(fn, rawn, 3);
             __builtin_amdgcn_sched_barrier(0);
@@ -353,9 +359,11 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             // unit after it (past the last tile: zeros nobody reads)
             const int ncc = last ? (has_next ? 0 : nC) : cc + 1;
             const int nn0 = last ? nxt.n0 : cur.n0;
-            issue_slot(ff, rawc, 0);
+            // (behind a tile's LAST chunk this would be the next tile's second chunk, in the raw buffer the epilogue's exchange is about to
+            //  use: held back until that tile's first phase)
+            issue_slot(ff, rawc, 0, !last);
             __builtin_amdgcn_sched_barrier(0);
-            wino_phase<1, ABL>(t, dtB, dtA, rawn, w0, w1, acc, [&]() { load_w(nn0, ncc, 0, 0, w0); issue_slot(ff, rawc, 1); });
+            wino_phase<1, ABL>(t, dtB, dtA, rawn, w0, w1, acc, [&]() { load_w(nn0, ncc, 0, 0, w0); issue_slot(ff, rawc, 1, !last); });
             WSTAMP();   // phase B issued
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (no VMEM wait: patch pieces and w0 stay in flight)
             __builtin_amdgcn_s_barrier();

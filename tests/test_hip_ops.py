@@ -210,6 +210,9 @@ WINO_CASES = [
     ("L3_8x8_four_frames", 12, 8, 8, 256, 0, 512, {"bias": True, "gn": True}),             # 4 whole frames per workgroup
     ("L3_8x8_cat_deepK", 8, 8, 8, 512, 512, 256, {"bias": True, "gn": True}),
     ("clip_edges_1frame", 1, 64, 64, 32, 0, 64, {"bias": True}),
+    ("many_tiles_per_workgroup_L0", 50, 64, 64, 64, 0, 64, {"bias": True, "gn": True}),    # 800 tiles on 256 CUs: the flat (tile, chunk) loop crosses tiles
+    ("many_tiles_per_workgroup_L2_N128", 300, 16, 16, 64, 0, 128, {"bias": True, "gn": True}),  # 600 tiles, two channel tiles per pixel tile
+    ("many_tiles_per_workgroup_L3_two_chunks", 1200, 8, 8, 32, 0, 64, {"bias": True}),    # 300 x 1 tiles of 4 frames, the shortest K
     ("H_not_square_32x64", 2, 32, 64, 32, 0, 64, {"bias": True, "gn": True}),
 ]
 
