@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--data", default="randn")
     ap.add_argument("--only", type=int, nargs="*", default=None, help="indices into SHAPES")
     ap.add_argument("--wino-only", action="store_true")
+    ap.add_argument("--extra-policy", type=lambda v: int(v, 0), default=0, help="a third policy to time (A/B of kernel variants)")
+    ap.add_argument("--check", action="store_true", help="compare the extra policy's output with the Winograd one (bit-identical expected)")
     ap.add_argument("--stamps", action="store_true", help="instrumented build (DAWN_WINO_ABL=64): print the s_memtime timeline of a few workgroups")
     a = ap.parse_args()
     ops = HipOps()
@@ -72,7 +74,10 @@ def main():
             continue
         res = {}
         for rnd_ in range(2):
-            for name, pol in ((("wino", WINO),) if a.wino_only else (("direct", DIRECT), ("wino", WINO))):
+            pols = [("wino", WINO)] if a.wino_only else [("direct", DIRECT), ("wino", WINO)]
+            if a.extra_policy:
+                pols.append(("extra", a.extra_policy))
+            for name, pol in pols:
                 ops.conv_policy = pol
                 part = ops.conv_gn_part(rows, N, x0)
                 for _ in range(3):
@@ -87,6 +92,18 @@ def main():
         wn = min(res["wino"])
         d = min(res["direct"]) if "direct" in res else wn
         fl = 2.0 * rows * N * 9 * Cin
+        if a.extra_policy:
+            ex_ = min(res["extra"])
+            same = ""
+            if a.check:
+                o1, o2 = torch.empty_like(out), torch.empty_like(out)
+                ops.conv_policy = WINO
+                ops.conv_gemm(x0, w, N, in1=x1, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=bias, w_bf3=ws, w_wino=ww, out=o1)
+                ops.conv_policy = a.extra_policy
+                ops.conv_gemm(x0, w, N, in1=x1, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=bias, w_bf3=ws, w_wino=ww, out=o2)
+                torch.cuda.synchronize()
+                same = f"  max|diff| {float((o1 - o2).abs().max()):.2e}"
+            print(f"   extra policy {a.extra_policy:#x}: {ex_:8.1f} us  {(ex_ / wn - 1) * 100:+.1f} % vs winograd{same}")
         print(f"M={rows} N={N} K={9 * Cin} ({H}x{W})   direct {d:8.1f} us ({fl / d / 1e6:6.1f} alg TF/s)   winograd {wn:8.1f} us ({fl / wn / 1e6:6.1f} alg TF/s)   "
               f"{(wn / d - 1) * 100:+.1f} %", flush=True)
 
