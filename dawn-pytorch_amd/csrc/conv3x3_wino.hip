@@ -13,8 +13,8 @@
 // Error vs an fp64 convolution: that of an fp32 Winograd F(2x2,3x3) (tests/test_hip_ops.py::test_conv_wino_is_fp32_accurate).
 //
 // Tile = 256 output pixels (64 Winograd tiles: TR rows x W columns of one frame, or nf whole small frames) x 64 output
-// channels, 8 waves, ONE workgroup per CU (148 KB of LDS, 2 x 256 registers per SIMD).  The grid is PERSISTENT: a workgroup walks a
-// contiguous range of tiles and the (tile, chunk) loop is flat -- the next tile's first patch, first transform and first weight
+// channels, 8 waves, ONE workgroup per CU (148 KB of LDS, 2 x 256 registers per SIMD).  The grid is PERSISTENT: a workgroup walks
+// every G-th tile (XCD-contiguous positions) and the (tile, chunk) loop is flat -- the next tile's first patch, first transform and first weight
 // fragments ride in the last chunk of the current one, so a tile has no prologue and its stores drain behind the next tile's MFMAs
 // (measured on the one-tile-per-workgroup form: 12 us of launch + first-fetch + drain per tile against 3.4 us per chunk).
 // Per 16-channel chunk:
@@ -198,7 +198,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     const int nNt = d.N >> 6;
     const int nCB = d.N >> 4;
     const int TX = W >> 1, TPF = TX * (TR >> 1);       // Winograd tiles per row / per frame part
-    const int t_begin = (int)((long)blockIdx.x * ntiles / gridDim.x), t_end = (int)((long)(blockIdx.x + 1) * ntiles / gridDim.x);
+    // Tile order: round r hands tile r * G + p to the workgroup at position p, and the positions of one XCD (workgroups g, g + 8, ...:
+    // dispatch is round-robin over the 8 XCDs) are contiguous -- at any moment the 32 workgroups of an XCD work on 32 ADJACENT tiles
+    // (pixel tiles and their channel tiles), so the halo rows two neighbours share and the patch the channel tiles of one pixel tile
+    // share meet in that XCD's L2.  (A contiguous tile range per workgroup read every halo row twice from the fabric: 410 MB per
+    // launch at level 0 against 224 MB for the one-tile-per-workgroup kernel, profiles/r4_wino_fetch_by_shape.txt.)
+    const int G = gridDim.x;
+    int t_begin;
+    {
+        const int g = blockIdx.x, xcd = g & 7, idx = g >> 3, q = G >> 3, r = G & 7;
+        t_begin = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int t_end = ntiles;
     if (t_begin >= t_end) return;
 
     // ---- raw-patch DMA slots of this wave: slot s = wave + 8 i -> (channel quad, 64-pixel segment); lane = pixel.  The patch geometry
@@ -311,7 +322,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     bf16x8 w0[2][2], w1[2][2];
     tile_t cur, nxt;
     setup(t_begin, true, cur);
-    setup(t_begin + 1 < t_end ? t_begin + 1 : t_begin, t_begin + 1 < t_end, nxt);
+    setup(t_begin + G < t_end ? t_begin + G : t_begin, t_begin + G < t_end, nxt);
     fetch_t fn, ff;                                    // the patch of the next unit / of the unit after it
     fetch_of(cur, 0, fn);
     fetch_of(cur, 1, ff);                              // (nC >= 2)
@@ -330,9 +341,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     // three pieces: slot 0 at the top of phase B(u-2), slot 1 in its middle, slots 2..3 at the top of phase A(u-1), each right behind
     // a weight fetch: VMEM returns in order, so a patch piece has to land before the next YOUNGER weight fetch is waited for, which
     // is one phase later at these positions
-    for (int tile = t_begin; tile < t_end; ++tile) {
+    for (int tile = t_begin; tile < t_end; tile += G) {
         WSTAMP();   // tile start
-        const bool has_next = tile + 1 < t_end;
+        const bool has_next = tile + G < t_end;
         for (int cc = 0; cc < nC; ++cc) {
             const bool last = cc == nC - 1;
             unsigned char* rawc = (cc & 1) ? raw1 : raw0;
@@ -472,7 +483,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
 #pragma unroll
                 for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
         cur = nxt;
-        setup(tile + 2 < t_end ? tile + 2 : tile, tile + 2 < t_end, nxt);
+        setup(tile + 2 * G < t_end ? tile + 2 * G : tile, tile + 2 * G < t_end, nxt);
     }
 #endif
 }

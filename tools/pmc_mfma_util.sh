@@ -21,7 +21,7 @@ did = "dispatch_id" if "dispatch_id" in ci else None
 per = collections.defaultdict(dict)
 for r in db.execute("select * from counters_collection"):
     kn = str(r[ci[name_col]]).replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0]
-    if "conv3x3_bf16" not in kn:
+    if "conv3x3_bf16" not in kn and "conv3x3_wino" not in kn:
         continue
     key = (kn, r[ci[did]] if did else 0, r[ci["grid_size"]] if "grid_size" in ci else 0)
     per[key][r[ci["counter_name"]]] = per[key].get(r[ci["counter_name"]], 0.0) + float(r[ci["value"]])
