@@ -351,6 +351,8 @@ def main():
     ap.add_argument("--no-overlap", action="store_true", help="disable the two-stream overlap inside ResBlocks")
     ap.add_argument("--no-fuse-h1", action="store_true",
                     help="A/B only: separate h_cond tensor + GroupNorm-apply pass instead of the cross-attention kernels' fused h1 epilogue")
+    ap.add_argument("--no-fuse-gn", action="store_true",
+                    help="A/B only: separate GroupNorm reduce + finalize launch instead of the conv launch's own finalisation")
     ap.add_argument("--temporal-flags", type=int, default=0, help="dawn_temporal_layer_c64_ex flags (A/B: 16 = interleave hints in the WMODE-3 kernel)")
     ap.add_argument("--temporal-attn-flags", type=int, default=0, help="dawn_temporal_attn_ex flags (A/B: 1 = the fp32-MFMA attention core)")
     ap.add_argument("--conv-policy", type=lambda v: int(v, 0), default=0,
@@ -416,6 +418,7 @@ def main():
     ops.temporal_attn_flags = args.temporal_attn_flags
     ops.temporal_flags = args.temporal_flags
     ops.fuse_h1 = not args.no_fuse_h1
+    ops.fuse_gn = not args.no_fuse_gn
     diff.use_ctx = args.host == "ctx" and mode != "tshard"
     if diff.use_ctx:
         from dawn_pytorch_amd import ctx as _ctx

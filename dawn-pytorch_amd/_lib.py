@@ -41,6 +41,10 @@ class ConvDesc(C.Structure):
         ("ln_eps", _f),
         ("sk_ws", c_f), ("sk_ws_bytes", C.c_size_t),
         ("w_wino", c_f),
+        ("gn_gamma", c_f), ("gn_beta", c_f), ("gn_fs", c_f), ("gn_fsh", c_f),
+        ("gn_count", C.c_double), ("gn_eps", _f),
+        ("gn_a", c_f), ("gn_b", c_f),
+        ("gn_ticket", c_f),
     ]
 
 

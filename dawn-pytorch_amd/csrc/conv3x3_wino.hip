@@ -33,7 +33,7 @@
 // the matrix pipe's shadow, one barrier per 48 MFMAs per wave.
 // Epilogue: the nu half of A^T M A in registers (4 accumulators -> 2), the xi half across the four row-position waves through
 // LDS (8 values per (tile, channel) instead of 16; one 32-channel half at a time in the D~ region + raw buffer the next tile does not
-// need yet), then bias (+ residual), 16-byte row-segment stores and GroupNorm(8) partials (one gn_part row per tile).
+// need yet), then bias (+ residual), 16-byte row-segment stores and GroupNorm(8) partials (one gn_part row per workgroup; optionally the coefficients themselves).
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 #include <cstdlib>
@@ -314,6 +314,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    double gacc = 0.0;                                 // threads 0..15: this workgroup's GroupNorm partial (group tid >> 1, sum / sumsq), tiles in order
 
     // weight fragments: one position = 4 fragments (16 registers), TWO positions live: w0 serves tile blocks 0..3 of a phase, w1 blocks
     // 4..7; the next phase's w0 is fetched into w0's registers once it is dead (after block 3), the next phase's w1 at the top of that
@@ -474,7 +475,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
                     const int c = 8 * jg;
                     if (c >= lo && c < hi) a += (double)wsum[w * 16 + jg * 2 + which];
                 }
-            d.gn_part[(long)tile * 16 + tid] = a;
+            gacc += a;
         }
 #pragma unroll
         for (int i = 0; i < 4; ++i)
@@ -484,6 +485,55 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
                 for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
         cur = nxt;
         setup(tile + 2 * G < t_end ? tile + 2 * G : tile, tile + 2 * G < t_end, nxt);
+    }
+    // ---- GroupNorm(8): one gn_part row per WORKGROUP (fp64, tiles in fixed order); with dawn_conv_desc.gn_a the workgroup that
+    // finishes last also reduces the rows (fixed order: deterministic whoever is last) and writes the per-channel coefficients --
+    // the separate one-block reduce + finalize launch (40 per evaluation, on the critical path of every ResBlock) is gone
+    if (d.gn_part) {
+        if (tid < 16) __hip_atomic_store(d.gn_part + (long)blockIdx.x * 16 + tid, gacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (d.gn_a) {
+            // (no agent-scope fence: a release would write back the XCD's whole L2 -- the conv output the next kernel is about to read --
+            //  once per workgroup: measured -4.5 % on the whole benchmark.  The rows and the ticket are agent-scope atomics (write-through /
+            //  coherent reads); the row stores have been acknowledged (vmcnt 0) before thread 0 takes the ticket behind the barrier)
+            unsigned* flag = reinterpret_cast<unsigned*>(wsum);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            if (tid == 0) flag[0] = __hip_atomic_fetch_add(d.gn_ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == (unsigned)(G - 1);
+            __syncthreads();
+            if (flag[0]) {
+                double* sh = reinterpret_cast<double*>(smem_b);                  // [32 partial rows][16] + [16]
+                const int c = tid & 15, r0 = tid >> 4;
+                double a = 0.0;
+                for (int b = r0; b < G; b += 32) a += __hip_atomic_load(d.gn_part + (long)b * 16 + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                sh[tid] = a;
+                __syncthreads();
+                if (tid < 16) {
+                    double t2 = 0.0;
+                    for (int k = 0; k < 32; ++k) t2 += sh[k * 16 + tid];
+                    sh[512 + tid] = t2;
+                }
+                __syncthreads();
+                const int cpg = d.N >> 3;
+                for (int ch = tid; ch < d.N; ch += 512) {                       // (norm.hip gn_coeff: a = rstd gamma (fs + 1), b = (beta - mean rstd gamma)(fs + 1) + fsh)
+                    const int g = ch / cpg;
+                    const double mean = sh[512 + 2 * g] / d.gn_count;
+                    double var = sh[512 + 2 * g + 1] / d.gn_count - mean * mean;
+                    if (var < 0) var = 0;
+                    const float rstd = (float)(1.0 / sqrt(var + (double)d.gn_eps));
+                    const float mu = (float)mean;
+                    float av = rstd * d.gn_gamma[ch];
+                    float bv = d.gn_beta[ch] - mu * av;
+                    if (d.gn_fs) {
+                        const float sc = d.gn_fs[ch] + 1.0f;
+                        av *= sc;
+                        bv = bv * sc + d.gn_fsh[ch];
+                    }
+                    d.gn_a[ch] = av;
+                    d.gn_b[ch] = bv;
+                }
+                if (tid == 0) __hip_atomic_store(d.gn_ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // ready for the next launch
+            }
+        }
     }
 #endif
 }
@@ -557,6 +607,6 @@ int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream
 #endif
     WINO_LAUNCH(0);
 #undef WINO_LAUNCH
-    if (nrows) *nrows = ntiles;
+    if (nrows) *nrows = (d.gn_part && d.gn_a) ? -grid : grid;      // rows of gn_part written; negative: the launch also wrote gn_a / gn_b
     return 1;
 }

@@ -272,6 +272,7 @@ struct Eval {
     ClipLayout L;
     int rc = 0;
     void* sk_ws = nullptr;
+    unsigned* gn_ticket = nullptr;           // zeroed device word of the convs' fused GroupNorm finalisation (one per evaluation)
     size_t sk_bytes = 0;
     const dawn_shard_comm* sc = nullptr;     // T-shard exchanges (dawn_unet_forward_sharded) or nullptr = single GPU
     int Ftot = 0, f0g = 0;                   // clip length and first own frame, global
@@ -319,6 +320,10 @@ struct Eval {
         const float *tr = nullptr, *tr_a = nullptr, *tr_b = nullptr; int ld_tr = 0;
         float* out = nullptr; int ld_out = 0;
         double* gn_part = nullptr; int* gn_rows = nullptr;
+        // finish the GroupNorm in the conv launch (dawn_conv_desc.gn_a ...): gamma / beta / FiLM + outputs; *gn_rows < 0 says it happened
+        const float *gn_gamma = nullptr, *gn_beta = nullptr, *gn_fs = nullptr, *gn_fsh = nullptr;
+        float *gn_a = nullptr, *gn_b = nullptr;
+        long gn_total_rows = 0;
     };
     void conv(const ConvArgs& a) {
         dawn_conv_desc d;
@@ -330,6 +335,12 @@ struct Eval {
         d.res = a.res; d.ld_res = a.ld_res; d.tr = a.tr; d.ld_tr = a.ld_tr; d.tr_a = a.tr_a; d.tr_b = a.tr_b;
         d.out = a.out; d.ld_out = a.ld_out; d.gn_part = a.gn_part; d.w_bf3 = a.w_bf3; d.w_wino = a.w_wino; d.gn_rows = a.gn_rows;
         d.policy = c->conv_policy;
+        if (a.gn_a && a.gn_part && !sc && gn_ticket) {       // (T-sharded: an all-reduce sits between reduce and finalize)
+            d.gn_gamma = a.gn_gamma; d.gn_beta = a.gn_beta; d.gn_fs = a.gn_fs; d.gn_fsh = a.gn_fsh;
+            d.gn_count = (double)a.gn_total_rows * ((double)Ftot / (double)F) * (a.N / 8);
+            d.gn_eps = 1e-5f;
+            d.gn_a = a.gn_a; d.gn_b = a.gn_b; d.gn_ticket = gn_ticket;
+        }
         if (sk_ws && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1) { d.sk_ws = sk_ws; d.sk_ws_bytes = sk_bytes; }
         if (dry || rc) { if (a.gn_rows) *a.gn_rows = 1; return; }
         const bool prof = c->prof_on;
@@ -355,6 +366,7 @@ struct Eval {
     // per-channel (a, b): silu(x*a+b) == SiLU(FiLM(GroupNorm8(x)))   (ops.gn_coeffs, single-GPU form)
     void gn_coeffs(const double* part, int nblk, long total_rows, int Cc, const float* gamma, const float* beta, const float* fs,
                    const float* fsh, float* a, float* b) {
+        if (nblk < 0) return;                        // the conv launch that produced `part` wrote a / b itself (ConvArgs.gn_a)
         // statistics over the WHOLE clip (MT:230,235): total_rows counts this rank's rows
         const double cnt = (double)total_rows * ((double)Ftot / (double)F) * (Cc / 8);
         if (!sc) {
@@ -473,14 +485,15 @@ struct Eval {
         double* part = gn_part_alloc(rows, Co);
         int nblk = 0;
         T2 c1 = t2(rows, Co);
+        float* ab1 = falloc(2 * (size_t)Co);
         {
             ConvArgs a;
             a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.in1 = x2 ? x2->p : nullptr; a.C1 = x2 ? x2->C : 0; a.ld1 = a.C1;
             a.w = rb.w1; a.w_bf3 = rb.w1s; a.w_wino = rb.w1w; a.bias = rb.b1; a.N = Co; a.Fr = Fr; a.Hi = H; a.Wi = W; a.KH = 3; a.KW = 3; a.pad = 1;
             a.out = c1.p; a.ld_out = Co; a.gn_part = part; a.gn_rows = &nblk;
+            a.gn_gamma = rb.g1; a.gn_beta = rb.be1; a.gn_fs = fs; a.gn_fsh = fsh; a.gn_a = ab1; a.gn_b = ab1 + Co; a.gn_total_rows = total_rows;
             conv(a);
         }
-        float* ab1 = falloc(2 * (size_t)Co);
         gn_coeffs(part, nblk, total_rows, Co, rb.g1, rb.be1, fs, fsh, ab1, ab1 + Co);
         T2 h1;
         if (fuse_h1) {
@@ -502,14 +515,15 @@ struct Eval {
         double* part2 = gn_part_alloc(rows, Co);
         int nblk2 = 0;
         T2 c2 = t2(rows, Co);
+        float* ab2 = falloc(2 * (size_t)Co);
         {
             ConvArgs a;
             a.in0 = h1.p; a.C0 = Co; a.ld0 = Co; a.w = rb.w2; a.w_bf3 = rb.w2s; a.w_wino = rb.w2w; a.bias = rb.b2; a.N = Co;
             a.Fr = Fr; a.Hi = H; a.Wi = W; a.KH = 3; a.KW = 3; a.pad = 1; a.out = c2.p; a.ld_out = Co; a.gn_part = part2; a.gn_rows = &nblk2;
+            a.gn_gamma = rb.g2; a.gn_beta = rb.be2; a.gn_a = ab2; a.gn_b = ab2 + Co; a.gn_total_rows = total_rows;
             conv(a);
         }
         rel(h1);
-        float* ab2 = falloc(2 * (size_t)Co);
         gn_coeffs(part2, nblk2, total_rows, Co, rb.g2, rb.be2, nullptr, nullptr, ab2, ab2 + Co);
         T2 out;
         if (rb.wr) {
@@ -694,6 +708,8 @@ struct Eval {
             if (!sk_ws && rc == 0) rc = dawn_set_error_msg(-201, "dawn_ctx: activation workspace too small (dawn_workspace_bytes)");
             if (sk_ws) LAUNCH(dawn_conv_sk_workspace_init(sk_ws, cur));
         }
+        gn_ticket = (unsigned*)falloc(4);
+        if (gn_ticket && !dry && rc == 0) (void)hipMemsetAsync(gn_ticket, 0, 16, cur);
         // time_film: sinusoidal -> Linear -> GELU -> Linear -> [SiLU -> Linear] for every block in one GEMV
         float* e0 = falloc(dim);
         float* e1 = falloc(c->time_dim);
@@ -779,6 +795,7 @@ struct Eval {
             rel(hg); rel(ho);
         }
         A.free(film);
+        if (gn_ticket) { A.free(gn_ticket); gn_ticket = nullptr; }
         if (sk_ws) { A.free(sk_ws); sk_ws = nullptr; }
     }
 };

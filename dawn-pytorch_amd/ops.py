@@ -49,6 +49,8 @@ class HipOps:
         self.fuse_h1 = True          # cross-attention kernels write h1 = SiLU(GN(c1)) + h_cond themselves (False: A/B, two-stream form)
         self._sk_ws = {}             # (device index, stream) -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
         self._sel_ws = {}            # (device index, stream) -> scratch of the threshold selection (histograms, state)
+        self._tickets = {}           # (device index, stream) -> the zeroed device word of the convs' fused GroupNorm finalisation
+        self.fuse_gn = True          # GroupNorm coefficients from the conv launch itself where the kernel can (False: A/B, separate launch)
         # (keyed by stream as well: the dicts are shared by every with_comm() copy, and two samplers on one device -- in-process
         # ranks, concurrent clips -- run on different streams and must not share histograms / hand-off flags)
 
@@ -62,6 +64,13 @@ class HipOps:
             check(self.L.dawn_conv_sk_workspace_init(_p(ws), self._stream()), "dawn_conv_sk_workspace_init")
             self._sk_ws[key] = ws
         return ws
+
+    def _gn_ticket(self, like: Tensor) -> Tensor:
+        key = (like.device.index, self._stream())
+        t = self._tickets.get(key)
+        if t is None:
+            t = self._tickets[key] = torch.zeros(1, device=like.device, dtype=torch.int32)
+        return t
 
     def sk_check(self) -> None:
         """Synchronising check of the stream-K kernel's error word (call once per clip, not per launch)."""
@@ -81,6 +90,8 @@ class HipOps:
         o.fuse_h1 = self.fuse_h1
         o._sk_ws = self._sk_ws
         o._sel_ws = self._sel_ws
+        o._tickets = self._tickets
+        o.fuse_gn = self.fuse_gn
         return o
 
     # ------------------------------------------------------------------ helpers
@@ -129,7 +140,9 @@ class HipOps:
                   pro_act: int = 0, pro_add: Optional[Tensor] = None, res: Optional[Tensor] = None,
                   tr: Optional[Tuple[Tensor, Tensor, Tensor]] = None, out: Optional[Tensor] = None,
                   gn_part: Optional[Tensor] = None, w_bf3: Optional[Tensor] = None, ln_eps: float = 0.0,
-                  w_wino: Optional[Tensor] = None) -> Tensor:
+                  w_wino: Optional[Tensor] = None, gn_fin: Optional[tuple] = None) -> Tensor:
+        """gn_fin = (gamma, beta, film or None, total_rows[, eps]) with gn_part: ask the launch to finish the GroupNorm itself (the
+        Winograd 3x3 kernel's last workgroup reduces and finalises); gn_coeffs(part=...) then returns its coefficients without a launch."""
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
         rows_out = F * Ho * Wo
@@ -162,15 +175,28 @@ class HipOps:
             ws = self.sk_workspace(in0)
             d.sk_ws, d.sk_ws_bytes = _p(ws), ws.numel()
         nrows = C.c_int(0)
+        fin_ab = None
         if gn_part is not None:
             d.gn_rows = C.pointer(nrows)
+            gn_part.dawn_ab = None
+            if gn_fin is not None and self.comm is None and self.fuse_gn:
+                gamma, beta, film, total_rows = gn_fin[:4]
+                fin_ab = (self.empty(N, like=in0), self.empty(N, like=in0))
+                d.gn_gamma, d.gn_beta = _p(gamma), _p(beta)
+                if film is not None:
+                    d.gn_fs, d.gn_fsh = _p(film[0]), _p(film[1])
+                d.gn_count = float(total_rows) * (N // 8)
+                d.gn_eps = gn_fin[4] if len(gn_fin) > 4 else 1e-5
+                d.gn_a, d.gn_b = _p(fin_ab[0]), _p(fin_ab[1])
+                d.gn_ticket = _p(self._gn_ticket(in0))
         if self.prof is not None and self.prof_on:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
             e1.record()
             if gn_part is not None:
-                gn_part.dawn_rows = nrows.value
+                gn_part.dawn_rows = abs(nrows.value)
+                gn_part.dawn_ab = fin_ab if nrows.value < 0 else None
             rows_gemm = rows_out if mode == 0 else F * Hi * Wi * 4
             self.prof.append((2.0 * rows_gemm * N * KH * KW * (d.C0 + d.C1), e0, e1,
                               f"M={rows_gemm} N={N} K={KH * KW * (d.C0 + d.C1)} k={KH}x{KW} s={stride} mode={mode} "
@@ -182,7 +208,8 @@ class HipOps:
             return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
         if gn_part is not None:
-            gn_part.dawn_rows = nrows.value      # rows the launch wrote (the rest of the buffer is unused)
+            gn_part.dawn_rows = abs(nrows.value)      # rows the launch wrote (the rest of the buffer is unused)
+            gn_part.dawn_ab = fin_ab if nrows.value < 0 else None      # ... and the coefficients, when the launch finalised them itself
         return out
 
     def _runs_split_kernel(self, w_bf3, KH, KW, stride, mode, rows, N, C0, C1, tr, gn_part) -> bool:
@@ -229,6 +256,8 @@ class HipOps:
         WHOLE clip: with a T-shard communicator the fp64 partial sums are all-reduced.  `part` = partial sums
         already produced by the conv epilogue (conv_gemm(gn_part=...)); otherwise a statistics pass runs."""
         rows, Cc = x.shape
+        if part is not None and getattr(part, "dawn_ab", None) is not None:
+            return part.dawn_ab                  # the conv launch that produced `part` finalised the coefficients itself (gn_fin)
         self._require(x, gamma, beta)
         sums = self.empty(16, like=x, dtype=torch.float64) if self.comm is not None else None
         s = self._stream()

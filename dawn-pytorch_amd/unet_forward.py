@@ -128,7 +128,8 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     def conv1_and_stats():
         # GroupNorm partial sums come out of the conv epilogue (no separate statistics pass over c)
         part = ops.conv_gn_part(F * H * W, Co, x)
-        c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, gn_part=part, w_bf3=rb.w1s, w_wino=rb.w1w, **g)
+        c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, gn_part=part, w_bf3=rb.w1s, w_wino=rb.w1w,
+                          gn_fin=(rb.g1, rb.be1, film, total_rows), **g)
         return c, ops.gn_coeffs(c, rb.g1, rb.be1, film, total_rows, part=part)
 
     h1 = None
@@ -154,7 +155,8 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
         h1 = ops.gn_apply_res(c1, ab1[0], ab1[1], hcond, inplace=True)      # (over c1: it has no other reader)
         del c1, hcond
     part2 = ops.conv_gn_part(F * H * W, Co, x)
-    c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, w_bf3=rb.w2s, w_wino=rb.w2w, **g)
+    c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, w_bf3=rb.w2s, w_wino=rb.w2w,
+                       gn_fin=(rb.g2, rb.be2, None, total_rows), **g)
     del h1
     a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows, part=part2)
     if rb.wr is not None:

@@ -56,7 +56,7 @@ typedef struct dawn_conv_desc {
                                                       bf16 planes w = w1+w2+w3, [K/16][3][2][N][8] (k = tap*(C0+C1)+c), for
                                                       the split-operand bf16-MFMA kernel; NULL = fp32 MFMA */
     int* gn_rows;                                  /* optional HOST pointer: receives the number of gn_part rows this launch
-                                                      writes (= its thread-block count; <= dawn_conv_gemm_nblocks) */
+                                                      writes (<= dawn_conv_gemm_nblocks); negative = the launch also finalised (gn_a below) */
     int policy;                                    /* kernel-selection policy bits (see below); 0 = shipped default */
     float ln_eps;                                  /* > 0: LayerNorm (no gain) over the C0+C1 channels of every input row, computed by the
                                                       GEMM itself -- no statistics pass (instead of row_mean / row_rstd).  <= 128 channels: from the
@@ -71,6 +71,14 @@ typedef struct dawn_conv_desc {
                                                       [(C0+C1)/16][16 positions][N/16][2][64 lanes][8] (pack.pack_wino_bf3).  With policy bit
                                                       0x2000000 such convs run in the Winograd form (2.25x fewer matrix-pipe flops, fp32 results to
                                                       fp32-Winograd accuracy); NULL or other shapes = the direct split kernel */
+    /* optional, with gn_part: finish the GroupNorm in the conv launch itself (dawn_gn_reduce_finalize's arguments: MT:230-248) -- the
+     * workgroup that finishes last reduces the partial rows in fixed order and writes a[c] / b[c].  Honoured by the Winograd kernel
+     * only; *gn_rows < 0 then says so (|*gn_rows| rows were written), otherwise call dawn_gn_reduce_finalize as before.  gn_ticket =
+     * one device word, zero before the first launch (the launch leaves it zero); one per stream. */
+    const float* gn_gamma; const float* gn_beta; const float* gn_fs; const float* gn_fsh;
+    double gn_count; float gn_eps;
+    float* gn_a; float* gn_b;
+    unsigned* gn_ticket;
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
 /* 1 when a 3x3 / stride 1 / pad 1 conv of this shape (F frames of H x W pixels, C0 + C1 input channels, N output channels) runs in the

@@ -44,8 +44,8 @@ def test_conv_desc_layout_matches_c():
         decl = decl.strip()
         if not decl:
             continue
-        is_wide = "*" in decl or decl.startswith("size_t")
-        for name in re.sub(r"^(const\s+)?(float|int|double|void|size_t)\s*\*?", "", decl).split(","):
+        is_wide = "*" in decl or decl.startswith("size_t") or decl.startswith("double")
+        for name in re.sub(r"^(const\s+)?(float|int|double|void|size_t|unsigned)\s*\*?", "", decl).split(","):
             fields.append((name.strip().lstrip("*").strip(), 8 if is_wide else 4))
     off, expect = 0, {}
     for name, size in fields:

@@ -258,6 +258,19 @@ def test_conv3x3_winograd(hip, ref, case):
                 a2, b2 = hip.gn_coeffs(got, gamma, beta, None, rows)
                 check(f"conv3x3_wino/{name}/gn_a/v{variant:#x}", a1, a2, 1e-5)
                 check(f"conv3x3_wino/{name}/gn_b/v{variant:#x}", b1, b2, 1e-5)
+                if variant == WINO and not ex.get("fallback"):
+                    # ... and the coefficients the launch finalises itself (gn_fin: last workgroup reduces + finalises, FiLM included),
+                    # twice in a row: the ticket word is left zero for the next launch
+                    film = (rnd(N, seed=16).cuda() * 0.1, rnd(N, seed=17).cuda() * 0.1)
+                    a3, b3 = hip.gn_coeffs(got, gamma, beta, film, 3 * rows)
+                    for rep in range(2):
+                        part2 = hip.conv_gn_part(rows, N, x0g)
+                        got2 = hip.conv_gemm(x0g, wg, N, in1=x1g, gn_part=part2, gn_fin=(gamma, beta, film, 3 * rows), **gkw)
+                        assert part2.dawn_ab is not None and torch.equal(got2, got)
+                        a4, b4 = hip.gn_coeffs(got2, gamma, beta, film, 3 * rows, part=part2)
+                        assert a4 is part2.dawn_ab[0]
+                        check(f"conv3x3_wino/{name}/gn_fused_a/{rep}", a4, a3, 1e-5)
+                        check(f"conv3x3_wino/{name}/gn_fused_b/{rep}", b4, b3, 1e-5)
         hip.conv_policy = WINO
         again = hip.conv_gemm(x0g, wg, N, in1=x1g, **gkw)
         assert torch.equal(again, outs[0])                                    # fixed summation order
