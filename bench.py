@@ -66,7 +66,7 @@ def synthetic_inputs(T, h, device, seed=123, f0=0, Ttotal=None):
 def cpu_baseline(h, S, sample_frames, unet_cpu_sd):
     """The CPU oracle (oracle/dawn_oracle.py, kind "port": the reference is Python and does not travel)
     timed on this box's host cores on a bounded sample: ONE warm UNet evaluation + sampler epilogue on
-    `sample_frames` frames (>= 2w+1 = 81 so that the attention window cuts as it does at the benchmark length)
+    `sample_frames` frames (default: the benchmark's own clip length, so attended pairs per frame are the benchmark's)
     at the benchmark resolution, after an untimed 4-frame evaluation that pays the one-off costs (thread pool,
     allocator, oneDNN primitive caches); frames/s = frames / (S * t_step)."""
     from oracle import dawn_oracle as O
@@ -97,10 +97,10 @@ def cpu_baseline(h, S, sample_frames, unet_cpu_sd):
             dt = one(Ts)
     finally:
         torch.set_num_threads(prev)
-    return {"value": Ts / (S * dt), "unit": "frames/s", "cores": nthr, "kind": "port",
-            "sample": f"1 warm UNet evaluation + threshold/update on {Ts} frames @ {h * 4}x{h * 4} ({dt:.1f} s on "
+    return {"value": Ts / (S * dt), "unit": "frames/s", "cores": nthr, "kind": "port", "sample_frames": Ts,
+            "sample": f"1 warm UNet evaluation + threshold/update on a {Ts}-frame clip @ {h * 4}x{h * 4} ({dt:.1f} s on "
                       f"{nthr} threads -- the fastest of 16/32/64/128 on this box --, after an untimed 2-frame warm-up of "
-                      f"{warm:.1f} s), extrapolated to {S} DDIM steps"}
+                      f"{warm:.1f} s); the {S} DDIM steps of a clip repeat that evaluation: frames/s = {Ts} / ({S} x {dt:.1f} s)"}
 
 
 def power_ceiling(ops, device, iters=20000):
@@ -334,7 +334,8 @@ def main():
     ap.add_argument("--ddim-steps", type=int, default=50)
     ap.add_argument("--mode", choices=["tshard", "replica"], default="tshard")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-frames", type=int, default=96)
+    ap.add_argument("--cpu-sample-frames", type=int, default=0,
+                    help="frames of the CPU oracle's timed evaluation (0 = the benchmark's own clip length: SURVEY 8d D4)")
     ap.add_argument("--no-max-clip", action="store_true", help="skip the max-clip-length probes")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) flow-decode report")
@@ -634,7 +635,7 @@ def main():
                           "per_rank": per_rank}
     if not args.no_cpu_baseline and n_gpus == 1:
         sd = {"denoise_fn." + k: v.detach().cpu() for k, v in unet.state_dict().items()}
-        result["cpu_baseline"] = cpu_baseline(h, S, args.cpu_sample_frames, sd)
+        result["cpu_baseline"] = cpu_baseline(h, S, args.cpu_sample_frames or T, sd)
     if dist is not None:
         dist.destroy_process_group()
     sys.stdout.flush()

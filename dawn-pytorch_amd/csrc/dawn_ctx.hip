@@ -577,6 +577,30 @@ struct Eval {
             rel(xe);
             return o;
         }
+        if (Fr > c->long_clip_frames) {
+            // long shards (unet_forward._temporal_sharded): qkv per segment of 200 query frames on the row window [a - win, b + win) of the
+            // extended buffer -- the (rows, 768) tensor of the whole shard was the workspace peak; the projection of the own rows no
+            // longer overlaps the transfer (2 * win frames of thousands: a 1 % matter)
+            CALLBACK(halo_end, (void*)cur);
+            o = t2(x.rows, C);
+            for (int fa = hl; fa < hl + Fr; fa += 200) {
+                const int fb = fa + 200 < hl + Fr ? fa + 200 : hl + Fr;
+                const int ea = fa - win > 0 ? fa - win : 0, eb = fb + win < Fext ? fb + win : Fext;
+                T2 xv;
+                xv.p = xe.p ? xe.p + (size_t)ea * HW * C : nullptr; xv.rows = (long)(eb - ea) * HW; xv.C = C;
+                T2 qkv = ln_gemm(xv, nullptr, a.wqkv, 768, a.wqkv_s, eb - ea, H, W);
+                T2 at = t2((long)(fb - fa) * HW, 256);
+                LAUNCH(dawn_temporal_attn(qkv.p, eb - ea, HW, fa - ea, fb - fa, win, clipf(L.rcos), clipf(L.rsin), clipf(L.band), at.p, cur));
+                rel(qkv);
+                ConvArgs g;
+                g.in0 = at.p; g.C0 = 256; g.ld0 = 256; g.w = a.wout; g.w_bf3 = a.wout_s; g.N = C; g.Fr = fb - fa; g.Hi = H; g.Wi = W;
+                g.res = x.p + (size_t)(fa - hl) * HW * C; g.ld_res = C; g.out = o.p ? o.p + (size_t)(fa - hl) * HW * C : nullptr; g.ld_out = C;
+                conv(g);
+                rel(at);
+            }
+            rel(xe);
+            return o;
+        }
         T2 qkv = t2((long)Fext * HW, 768);
         auto project = [&](int fa, int fb) {             // LayerNorm + qkv projection of buffer frames [fa, fb)
             T2 v; v.rows = (long)(fb - fa) * HW; v.C = C; v.p = xe.p ? xe.p + (size_t)fa * HW * C : nullptr;
@@ -725,7 +749,7 @@ struct Eval {
         LAUNCH(dawn_init_conv_x(x3, c->w3, clipf(L.fea_pre), F, H, W, dim, r.p, cur));
         T2 x = temporal(c->init_tattn, r, F, H, W);
         // long clips: the heads' skip is recomputed at the end (0.8 % of an evaluation) instead of held through it (unet_forward)
-        const bool lean = !sc && F > c->long_clip_frames;
+        const bool lean = F > c->long_clip_frames;          // (sharded ranks too: the skip is frame-local, no halo is involved)
         if (lean) rel(r);
         struct Skip { T2 t; int H, W; };
         std::vector<Skip> skips;

@@ -95,3 +95,41 @@ def test_ctx_sharded_two_ranks_in_process_equal_unsharded(tiny, world):
         assert torch.equal(thr, res[0][1])                     # every rank selected the same whole-clip threshold
     err = log(f"ctx_sharded_world{world}_ddim_vs_unsharded", got_s, want_s)
     assert err < 5e-5, err
+
+
+def test_ctx_sharded_long_shards_run_the_lean_form(tiny):
+    """DAWN_OPT_LONG_CLIP_FRAMES applies to sharded calls too (VERDICT r3 #5 / ADVICE): shards longer than the option run the
+    memory-lean form -- qkv of the unfused attention levels per 200-query segment on row windows of the extended buffer, the heads'
+    skip recomputed, the heads one after the other -- with a smaller workspace, and still equal the unsharded clip.  Two in-process
+    ranks of 230 frames (two segments each, the second one short), window 3."""
+    from dawn_pytorch_amd import ctx as C_
+    g, sd = tiny
+    unet = tiny_unet(sd)
+    ops, P = unet._ops(), unet.packed()
+    world, Fr = 2, 230
+    Tt = Fr * world
+    gen = torch.Generator().manual_seed(12)
+    fea272 = T(g["x"])[0, 3:, 0].contiguous().cuda()
+    cond = torch.randn(Tt, T(g["cond"]).shape[2], generator=gen).cuda()
+    x3 = torch.randn(3, Tt, 8, 8, generator=gen).cuda()
+    unet.update_num_frames(Tt)
+    want = unet_forward(ops, P, unet.build_clip(fea272, cond), x3, 500)
+    torch.cuda.synchronize()
+    need = {}
+    for lean in (False, True):
+        ex = _Exchange(world)
+        evs = [CtxEvaluator(P) for _ in range(world)]
+        if lean:
+            for ev in evs:
+                ev.set_option(C_.OPT_LONG_CLIP_FRAMES, 100)
+
+        def rank_forward(r):
+            clip = evs[r].prepare_clip(fea272, cond[r * Fr:(r + 1) * Fr].contiguous())
+            cb = ex.callbacks(r)
+            out = evs[r].forward(clip, x3[:, r * Fr:(r + 1) * Fr].contiguous(), 500.0, shard=cb)
+            need[(lean, r)] = evs[r]._need[(Fr, 8, 8, evs[r]._policy, (r, world))]
+            return out
+        got = torch.cat(_run_ranks(world, rank_forward), dim=1)
+        err = log(f"ctx_sharded_world2_long_shards_lean{int(lean)}_vs_unsharded", got, want)
+        assert err < 2e-5 * max(1.0, float(want.abs().max())), (lean, err)
+    assert need[(True, 0)] < need[(False, 0)], need                  # the lean form needs less workspace
