@@ -49,6 +49,10 @@ class TShardComm:
         if world > 1 and (f0 != rank * F or Ttotal != world * F):
             raise ValueError("TShardComm expects equal contiguous shards: f0 == rank*F and Ttotal == world*F")
         self._bufs = {}
+        # long shards (the memory-lean form of an evaluation) do not keep the extended buffers between layers: cached per shape they pin
+        # 2.4 MB per frame at 256 x 256 (one (Fext*HW, C) buffer per level and width) -- half as much again as the evaluation itself
+        # needs (measured: 7.2 instead of 4.8 MB per own frame); short shards keep them (no allocation per layer and step)
+        self.keep_buffers = True
         self._win = 0                 # attention window of the exchanges (set by halo_begin / set_window)
         self.n_halo = self.n_allreduce = 0
         self.n_halo_edge_first = 0    # exchanges posted by the PRODUCER of the layer input (unet_forward._edge_first), own rows in place
@@ -162,6 +166,8 @@ class TShardComm:
         for w in hx.works:
             w.wait()          # NCCL/RCCL: the current stream waits for the transfer; gloo: the host does
         hx.works = []
+        if not self.keep_buffers:
+            self._bufs.clear()        # (hx.xe keeps the buffer alive until the layer that reads it has been enqueued)
 
     def halo_exchange(self, x: Tensor, HW: int, win: int) -> Tuple[Tensor, int]:
         """Blocking form: (xe, first own frame index in xe).  xe is a private copy (safe to keep), unlike halo_begin's."""
