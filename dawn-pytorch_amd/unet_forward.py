@@ -368,6 +368,7 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
             o.copy_(r[fa * HW:fb * HW])
         own, hx = _edge_first(ops, cs, F, H, W, P.dim, r, produce)
         x = _temporal(ops, P.init_tattn, own, F, H, W, cs, hx)
+        del own, hx, produce         # (a view of the extended buffer held to the end of the evaluation is one level-0 tensor at the peak)
     else:
         r = ops.init_conv_x(x3, P.w3, cs.fea_pre, F, H, W, P.dim)
         x = _temporal(ops, P.init_tattn, r, F, H, W, cs)
