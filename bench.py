@@ -213,7 +213,7 @@ def max_clip_frames(unet, diff, h, device, world, win=40, probes=(4800, 6400)):
             "probes": [{"frames": T, "peak_bytes": p} for T, p in pts],
             "method": "linear fit of the peak allocator bytes of one DDIM step at the two probe lengths (memory-lean long-clip path of clips "
                       "> 4096 frames: segmented fused temporal layers, qkv of the unfused levels per frame segment, heads' skip recomputed); "
-                      "proved by running: 62,000 frames with this host (max_split_size_mb:2048; 52,000 with the allocator's defaults), 58,000 through the C-side evaluator (profiles/r3_max_clip_length.log); largest T with "
+                      "proved by running: 62,000 frames with this host (no environment variable: the host switches the allocator's block splitting above 2 GiB off itself), 60,000 OWN frames of one interior rank of an 8-way T-shard (profiles/r4_max_clip_length.log), 58,000 through the C-side evaluator (profiles/r3_max_clip_length.log); largest T with "
                       "fixed + T*bytes_per_frame <= 0.97*HBM; T-sharded total = n_gpus*(per_gpu - 2*win halo frames)"}
 
 
