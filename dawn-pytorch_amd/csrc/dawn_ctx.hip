@@ -820,7 +820,13 @@ struct Eval {
         }
         A.free(film);
         if (gn_ticket) { A.free(gn_ticket); gn_ticket = nullptr; }
-        if (sk_ws) { A.free(sk_ws); sk_ws = nullptr; }
+        if (sk_ws) {
+            // the opt-in stream-K kernel reports a timed-out partial-tile hand-off through an error word in its scratch: read it
+            // before the scratch goes back to the arena (one stream synchronisation per evaluation -- in this opt-in mode only; the
+            // shipped policy never takes this branch), -30 as the Python host returns
+            if (!dry && rc == 0) { const int e = dawn_conv_sk_check(sk_ws, cur); if (e) rc = e; }
+            A.free(sk_ws); sk_ws = nullptr;
+        }
     }
 };
 

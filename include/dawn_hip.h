@@ -346,7 +346,8 @@ typedef struct dawn_named_ptr { const char* name; const void* ptr; } dawn_named_
 int dawn_ctx_create(const dawn_unet_cfg* cfg, const dawn_named_ptr* weights, int n_weights, dawn_ctx** out);
 void dawn_ctx_destroy(dawn_ctx* ctx);
 enum { DAWN_OPT_CONV_POLICY = 1, DAWN_OPT_TEMPORAL_FLAGS = 2, DAWN_OPT_OVERLAP = 3, DAWN_OPT_PROFILE = 4, DAWN_OPT_LONG_CLIP_FRAMES = 5 };
-/* tuning state lives in the ctx: conv policy bits (dawn_conv_desc.policy), temporal-layer kernel family, two-stream
+/* tuning state lives in the ctx: conv policy bits (dawn_conv_desc.policy; with the opt-in stream-K bit 0x400 every evaluation ends with one
+ * stream synchronisation that reads the kernel's error word: -30 from dawn_unet_forward / dawn_sampler_run), temporal-layer kernel family, two-stream
  * overlap on/off, per-launch HIP events around every dawn_conv_gemm (read with dawn_ctx_profile_read), the clip length above which an
  * evaluation runs in its memory-lean form (default 4096 frames: qkv tensors of the unfused attention levels per frame segment, the
  * heads' skip recomputed, the heads one after the other: 4.65 instead of 7.8 MB of workspace per frame at 256x256 for ~3 % of time;
