@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""GPU smoke of the T-shard path over RCCL: launch with torchrun, ranks share GPU 0 when only one is visible.
+"""GPU smoke of the T-shard path over RCCL: launch with torchrun on a box with at least WORLD_SIZE GPUs (RCCL refuses two ranks on one
+device: "Duplicate GPU detected", tried on the 1-GPU boxes of this build's pool in round 4 -- the multi-rank path is covered there by the
+in-process ranks of tests/test_hip_shard_fullsize.py and by the gloo tests on CPU).
 Checks that the sharded 2-rank result equals the single-rank result of the same clip (tiny model)."""
 import os, sys, datetime
 import numpy as np, torch, torch.distributed as dist
@@ -9,6 +11,8 @@ import dawn_pytorch_amd as D
 from dawn_pytorch_amd.tshard import TShardComm
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 ndev = torch.cuda.device_count()
+if ndev < world:
+    sys.exit(f"tshard_gpu_smoke: {world} ranks need {world} GPUs, {ndev} visible (RCCL refuses two ranks on one device)")
 dev = torch.device("cuda", rank % ndev)
 torch.cuda.set_device(dev)
 dist.init_process_group("nccl", timeout=datetime.timedelta(seconds=120), device_id=dev)
