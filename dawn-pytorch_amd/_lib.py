@@ -53,9 +53,6 @@ SIGNATURES = {
     "dawn_conv_gemm": [C.POINTER(ConvDesc), c_f],
     "dawn_conv_gemm_nblocks": [_l, _i],
     "dawn_conv3x3_wino_ok": [_i, _i, _i, _i, _i, _i],
-    "dawn_conv_sk_workspace_bytes": [],
-    "dawn_conv_sk_workspace_init": [c_f, c_f],
-    "dawn_conv_sk_check": [c_f, c_f],
     "dawn_gn_partial": [c_f, _l, _i, _i, c_f, _i, c_f],
     "dawn_gn_reduce": [c_f, _i, c_f, c_f],
     "dawn_gn_finalize": [c_f, _d, c_f, c_f, c_f, c_f, _i, _f, c_f, c_f, c_f],
@@ -117,7 +114,7 @@ class DawnHipError(RuntimeError):
     pass
 
 
-LONG_RESULT = {"dawn_sla_ws_floats", "dawn_conv_sk_workspace_bytes"}       # entry points that return a size (long), not a status
+LONG_RESULT = {"dawn_sla_ws_floats"}       # entry points that return a size (long), not a status
 
 
 def lib() -> C.CDLL:

@@ -30,7 +30,8 @@ namespace {
 // 3x3/s1/p1 convs whose tile geometry fits (+5..19 %, profiles/r1_l_conv_halo.txt), 0x1000 split-operand bf16
 // MFMA version of that kernel when the caller supplies w_bf3 (6 cross terms; 0x2000: all 9), 0x4000 its second
 // generation (conv3x3_bf16_v2_kernel: +5..20 %, profiles/r1_n_conv_bf16.txt), 0x10/0x20 fp32-kernel perf ablations,
-// (8 << 16) the s_memtime build of the split kernel, 0x400 the persistent stream-K 3x3 kernel (conv3x3_sk.hip) when the caller
+// (8 << 16) the s_memtime build of the split kernel, 0x400 -- ONLY in the experimental build of tools/build_sk_timing_lib.sh (-DDAWN_WITH_STREAMK; the
+// shipped library ignores the bit since round 4) -- the persistent stream-K 3x3 kernel (tools/ubench/conv3x3_sk.hip) when the caller
 // supplies dawn_conv_desc.sk_ws (0x200: without the half-tile offset between co-resident workgroups; 0x40 + bits 16..17: issue-priority
 // alternation between them; bits 20..23 there: leave n/16 of the resident slots to a concurrent stream).  NOT in the shipped
 // default: in isolation it takes 6..16 % off the 128..512-channel levels, inside the benchmark it is 3..5 % slower end to end --
@@ -2493,7 +2494,9 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 
 }  // namespace
 
-int dawn_conv3x3_sk_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows);   // conv3x3_sk.hip
+#ifdef DAWN_WITH_STREAMK
+int dawn_conv3x3_sk_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows);   // tools/ubench/conv3x3_sk.hip (experimental build)
+#endif
 int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows); // conv3x3_wino.hip
 
 #ifdef DAWN_ABLATION
@@ -2565,7 +2568,8 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
                 return 0;
             }
         }
-        if ((policy_of(d) & 0x400) && !nine && d.sk_ws) {   // persistent stream-K kernel (conv3x3_sk.hip)
+#ifdef DAWN_WITH_STREAMK
+        if ((policy_of(d) & 0x400) && !nine && d.sk_ws) {   // persistent stream-K kernel (experimental build only)
             int rows = 0;
             if (dawn_conv3x3_sk_try(d, M, policy_of(d), s, &rows)) {
                 if (d.gn_rows) *d.gn_rows = rows;
@@ -2573,6 +2577,7 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
                 return 0;
             }
         }
+#endif
         if (policy_of(d) & 0x4000) {           // v2 structure (row-of-taps weight stages, register-prefetched patch)
             // 256 x 128 tiles run one 8-wave workgroup per CU: when they occupy at most half of the 256 CUs (M = 12,800 rows,
             // N = 256: 100 tiles), 256 x 64 tiles put one 4-wave workgroup on twice as many CUs and the launch takes

@@ -271,9 +271,7 @@ struct Eval {
     const char* clip;
     ClipLayout L;
     int rc = 0;
-    void* sk_ws = nullptr;
     unsigned* gn_ticket = nullptr;           // zeroed device word of the convs' fused GroupNorm finalisation (one per evaluation)
-    size_t sk_bytes = 0;
     const dawn_shard_comm* sc = nullptr;     // T-shard exchanges (dawn_unet_forward_sharded) or nullptr = single GPU
     int Ftot = 0, f0g = 0;                   // clip length and first own frame, global
 
@@ -341,7 +339,6 @@ struct Eval {
             d.gn_eps = 1e-5f;
             d.gn_a = a.gn_a; d.gn_b = a.gn_b; d.gn_ticket = gn_ticket;
         }
-        if (sk_ws && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1) { d.sk_ws = sk_ws; d.sk_ws_bytes = sk_bytes; }
         if (dry || rc) { if (a.gn_rows) *a.gn_rows = 1; return; }
         const bool prof = c->prof_on;
         ProfEntry pe;
@@ -725,13 +722,6 @@ struct Eval {
     // ---- one evaluation: x3 (3,F,h,w) latent, t -> eps (3,F,h,w)   (unet_forward.unet_forward)
     void forward(const float* x3, float t, float* eps_out) {
         const int dim = c->cfg.dim;
-        // scratch of the persistent stream-K 3x3 kernel (partial-tile hand-offs); its flag header must start zeroed
-        if (c->conv_policy & 0x400) {           // (opt-in kernel: policy bit 0x400)
-            sk_bytes = dawn_conv_sk_workspace_bytes();
-            sk_ws = A.alloc(sk_bytes);
-            if (!sk_ws && rc == 0) rc = dawn_set_error_msg(-201, "dawn_ctx: activation workspace too small (dawn_workspace_bytes)");
-            if (sk_ws) LAUNCH(dawn_conv_sk_workspace_init(sk_ws, cur));
-        }
         gn_ticket = (unsigned*)falloc(4);
         if (gn_ticket && !dry && rc == 0) (void)hipMemsetAsync(gn_ticket, 0, 16, cur);
         // time_film: sinusoidal -> Linear -> GELU -> Linear -> [SiLU -> Linear] for every block in one GEMV
@@ -820,13 +810,6 @@ struct Eval {
         }
         A.free(film);
         if (gn_ticket) { A.free(gn_ticket); gn_ticket = nullptr; }
-        if (sk_ws) {
-            // the opt-in stream-K kernel reports a timed-out partial-tile hand-off through an error word in its scratch: read it
-            // before the scratch goes back to the arena (one stream synchronisation per evaluation -- in this opt-in mode only; the
-            // shipped policy never takes this branch), -30 as the Python host returns
-            if (!dry && rc == 0) { const int e = dawn_conv_sk_check(sk_ws, cur); if (e) rc = e; }
-            A.free(sk_ws); sk_ws = nullptr;
-        }
     }
 };
 

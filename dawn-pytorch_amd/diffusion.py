@@ -152,8 +152,6 @@ class GaussianDiffusion(nn.Module):
                                          use_graph=self.use_graph, eager_every=self.eager_every))
             traces.append(tr)
         self.last_trace = traces if trace else None
-        if hasattr(ops, "sk_check"):
-            ops.sk_check()          # error word of the stream-K conv kernel's partial-tile hand-offs (one sync per sample call)
         return torch.stack(outs, 0)
 
     def forward(self, *a, **k):

@@ -45,25 +45,13 @@ class HipOps:
         self.conv_policy = 0         # dawn_conv_desc.policy of every conv_gemm launch (0 = shipped kernel policy)
         self.temporal_flags = 0      # kernel-family selector of the fused temporal layer (0 = automatic; A/B and tests)
         self.temporal_attn_flags = 0  # dawn_temporal_attn_ex flags (1 = the fp32-MFMA attention core; A/B and tests)
-        self.stream_k = True         # supply the stream-K scratch when conv_policy selects that kernel (bit 0x400; opt-in)
+        self.sk_ws = None            # experimental library only (tools/build_sk_timing_lib.sh): scratch tensor handed to dawn_conv_desc.sk_ws
         self.fuse_h1 = True          # cross-attention kernels write h1 = SiLU(GN(c1)) + h_cond themselves (False: A/B, two-stream form)
-        self._sk_ws = {}             # (device index, stream) -> scratch of the stream-K 3x3 kernel (partial-tile hand-offs)
         self._sel_ws = {}            # (device index, stream) -> scratch of the threshold selection (histograms, state)
         self._tickets = {}           # (device index, stream) -> the zeroed device word of the convs' fused GroupNorm finalisation
         self.fuse_gn = True          # GroupNorm coefficients from the conv launch itself where the kernel can (False: A/B, separate launch)
         # (keyed by stream as well: the dicts are shared by every with_comm() copy, and two samplers on one device -- in-process
-        # ranks, concurrent clips -- run on different streams and must not share histograms / hand-off flags)
-
-    def sk_workspace(self, like: Tensor) -> Tensor:
-        """Scratch of the persistent stream-K 3x3 kernel (dawn_conv_desc.sk_ws): one per device, flag header zeroed once.
-        All 3x3 convs of an evaluation run on ONE stream (unet_forward), so one buffer per (device, stream) serves them all."""
-        key = (like.device.index, self._stream())
-        ws = self._sk_ws.get(key)
-        if ws is None:
-            ws = torch.empty(int(self.L.dawn_conv_sk_workspace_bytes()), device=like.device, dtype=torch.uint8)
-            check(self.L.dawn_conv_sk_workspace_init(_p(ws), self._stream()), "dawn_conv_sk_workspace_init")
-            self._sk_ws[key] = ws
-        return ws
+        # ranks, concurrent clips -- run on different streams and must not share histograms / hand-off tickets)
 
     def _gn_ticket(self, like: Tensor) -> Tensor:
         key = (like.device.index, self._stream())
@@ -71,11 +59,6 @@ class HipOps:
         if t is None:
             t = self._tickets[key] = torch.zeros(1, device=like.device, dtype=torch.int32)
         return t
-
-    def sk_check(self) -> None:
-        """Synchronising check of the stream-K kernel's error word (call once per clip, not per launch)."""
-        for ws in self._sk_ws.values():
-            check(self.L.dawn_conv_sk_check(_p(ws), self._stream()), "dawn_conv_sk_check")
 
     def with_comm(self, comm):
         o = HipOps(comm)
@@ -86,9 +69,8 @@ class HipOps:
         o.conv_policy = self.conv_policy
         o.temporal_flags = self.temporal_flags
         o.temporal_attn_flags = self.temporal_attn_flags
-        o.stream_k = self.stream_k
+        o.sk_ws = self.sk_ws
         o.fuse_h1 = self.fuse_h1
-        o._sk_ws = self._sk_ws
         o._sel_ws = self._sel_ws
         o._tickets = self._tickets
         o.fuse_gn = self.fuse_gn
@@ -171,9 +153,8 @@ class HipOps:
         d.w_wino = _p(w_wino)
         d.policy = self.conv_policy
         d.ln_eps = ln_eps
-        if self.stream_k and (self.conv_policy & 0x400) and w_bf3 is not None and KH == 3 and KW == 3 and stride == 1 and mode == 0:
-            ws = self.sk_workspace(in0)
-            d.sk_ws, d.sk_ws_bytes = _p(ws), ws.numel()
+        if self.sk_ws is not None and w_bf3 is not None and KH == 3 and KW == 3 and stride == 1 and mode == 0:
+            d.sk_ws, d.sk_ws_bytes = _p(self.sk_ws), self.sk_ws.numel()        # (ignored by the shipped library)
         nrows = C.c_int(0)
         fin_ab = None
         if gn_part is not None:

@@ -62,10 +62,10 @@ typedef struct dawn_conv_desc {
                                                       GEMM itself -- no statistics pass (instead of row_mean / row_rstd).  <= 128 channels: from the
                                                       rows it holds in registers; deeper narrow projections: one shifted one-pass statistics sweep
                                                       per row panel before its K loop.  Only shapes with dawn_gemm1x1_ln_inline_ok, error otherwise */
-    void* sk_ws; size_t sk_ws_bytes;               /* optional scratch of dawn_conv_sk_workspace_bytes() bytes, zeroed once with dawn_conv_sk_workspace_init:
-                                                      3x3 convs with w_bf3 and policy bit 0x400 (not in the shipped default) then run on the persistent stream-K kernel, which hands
-                                                      partial tiles between workgroups through it.  One workspace per concurrently running launch;
-                                                      NULL = the one-tile-per-workgroup kernels */
+    void* sk_ws; size_t sk_ws_bytes;               /* RESERVED, leave NULL / 0 (kept for the struct layout).  Round 3: hand-off scratch of a persistent stream-K
+                                                      form of the 3x3 kernel -- faster in isolation, slower end to end on a power-limited chip; since round 4 that
+                                                      kernel lives in tools/ubench/conv3x3_sk.hip and exists only in the experimental library of
+                                                      tools/build_sk_timing_lib.sh.  The shipped library ignores both fields */
     const void* w_wino;                            /* optional (3x3/s1/p1 convs): the Winograd F(2x2,3x3) image of the weights, U = G g G^T computed in
                                                       fp64 and split into three bf16 planes, in the fragment order of conv3x3_wino_kernel:
                                                       [(C0+C1)/16][16 positions][N/16][2][64 lanes][8] (pack.pack_wino_bf3).  With policy bit
@@ -88,17 +88,11 @@ int dawn_conv3x3_wino_ok(int F, int H, int W, int C0, int C1, int N);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;
  * the launch reports the exact count through dawn_conv_desc.gn_rows */
 int dawn_conv_gemm_nblocks(long M, int N);
-/* scratch of the persistent stream-K 3x3 kernel (dawn_conv_desc.sk_ws): size; one-time zeroing of its flag header; and a
- * SYNCHRONISING check of its error word (a partial-tile hand-off that timed out: cannot happen while the grid fits the
- * device -- the bounded spin exists so that a violated assumption is an error code, not a hung GPU) */
-size_t dawn_conv_sk_workspace_bytes(void);
-int dawn_conv_sk_workspace_init(void* ws, void* stream);
-int dawn_conv_sk_check(const void* ws, void* stream);
 /* dawn_conv_desc.policy bits (0 = shipped policy 0x300580D; per call, no process-global state): bit0 BK=32 tiles,
  * bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel,
  * 0x1000 split-operand (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000
  * second-generation split 3x3 kernel, 0x1000000 that kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction: less energy per
- * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops), 0x400 its persistent stream-K variant (opt-in; needs dawn_conv_desc.sk_ws).  Every combination computes the same function (tests run the kernel families
+ * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops); 0x400 is ignored (round 3's opt-in stream-K variant: experimental builds only).  Every combination computes the same function (tests run the kernel families
  * against each other); perf-ablation / s_memtime builds exist only under -DDAWN_ABLATION (tools/build_timing_lib.sh). */
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --
@@ -346,8 +340,7 @@ typedef struct dawn_named_ptr { const char* name; const void* ptr; } dawn_named_
 int dawn_ctx_create(const dawn_unet_cfg* cfg, const dawn_named_ptr* weights, int n_weights, dawn_ctx** out);
 void dawn_ctx_destroy(dawn_ctx* ctx);
 enum { DAWN_OPT_CONV_POLICY = 1, DAWN_OPT_TEMPORAL_FLAGS = 2, DAWN_OPT_OVERLAP = 3, DAWN_OPT_PROFILE = 4, DAWN_OPT_LONG_CLIP_FRAMES = 5 };
-/* tuning state lives in the ctx: conv policy bits (dawn_conv_desc.policy; with the opt-in stream-K bit 0x400 every evaluation ends with one
- * stream synchronisation that reads the kernel's error word: -30 from dawn_unet_forward / dawn_sampler_run), temporal-layer kernel family, two-stream
+/* tuning state lives in the ctx: conv policy bits (dawn_conv_desc.policy), temporal-layer kernel family, two-stream
  * overlap on/off, per-launch HIP events around every dawn_conv_gemm (read with dawn_ctx_profile_read), the clip length above which an
  * evaluation runs in its memory-lean form (default 4096 frames: qkv tensors of the unfused attention levels per frame segment, the
  * heads' skip recomputed, the heads one after the other: 4.65 instead of 7.8 MB of workspace per frame at 256x256 for ~3 % of time;

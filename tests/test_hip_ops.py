@@ -130,71 +130,6 @@ def _conv_case(hip, name, in0, in1, w, N, kw, want):
     check("conv_gemm/" + name, got, want)
 
 
-SK_CASES = [
-    # name, F, H, W, C0, C1, N, extras, leave (policy bits 20..23: grid = (16 - leave)/16 of the resident slots)
-    ("L0_64x64_18units", 9, 64, 64, 64, 0, 64, {"bias": True, "gn": True}, 15),           # 4.5 tiles per workgroup
-    ("L0_cat_N128_cut_tiles", 3, 64, 64, 64, 64, 128, {"bias": True}, 14),                # two sources, 2 n-tiles, 1.5 tiles each
-    ("L1_32x32_res", 5, 32, 32, 32, 0, 64, {"res": True}, 15),                            # 1.25 units each
-    ("L2_16x16_N192_tr", 7, 16, 16, 128, 0, 192, {"tr": True, "bias": True}, 15),
-    ("L2_16x16_N256_gn", 7, 16, 16, 64, 0, 256, {"bias": True, "gn": True}, 15),
-    ("L3_8x8_deepK_many_parts", 12, 8, 8, 256, 256, 64, {"bias": True, "gn": True}, 15),  # a tile spans ~10 workgroups
-    ("decoder_W128_column_tiles", 2, 16, 128, 48, 0, 64, {"res": True, "gn": True}, 15),
-    ("L0_full_grid_2units", 16, 64, 64, 64, 0, 64, {"bias": True, "gn": True}, 0),        # 512 workgroups, every tile cut
-    ("L0_full_grid_5units", 40, 64, 64, 64, 0, 64, {"bias": True, "gn": True}, 0),
-    ("L1_full_grid_N128", 24, 32, 32, 128, 0, 128, {"bias": True, "gn": True}, 0),
-    ("L3_full_grid_N512", 32, 8, 8, 256, 0, 512, {"bias": True}, 0),
-    ("one_unit_per_workgroup", 1, 16, 16, 64, 0, 64, {"bias": True, "gn": True}, 0),      # U = 4 < resident slots
-]
-
-
-@pytest.mark.parametrize("case", SK_CASES, ids=[c[0] for c in SK_CASES])
-def test_conv3x3_stream_k(hip, ref, case):
-    """Persistent stream-K 3x3 kernel (conv3x3_sk.hip): == the torch conv, == the one-tile-per-workgroup kernel to fp32
-    rounding, bit-deterministic, GroupNorm sums == a statistics pass, no hand-off left pending (flags back to zero)."""
-    from dawn_pytorch_amd.pack import pack_bf3, unpack_kn
-    name, F, H, W, C0, C1, N, ex, leave = case
-    rows = F * H * W
-    in0 = rnd(rows, C0, seed=1)
-    in1 = rnd(rows, C1, seed=2) if C1 else None
-    w = packw(9 * (C0 + C1), N, seed=3)
-    kw = dict(F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1)
-    if ex.get("bias"):
-        kw["bias"] = rnd(N, seed=4)
-    if ex.get("res"):
-        kw["res"] = rnd(rows, N, seed=8)
-    if ex.get("tr"):
-        kw["tr"] = (rnd(rows, N, seed=9), rnd(N, seed=10) * 0.3 + 1.0, rnd(N, seed=11) * 0.3)
-    want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
-    gkw = {k_: (tuple(t.cuda() for t in v) if isinstance(v, tuple) else (v.cuda() if torch.is_tensor(v) else v)) for k_, v in kw.items()}
-    gkw["w_bf3"] = pack_bf3(unpack_kn(w)).cuda()
-    x0g, x1g, wg = in0.cuda(), None if in1 is None else in1.cuda(), w.cuda()
-    try:
-        outs = []
-        for variant in (0x5C0D | (leave << 20), 0x5C0D | 0x200 | (leave << 20), 0x580D, 0x580D | 0x1000000):   # stream-K, without the pair offset, v2, v2 on 16x16x32
-            hip.conv_policy = variant
-            part = hip.conv_gn_part(rows, N, x0g) if ex.get("gn") else None
-            got = hip.conv_gemm(x0g, wg, N, in1=x1g, gn_part=part, **gkw)
-            torch.cuda.synchronize()
-            check(f"conv3x3_sk/{name}/v{variant:#x}", got, want)
-            outs.append(got)
-            if part is not None:
-                gamma, beta = rnd(N, seed=14).cuda() * 0.2 + 1, rnd(N, seed=15).cuda() * 0.2
-                a1, b1 = hip.gn_coeffs(got, gamma, beta, None, rows, part=part)
-                a2, b2 = hip.gn_coeffs(got, gamma, beta, None, rows)
-                check(f"conv3x3_sk/{name}/gn_a/v{variant:#x}", a1, a2, 1e-5)
-                check(f"conv3x3_sk/{name}/gn_b/v{variant:#x}", b1, b2, 1e-5)
-        hip.conv_policy = 0x5C0D | (leave << 20)
-        again = hip.conv_gemm(x0g, wg, N, in1=x1g, **gkw)
-        assert torch.equal(again, outs[0])                                    # fixed summation order
-        scale = max(1.0, float(want.abs().max()))
-        assert float((outs[0] - outs[2]).abs().max()) <= 2e-5 * scale         # vs the v2 kernel: fp32 rounding only
-        assert float((outs[3] - outs[2]).abs().max()) <= 2e-5 * scale         # the 16x16x32 form of the v2 kernel: likewise
-        hip.sk_check()
-        ws = hip.sk_workspace(x0g)
-        assert int(ws[:4096].view(torch.int32).abs().sum()) == 0              # every published partial was consumed
-    finally:
-        hip.conv_policy = 0
-
 # ---------------------------------------------------------------------------------------------- Winograd F(2x2,3x3) split conv
 WINO = 0x580D | 0x1000000 | 0x2000000              # shipped policy + the Winograd form where w_wino is supplied
 WINO_CASES = [

@@ -32,6 +32,11 @@ w, ws = pack_kn(w_kn).cuda(), pack_bf3(w_kn).cuda()
 dbg = torch.zeros(1024 * 64, dtype=torch.int64, device="cuda")
 ops.L.dawn_conv_sk_set_debug.argtypes = [ctypes.c_void_p]
 assert ops.L.dawn_conv_sk_set_debug(dbg.data_ptr()) == 0
+# hand-off scratch of the stream-K kernel (experimental library only: the shipped one has neither these entry points nor the kernel)
+ops.L.dawn_conv_sk_workspace_bytes.restype = ctypes.c_size_t
+ops.L.dawn_conv_sk_workspace_init.argtypes = [ctypes.c_void_p, ctypes.c_void_p]
+ops.sk_ws = torch.empty(int(ops.L.dawn_conv_sk_workspace_bytes()), dtype=torch.uint8, device="cuda")
+assert ops.L.dawn_conv_sk_workspace_init(ops.sk_ws.data_ptr(), torch.cuda.current_stream().cuda_stream) == 0
 part = ops.conv_gn_part(rows, N, x0)
 ops.conv_policy = a.policy | (a.leave << 20)
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

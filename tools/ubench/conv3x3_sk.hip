@@ -18,8 +18,13 @@
 //   * the tile geometry (TR, WT, NF) is a template parameter: every LDS address is a register base + immediate;
 //   * GroupNorm(8) partial sums: wave-level DPP reduction per finished tile, fp64 accumulation per workgroup, ONE gn_part row
 //     per workgroup.
-#include "dawn_common.h"
+#include "../../dawn-pytorch_amd/csrc/dawn_common.h"
 #include "../../include/dawn_hip.h"
+// (round 4: not part of the shipped library any more -- built into the experimental library by tools/build_sk_timing_lib.sh, which
+//  compiles conv_gemm.hip with -DDAWN_WITH_STREAMK so that policy bit 0x400 + dawn_conv_desc.sk_ws reach dawn_conv3x3_sk_try)
+extern "C" size_t dawn_conv_sk_workspace_bytes(void);
+extern "C" int dawn_conv_sk_workspace_init(void* ws, void* stream);
+extern "C" int dawn_conv_sk_check(const void* ws, void* stream);
 
 namespace {
 
