@@ -380,7 +380,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (no VMEM wait: patch pieces and w0 stay in flight)
             __builtin_amdgcn_s_barrier();
             WSTAMP();   // ... barrier passed
-            load_w(nn0, ncc, 0, 1, w1);
+            // (behind a tile's last chunk this fetch waits until the epilogue is over: the epilogue begins with a full VMEM drain -- a
+            //  spilled register comes back from scratch there -- and would sit out this request's L2 round trip; its 16 registers are
+            //  free for the epilogue meanwhile)
+            if (!last) load_w(nn0, ncc, 0, 1, w1);
         }
 
         // ---- epilogue of the tile.  Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  nu half in registers: Z[zb] over this wave's 4 column
@@ -483,6 +486,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             for (int j = 0; j < 4; ++j)
 #pragma unroll
                 for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+        load_w(nxt.n0, has_next ? 0 : nC, 0, 1, w1);       // the next tile's second position of phase A (needed from its tile block 4 on)
         cur = nxt;
         setup(tile + 2 * G < t_end ? tile + 2 * G : tile, tile + 2 * G < t_end, nxt);
     }
