@@ -954,6 +954,13 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
         }
         }
         if (h < 2) TSTAMP();   // K/V projected (before barrier)
+        // the 12 weight fragments of this head's Q projection are requested BEFORE the barrier (into the registers the K / V fragments just
+        // left): their L2 round trip passes while the wave waits for the others instead of in front of its first Q MFMA (-0.9 % on the
+        // layer, bit-identical: profiles/r4_temporal_issue_priority_ab.txt).  The same for the K / V fragments -- requested once per head
+        // instead of once per item, or ahead across the closing barrier -- costs 41..125 spilled registers (251 of 256 are in use): not done
+        KVWeights qw;
+        if constexpr (!EXT)
+            if (has_q) kv_weights_request<false>(rsw, wvoff, h * DH, qw);
         __syncthreads();
         if (h < 2) TSTAMP();   // barrier passed
         if constexpr (EXT)
@@ -977,7 +984,7 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
                         for (int e = 0; e < 4; ++e) qT[4 * c + e] = qreg[4 * c + e];
                     }
                 } else {
-                    qT = proj_Q_split(rsw, wvoff, h * DH, Xp + ((size_t)half * FA + iqc) * 16, FA);
+                    qT = proj_pass<false>(qw, Xp + ((size_t)half * FA + iqc) * 16, FA);
                 }
 #pragma unroll
                 for (int kc = 0; kc < 2; ++kc) {
