@@ -103,6 +103,23 @@ def cpu_baseline(h, S, sample_frames, unet_cpu_sd):
                       f"{warm:.1f} s); the {S} DDIM steps of a clip repeat that evaluation: frames/s = {Ts} / ({S} x {dt:.1f} s)"}
 
 
+class stdout_to_stderr:
+    """File-descriptor-level redirection of stdout to stderr: RCCL prints its version banner with printf on fd 1 when a communicator
+    is created, and bench.py's stdout carries exactly ONE JSON line."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+        return self
+
+    def __exit__(self, *exc):
+        sys.stdout.flush()
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+        return False
+
+
 def power_ceiling(ops, device, iters=20000):
     """Sustained executed TFLOP/s of an MFMA-only bf16 loop on this box under its power budget (dawn_ubench_mfma_bf16): operands =
     the three split planes of N(0,1) values, from registers and re-read from LDS at the conv kernels' ratio; zeros for contrast."""
@@ -132,7 +149,7 @@ def power_ceiling(ops, device, iters=20000):
     return out
 
 
-def shard_sim(unet, diff, T, h, device, single_ms, world=8, rank=3, rccl=False):
+def shard_sim(unet, diff, T, h, device, single_ms, world=8, rank=3, rccl=True):
     """OUTSIDE the timed region, one GPU: the workload of ONE interior rank of a T-sharded clip (BASELINE configs[3]:
     8 x 200 frames) -- 200 own frames, 2 x 40 halo frames at every temporal attention (filled locally), GroupNorm statistics on the
     reduce -> all-reduce -> finalize path, histogram all-reduces of the threshold selection (world-size-1 RCCL communicator when it
@@ -149,29 +166,44 @@ def shard_sim(unet, diff, T, h, device, single_ms, world=8, rank=3, rccl=False):
             f = tempfile.NamedTemporaryFile(prefix="dawn_pg_", delete=True)
             name = f.name
             f.close()
-            dist_mod.init_process_group("nccl", init_method=f"file://{name}", rank=0, world_size=1, device_id=device)
-            pg = True
-    except Exception:                                         # noqa: BLE001
+            with stdout_to_stderr():                          # (RCCL's banner goes to stderr, not into the JSON line's stream)
+                dist_mod.init_process_group("nccl", init_method=f"file://{name}", rank=0, world_size=1, device_id=device)
+                pg = True
+                warm = torch.zeros(16, device=device, dtype=torch.float64)
+                dist_mod.all_reduce(warm)                     # communicator created here, inside the redirection
+                torch.cuda.synchronize()
+    except Exception as e:                                    # noqa: BLE001
+        why = f"{type(e).__name__}: {str(e)[:120]}"
         dist_mod = None
+    else:
+        why = "RCCL not requested" if dist_mod is None else None
     try:
-        comm = SimulatedInteriorShard(T, world=world, rank=rank, dist=dist_mod)
-        fea, bbox, cond = synthetic_inputs(T, h, device, seed=123, f0=rank * T, Ttotal=world * T)
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
-        diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)          # warm-up (buffers, RCCL)
-        ev[0].record()
-        for i in range(2):
-            out = diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)
-            ev[i + 1].record()
-        torch.cuda.synchronize()
-        assert torch.isfinite(out).all()
-        ms = min(ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]))
-        st = comm.stats()
+        with stdout_to_stderr():
+            comm = SimulatedInteriorShard(T, world=world, rank=rank, dist=dist_mod)
+            fea, bbox, cond = synthetic_inputs(T, h, device, seed=123, f0=rank * T, Ttotal=world * T)
+            ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)          # warm-up (buffers, RCCL)
+            ev[0].record()
+            for i in range(2):
+                out = diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)
+                ev[i + 1].record()
+            torch.cuda.synchronize()
+            assert torch.isfinite(out).all()
+            ms = min(ev[0].elapsed_time(ev[1]), ev[1].elapsed_time(ev[2]))
+            st = comm.stats()
+            # one more clip with the waits timed (HIP events around every all-reduce: what the 2,200 dependent launches cost the stream)
+            comm.timing = True
+            diff.sample(fea, bbox, cond=cond, cond_scale=1.0, comm=comm)
+            tm = comm.timing_ms()
     finally:
         if pg:
-            dist_mod.destroy_process_group()
+            with stdout_to_stderr():
+                dist_mod.destroy_process_group()
     return {"ms_per_clip": ms, "single_gpu_ms_per_clip": single_ms, "shard_overhead": ms / single_ms,
             "rank": f"{rank} of {world} (interior: a neighbour on both sides)", "frames_per_rank": T,
-            "all_reduces": "world-size-1 RCCL" if dist_mod is not None else "skipped (no communicator)",
+            "all_reduces": "world-size-1 RCCL communicator (launch + latency real, payload trivial)" if dist_mod is not None
+                           else f"skipped (no communicator: {why})",
+            "allreduce_ms_per_clip": tm["allreduce_ms"], "allreduces_timed": tm["allreduces_timed"],
             "halo_exchanges_per_clip": st["halo_exchanges"] // 3, "all_reduces_per_clip": st["all_reduces"] // 3,
             "what": "one interior rank's compute of a T-sharded clip on one GPU (halos filled locally; link time not included) vs "
                     "the unsharded clip of the same length"}
@@ -254,9 +286,21 @@ def other_configs(unet, device, S, which=((128, 400, 3, "BASELINE configs[1]: 12
 class LaunchError(SystemExit):
     """bench.py refuses to run rather than report a GPU count it did not use (exit code 2, message on stderr)."""
 
-    def __init__(self, msg):
+    def __init__(self, msg, code=2):
         print(f"bench.py: {msg}", file=sys.stderr, flush=True)
-        super().__init__(2)
+        super().__init__(code)
+
+
+def resolve_mode(requested: str, preflight_ok: bool, allow_fallback: bool) -> str:
+    """The parallelism a multi-GPU run reports.  A T-shard request whose preflight failed on any rank is an ERROR (exit code 3): a
+    scaling run that asked for `--mode tshard` must not exit 0 with a replica-mode number.  Only `--allow-fallback` turns it into
+    replica mode (then visible as comm.mode != comm.mode_requested and in config.parallelism)."""
+    if requested != "tshard" or preflight_ok:
+        return requested
+    if allow_fallback:
+        return "replica"
+    raise LaunchError("--mode tshard requested but the T-shard preflight failed on at least one rank (see the ranks' stderr); refusing to "
+                      "report a replica-mode number for it -- pass --allow-fallback or --mode replica", code=3)
 
 
 def launch_plan(gpus: int, env, device_count: int, argv):
@@ -294,9 +338,9 @@ def device_identity(device) -> str:
     return f"index:{torch.cuda.current_device()}"
 
 
-def tshard_preflight(dist, rank, world, device) -> bool:
-    """Tiny T-sharded sample over RCCL (halo send/recv + fp64 / int32 all-reduces).  Any failure on any rank
-    makes every rank fall back to replica mode instead of losing the whole scaling run."""
+def tshard_preflight(dist, rank, world, device, groups=(None, None)) -> bool:
+    """Tiny T-sharded sample over RCCL (halo send/recv + fp64 / int32 all-reduces on the two process groups the run will use).
+    False when it failed on ANY rank: main() then exits with code 3 (or, with --allow-fallback, runs replica mode and says so)."""
     ok = 1
     try:
         import dawn_pytorch_amd as D
@@ -310,7 +354,8 @@ def tshard_preflight(dist, rank, world, device) -> bool:
         g = torch.Generator().manual_seed(1)
         fea, bbox = torch.randn(1, 28, h, h, generator=g).to(device), torch.randn(1, 4, h, h, generator=g).to(device)
         cond = torch.randn(1, F * world, 40, generator=g)[:, rank * F:(rank + 1) * F].contiguous().to(device)
-        out = diff.sample(fea, bbox, cond=cond, comm=TShardComm(dist, rank, world, F * world, rank * F, F))
+        out = diff.sample(fea, bbox, cond=cond, comm=TShardComm(dist, rank, world, F * world, rank * F, F, group=groups[0],
+                                                                reduce_group=groups[1]))
         torch.cuda.synchronize()
         ok = int(bool(torch.isfinite(out).all()))
     except Exception as e:                                    # noqa: BLE001
@@ -339,9 +384,12 @@ def main():
     ap.add_argument("--no-max-clip", action="store_true", help="skip the max-clip-length probes")
     ap.add_argument("--no-kernel-events", action="store_true")
     ap.add_argument("--no-decode", action="store_true", help="skip the (untimed) flow-decode report")
-    ap.add_argument("--shard-sim-rccl", action="store_true",
-                    help="shard_sim: run its all-reduces on a world-size-1 RCCL communicator (RCCL prints a banner on stdout at "
-                         "init, so this is opt-in; default: the all-reduces are skipped)")
+    ap.add_argument("--no-shard-sim-rccl", action="store_true",
+                    help="shard_sim: skip its all-reduces (default: they run on a world-size-1 RCCL communicator -- 2,200 dependent "
+                         "launches per clip, so that shard_overhead includes them; RCCL's banner is redirected to stderr)")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1, --mode tshard: when the T-shard preflight fails on any rank, fall back to replica mode (reported in "
+                         "config.parallelism and comm.mode) instead of exiting with code 3")
     ap.add_argument("--no-other-configs", action="store_true",
                     help="skip the (untimed) runs of BASELINE configs[1] and of the unsharded 1600-frame clip reported as `other_configs`")
     ap.add_argument("--no-shard-sim", action="store_true",
@@ -388,7 +436,11 @@ def main():
     if world > 1 or os.environ.get("DAWN_FORCE_DIST") == "1":
         import datetime
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
+        with stdout_to_stderr():                               # (RCCL's banner: stdout carries the JSON line only)
+            dist.init_process_group("nccl", device_id=device, timeout=datetime.timedelta(seconds=300))
+            _w = torch.zeros(1, device=device)
+            dist.all_reduce(_w)                                # communicator created inside the redirection
+            torch.cuda.synchronize()
         # the rank count RCCL actually formed, and the physical devices behind it (never trusted from the environment)
         ranks_seen = dist.get_world_size()
         ids = [None] * ranks_seen
@@ -403,12 +455,22 @@ def main():
     Ttotal, f0 = T, 0
     if dist is not None:
         mode = args.mode
-        if mode == "tshard" and not tshard_preflight(dist, rank, world, device):
-            mode = "replica"            # reported honestly in config.parallelism
+        mode_requested = mode
+        groups = (None, None)
         if mode == "tshard":
             from dawn_pytorch_amd.tshard import TShardComm
+            # halo P2P on one process group, the tiny all-reduces on another: two RCCL communicators = two streams, so a 128-byte
+            # GroupNorm all-reduce does not queue behind a 186 MB halo transfer in flight (tshard.TShardComm)
+            groups = TShardComm.two_groups(dist)
+        if mode == "tshard":
+            try:
+                mode = resolve_mode(mode, tshard_preflight(dist, rank, world, device, groups), args.allow_fallback)
+            except LaunchError:
+                dist.destroy_process_group()
+                raise
+        if mode == "tshard":
             Ttotal, f0 = T * world, T * rank
-            comm = TShardComm(dist, rank, world, Ttotal, f0, T)
+            comm = TShardComm(dist, rank, world, Ttotal, f0, T, group=groups[0], reduce_group=groups[1])
     unet, diff = build_model(T, h, S, device)
     diff.noise_seed = 1234 + (rank if mode == "replica" else 0)
     fea, bbox, cond = synthetic_inputs(T, h, device, seed=123 + (rank if mode == "replica" else 0), f0=f0,
@@ -459,9 +521,24 @@ def main():
 
     per_rank = None
     if dist is not None:
+        waits = {}
+        if comm is not None:
+            # OUTSIDE the timed region: one more clip with HIP events around every halo_end and every all-reduce -- how long this
+            # rank's compute stream waited for the neighbours' frames (0 when the transfer hid behind the producer) and what the
+            # dependent all-reduces cost it, so that the first SCALE line explains itself
+            keep = {k_: getattr(comm, k_) for k_ in ("n_halo", "n_halo_edge_first", "n_allreduce", "halo_bytes_sent", "halo_bytes_recv",
+                                                     "allreduce_bytes")}
+            comm.timing = True
+            one_clip()
+            tm = comm.timing_ms()
+            comm.timing = False
+            for k_, v_ in keep.items():                      # (the counters keep describing the warm-up + timed clips only)
+                setattr(comm, k_, v_)
+            waits = {"halo_wait_ms_per_clip": tm["halo_wait_ms"], "allreduce_ms_per_clip": tm["allreduce_ms"],
+                     "halo_waits_timed": tm["halo_waits"], "allreduces_timed": tm["allreduces_timed"]}
         per_rank = [None] * ranks_seen
         dist.all_gather_object(per_rank, dict(comm.stats() if comm is not None else {"rank": rank, "world": ranks_seen},
-                                              device=device_identity(device), ms_per_clip=clip_ms[len(clip_ms) // 2]))
+                                              device=device_identity(device), ms_per_clip=clip_ms[len(clip_ms) // 2], **waits))
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -617,7 +694,7 @@ def main():
                                  "sampler_plus_decode_frames_per_s": T / (dt / args.steps + td)}
     if n_gpus == 1 and mode == "single" and not args.no_shard_sim and not diff.use_ctx:
         try:
-            result["shard_sim"] = shard_sim(unet, diff, T, h, device, clip_ms[len(clip_ms) // 2], rccl=args.shard_sim_rccl)
+            result["shard_sim"] = shard_sim(unet, diff, T, h, device, clip_ms[len(clip_ms) // 2], rccl=not args.no_shard_sim_rccl)
         except Exception as e:                                # noqa: BLE001  (a report, never the metric)
             result["shard_sim"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     if n_gpus == 1 and mode == "single" and not args.no_other_configs and (args.res, T, S) == (256, 200, 50):
@@ -630,6 +707,8 @@ def main():
             result["max_clip_frames"] = {"error": f"{type(e).__name__}: {str(e)[:200]}"}
     if dist is not None:
         result["comm"] = {"backend": "nccl (RCCL)", "world": ranks_seen, "distinct_devices": devices_seen, "mode": mode,
+                          "mode_requested": mode_requested,
+                          "process_groups": "halo P2P and all-reduces on separate groups" if comm is not None and comm.reduce_group is not comm.group else "one group",
                           **(comm.stats() if comm is not None else {"halo_exchanges": 0, "all_reduces": 0,
                                                                    "note": "replica mode: no data-path collective"}),
                           "per_rank": per_rank}

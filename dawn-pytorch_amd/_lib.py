@@ -57,6 +57,7 @@ SIGNATURES = {
     "dawn_gn_reduce": [c_f, _i, c_f, c_f],
     "dawn_gn_finalize": [c_f, _d, c_f, c_f, c_f, c_f, _i, _f, c_f, c_f, c_f],
     "dawn_gn_reduce_finalize": [c_f, _i, _d, c_f, c_f, c_f, c_f, _i, _f, c_f, c_f, c_f],
+    "dawn_gn_ticket_reset": [c_f, c_f],
     "dawn_gn_apply_res": [c_f, c_f, c_f, c_f, c_f, _l, _i, c_f],
     "dawn_ln_rowstats": [c_f, _i, _i, c_f, _i, _i, _l, _f, c_f, c_f, c_f],
     "dawn_ln_rows": [c_f, _i, _i, c_f, _i, _i, _l, _f, c_f, c_f],

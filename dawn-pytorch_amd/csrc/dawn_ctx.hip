@@ -723,7 +723,9 @@ struct Eval {
     void forward(const float* x3, float t, float* eps_out) {
         const int dim = c->cfg.dim;
         gn_ticket = (unsigned*)falloc(4);
-        if (gn_ticket && !dry && rc == 0) (void)hipMemsetAsync(gn_ticket, 0, 16, cur);
+        // (a non-zero ticket means the last workgroup of a conv never sees itself as last: gn_a / gn_b would stay unwritten -- a failed
+        //  fill is an error of the evaluation, not something to continue from)
+        if (gn_ticket) LAUNCH(dawn_gn_ticket_reset(gn_ticket, cur));
         // time_film: sinusoidal -> Linear -> GELU -> Linear -> [SiLU -> Linear] for every block in one GEMV
         float* e0 = falloc(dim);
         float* e1 = falloc(c->time_dim);

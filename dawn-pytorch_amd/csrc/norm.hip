@@ -297,3 +297,12 @@ extern "C" int dawn_ln_rows(const float* in0, int C0, int ld0, const float* in1,
                             float* xn, void* stream) {
     return ln_launch(in0, C0, ld0, in1, C1, ld1, rows, eps, nullptr, nullptr, xn, stream);
 }
+
+/* the hand-off word of the conv launches' fused GroupNorm finalisation (dawn_conv_desc.gn_ticket): 16 bytes, zero before the first
+ * conv launch of an evaluation.  A stream-ordered fill (graph-capturable as a memset node). */
+extern "C" int dawn_gn_ticket_reset(unsigned* ticket, void* stream) {
+    if (!ticket) return dawn_set_error_msg(-15, "dawn_gn_ticket_reset: NULL ticket");
+    const hipError_t e = hipMemsetAsync(ticket, 0, 16, (hipStream_t)stream);
+    if (e != hipSuccess) return dawn_set_error(e, __FILE__, __LINE__);
+    return 0;
+}

@@ -17,21 +17,39 @@ Tensor = torch.Tensor
 
 
 _ALLOC_SET = False
+ALLOC_ENV = ("PYTORCH_HIP_ALLOC_CONF", "PYTORCH_CUDA_ALLOC_CONF", "PYTORCH_ALLOC_CONF")
 
 
-def _long_clip_allocator(T: int, like: Tensor) -> None:
+def _long_clip_allocator(T: int, like: Tensor, environ=None) -> Optional[str]:
     """Long clips (the memory-lean form, unet_forward.LONG_CLIP_FRAMES) allocate tensors of many GB each: PyTorch's caching
     allocator then must not split its large blocks, or 20 % of HBM ends up reserved but unusable (56,000 frames failed with 55 GiB
-    in fragments, profiles/r3_max_clip_length.log).  Set here, once, instead of asking the caller for PYTORCH_HIP_ALLOC_CONF."""
+    in fragments, profiles/r3_max_clip_length.log).  Applied here, ONCE per process, and ONLY when the user configured nothing:
+    the setting is process-global and permanent, and the allocator's parser resets every option the string does not name -- so a
+    caller who set PYTORCH_HIP_ALLOC_CONF / PYTORCH_CUDA_ALLOC_CONF / PYTORCH_ALLOC_CONF keeps exactly what they asked for (and
+    should add `max_split_size_mb:2048` there themselves for clips this long: INTEGRATION.md).  Returns what was done (also
+    logged once through `warnings`): "applied", "kept user configuration", "unavailable: ..." or None when nothing was needed."""
     global _ALLOC_SET
+    import os
+    import warnings
     from .unet_forward import LONG_CLIP_FRAMES
     if _ALLOC_SET or T <= LONG_CLIP_FRAMES or not like.is_cuda:
-        return
+        return None
     _ALLOC_SET = True
+    env = os.environ if environ is None else environ
+    user = [k for k in ALLOC_ENV if env.get(k)]
+    if user:
+        warnings.warn(f"dawn_pytorch_amd: {T}-frame clip, caching-allocator configuration left as set by {user[0]} "
+                      f"(add max_split_size_mb:2048 there for clips this long)", stacklevel=3)
+        return "kept user configuration"
     try:
         torch.cuda.memory._set_allocator_settings("max_split_size_mb:2048")
-    except Exception:                                             # noqa: BLE001  (an optimisation of the reachable length only)
-        pass
+    except (AttributeError, RuntimeError, ValueError) as e:      # (private API: an optimisation of the reachable length only)
+        warnings.warn(f"dawn_pytorch_amd: could not set max_split_size_mb:2048 for a {T}-frame clip ({type(e).__name__}: {e})",
+                      stacklevel=3)
+        return f"unavailable: {type(e).__name__}"
+    warnings.warn(f"dawn_pytorch_amd: {T}-frame clip -- caching allocator set to max_split_size_mb:2048 for this process "
+                  f"(no PYTORCH_*_ALLOC_CONF in the environment)", stacklevel=3)
+    return "applied"
 
 
 class GaussianDiffusion(nn.Module):

@@ -45,10 +45,12 @@ class HubertFeatures:
             ent = {"k": w.shape[2], "Cout": w.shape[0], "b": dev(sd[p + "conv.bias"]) if p + "conv.bias" in sd else None,
                    "g": dev(sd[p + "layer_norm.weight"]), "be": dev(sd[p + "layer_norm.bias"])}
             ent["w"] = dev(w[:, 0, :]) if i == 0 else dev(pack_kn(w.permute(2, 1, 0).reshape(-1, w.shape[0])))
-            assert i > 0 or w.shape[1] == 1
+            if not (i > 0 or w.shape[1] == 1):
+                raise ValueError("i > 0 or w.shape[1] == 1")
             self.conv.append(ent)
             i += 1
-        assert len(self.conv) == len(self.conv_stride)
+        if not (len(self.conv) == len(self.conv_stride)):
+            raise ValueError("len(self.conv) == len(self.conv_stride)")
         # ---- feature projection
         self.fp_g, self.fp_b = dev(sd["feature_projection.layer_norm.weight"]), dev(sd["feature_projection.layer_norm.bias"])
         wp = sd["feature_projection.projection.weight"]                  # (E, 512)
@@ -68,7 +70,8 @@ class HubertFeatures:
         wpos = v_ if g_ is None else v_ * (g_ / v_.norm(dim=(0, 1), keepdim=True))   # (E, E/groups, k)
         self.pos_k, self.pos_groups = wpos.shape[2], pos_groups
         gw = self.E // pos_groups
-        assert wpos.shape[1] == gw and gw % 16 == 0
+        if not (wpos.shape[1] == gw and gw % 16 == 0):
+            raise ValueError("wpos.shape[1] == gw and gw % 16 == 0")
         self.pos_w = [dev(pack_kn(wpos[g * gw:(g + 1) * gw].permute(2, 1, 0).reshape(-1, gw))) for g in range(pos_groups)]
         self.pos_b = dev(sd[q + "bias"])
         # ---- encoder layers (stable layer norm: pre-LN)
@@ -167,7 +170,8 @@ class HubertFeatures:
         if last.numel() >= kernel:
             res.append(self.encode(last))
         ret = torch.cat(res, dim=0)
-        assert abs(ret.shape[0] - expected_T) <= 1
+        if not (abs(ret.shape[0] - expected_T) <= 1):
+            raise ValueError("abs(ret.shape[0] - expected_T) <= 1")
         if ret.shape[0] < expected_T:
             ret = torch.nn.functional.pad(ret, (0, 0, 0, expected_T - ret.shape[0]))
         else:

@@ -29,6 +29,13 @@ def _ld(t: Optional[Tensor]) -> int:
     return 0 if t is None else (t.stride(0) if t.dim() >= 2 else t.numel())
 
 
+def _need(ok, what: str) -> None:
+    """Launch precondition (contiguity, shapes, the dtype a pointer offset is computed in): raised, never `assert`ed -- under
+    `python -O` an assert disappears and the raw pointers would reach the kernel unchecked."""
+    if not ok:
+        raise _lib.DawnHipError(f"HipOps precondition failed -- {what}")
+
+
 class HipOps:
     """Launches on the current PyTorch stream of the tensors' device."""
 
@@ -57,8 +64,16 @@ class HipOps:
         key = (like.device.index, self._stream())
         t = self._tickets.get(key)
         if t is None:
-            t = self._tickets[key] = torch.zeros(1, device=like.device, dtype=torch.int32)
+            t = self._tickets[key] = torch.empty(4, device=like.device, dtype=torch.int32)
+            check(self.L.dawn_gn_ticket_reset(_p(t), self._stream()), "dawn_gn_ticket_reset")
         return t
+
+    def begin_evaluation(self, like: Tensor) -> None:
+        """Start of one denoiser evaluation on the current stream: the hand-off word of the convs' fused GroupNorm finalisation is
+        zeroed by a stream-ordered fill (include/dawn_hip.h: hard precondition of dawn_conv_desc.gn_ticket).  Inside a HIP-graph
+        capture this records a memset node, so every replay starts from a zero ticket too; an aborted launch or capture can no
+        longer leave a stale count behind for the next evaluation (the C evaluator does the same, dawn_ctx.hip)."""
+        check(self.L.dawn_gn_ticket_reset(_p(self._gn_ticket(like)), self._stream()), "dawn_gn_ticket_reset")
 
     def with_comm(self, comm):
         o = HipOps(comm)
@@ -264,7 +279,7 @@ class HipOps:
         """out = SiLU(x * a + b) (+ res); inplace: written over x (the caller has no further use for the GroupNorm input --
         one tensor less at the allocator peak of long clips)."""
         rows, Cc = x.shape
-        assert x.is_contiguous() and (res is None or res.is_contiguous())
+        _need(x.is_contiguous() and (res is None or res.is_contiguous()), "gn_apply_res: x.is_contiguous() and (res is None or res.is_contiguous())")
         out = x if inplace else self.empty(rows, Cc, like=x)
         check(self.L.dawn_gn_apply_res(_p(x), _p(a), _p(b), _p(res), _p(out), rows, Cc, self._stream()),
               "dawn_gn_apply_res")
@@ -298,7 +313,7 @@ class HipOps:
 
     def xattn_core(self, q: Tensor, HW: int, kvtab: Tensor, nulltab: Tensor, q_scale: Tensor) -> Tensor:
         """In place on q (rows,192)."""
-        assert q.is_contiguous() and q.shape[1] == 192
+        _need(q.is_contiguous() and q.shape[1] == 192, "xattn_core: q.is_contiguous() and q.shape[1] == 192")
         self._require(q, kvtab, nulltab, q_scale)
         check(self.L.dawn_xattn_core(_p(q), _p(q), q.shape[0], HW, _p(kvtab), _p(nulltab), _p(q_scale),
                                      self._stream()), "dawn_xattn_core")
@@ -306,7 +321,7 @@ class HipOps:
 
     def xattn_ln_sum(self, y3: Tensor, g3: Tensor, Co: int, eps: float = 1e-5) -> Tensor:
         rows = y3.shape[0]
-        assert y3.is_contiguous() and y3.shape[1] == 3 * Co
+        _need(y3.is_contiguous() and y3.shape[1] == 3 * Co, "xattn_ln_sum: y3.is_contiguous() and y3.shape[1] == 3 * Co")
         out = self.empty(rows, Co, like=y3)
         check(self.L.dawn_xattn_ln_sum(_p(y3), _p(g3), _p(out), rows, Co, eps, self._stream()), "dawn_xattn_ln_sum")
         return out
@@ -335,12 +350,12 @@ class HipOps:
         LayerNorms and the branch sum in one pass (per-clip tables `xtab` from xattn_tables).  gn = (c1, a, b): returns the block's
         h1 = SiLU(c1*a + b) + h_cond instead (MT:473-476: no h_cond tensor, no GroupNorm-apply pass)."""
         rows = q.shape[0]
-        assert q.is_contiguous() and q.shape[1] == 192 and xtab.is_contiguous() and xtab.shape[1:] == (3, 64 + 9 * Co)
-        assert rows == xtab.shape[0] * HW
+        _need(q.is_contiguous() and q.shape[1] == 192 and xtab.is_contiguous() and xtab.shape[1:] == (3, 64 + 9 * Co), "xattn_sigma_out: q.is_contiguous() and q.shape[1] == 192 and xtab.is_contiguous() and xtab.shape[1:] == (3, 64 + 9 * Co)")
+        _need(rows == xtab.shape[0] * HW, "xattn_sigma_out: rows == xtab.shape[0] * HW")
         self._require(q, xtab, g3)
         out = self.empty(rows, Co, like=q)
         gx, ga, gb = gn if gn is not None else (None, None, None)
-        assert gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, Co))
+        _need(gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, Co)), "xattn_sigma_out: gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, Co))")
         self._require(gx, ga, gb)
         check(self.L.dawn_xattn_sigma_out_h1(_p(q), rows, HW, _p(xtab), _p(g3), Co, eps, _p(gx), _p(ga), _p(gb), _p(out),
                                              self._stream()), "dawn_xattn_sigma_out")
@@ -356,10 +371,10 @@ class HipOps:
         if xtab is None:
             xtab = self.xattn_tables(kvtab, nulltab, q_scale, wo, 64)
         self._require(x, x2, wq, g3, xtab)
-        assert xtab.is_contiguous() and xtab.shape[1:] == (3, 640) and rows == xtab.shape[0] * HW
+        _need(xtab.is_contiguous() and xtab.shape[1:] == (3, 640) and rows == xtab.shape[0] * HW, "xattn_layer_c64: xtab.is_contiguous() and xtab.shape[1:] == (3, 640) and rows == xtab.shape[0] * HW")
         out = self.empty(rows, 64, like=x)
         gx, ga, gb = gn if gn is not None else (None, None, None)       # (c1, a, b): write h1 = SiLU(c1*a + b) + h_cond instead of h_cond
-        assert gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, 64))
+        _need(gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, 64)), "xattn_layer_c64: gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, 64))")
         self._require(gx, ga, gb)
         check(self.L.dawn_xattn_layer_c64_h1(_p(x), x.shape[1], _ld(x), _p(x2), 0 if x2 is None else x2.shape[1], _ld(x2),
                                              rows, HW, _p(wq), _p(wq_bf3), _p(g3), _p(xtab), eps, _p(gx), _p(ga), _p(gb), _p(out),
@@ -369,7 +384,7 @@ class HipOps:
     # ------------------------------------------------------------------ attention cores
     def temporal_attn(self, qkv: Tensor, Fext: int, HW: int, q0: int, Fq: int, win: int, rcos: Tensor, rsin: Tensor,
                       band: Tensor) -> Tensor:
-        assert qkv.is_contiguous() and qkv.shape == (Fext * HW, 768)
+        _need(qkv.is_contiguous() and qkv.shape == (Fext * HW, 768), "temporal_attn: qkv.is_contiguous() and qkv.shape == (Fext * HW, 768)")
         self._require(qkv, rcos, rsin, band)
         out = self.empty(Fq * HW, 256, like=qkv)
         check(self.L.dawn_temporal_attn_ex(_p(qkv), Fext, HW, q0, Fq, win, _p(rcos), _p(rsin), _p(band), _p(out),
@@ -397,7 +412,7 @@ class HipOps:
         is re-projecting K / V of the 2*win overlap rows per segment -- instead of writing and re-reading a (rows, 768)
         qkv tensor (21 -> ~10 MB per frame of peak memory on long clips).  `segments` = explicit [(a, b)] query ranges
         (buffer frame indices; the T-shard path runs the halo-free interior segments first)."""
-        assert x.is_contiguous() and x.shape == (Fext * HW, 64)
+        _need(x.is_contiguous() and x.shape == (Fext * HW, 64), "temporal_layer_c64_segmented: x.is_contiguous() and x.shape == (Fext * HW, 64)")
         if out is None:
             out = self.empty(Fq * HW, 64, like=x)
         if segments is None:
@@ -413,11 +428,11 @@ class HipOps:
                            wqkv_bf3: Optional[Tensor] = None, wout_bf3p: Optional[Tensor] = None,
                            out: Optional[Tensor] = None) -> Tensor:
         """out = x[q0:q0+Fq] + to_out(attn(LayerNorm(x))) for 64-channel levels, one kernel."""
-        assert x.is_contiguous() and x.shape == (Fext * HW, 64)
+        _need(x.is_contiguous() and x.shape == (Fext * HW, 64), "temporal_layer_c64: x.is_contiguous() and x.shape == (Fext * HW, 64)")
         self._require(x, wqkv, wout, rcos, rsin, band)
         if out is None:
             out = self.empty(Fq * HW, 64, like=x)
-        assert out.is_contiguous() and out.shape == (Fq * HW, 64)
+        _need(out.is_contiguous() and out.shape == (Fq * HW, 64), "temporal_layer_c64: out.is_contiguous() and out.shape == (Fq * HW, 64)")
         check(self.L.dawn_temporal_layer_c64_ex(_p(x), Fext, HW, q0, Fq, win, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(wout_bf3p),
                                                 _p(rcos), _p(rsin), _p(band), eps, _p(out), self.temporal_flags,
                                                 self._stream()),
@@ -425,7 +440,7 @@ class HipOps:
         return out
 
     def sla(self, qkv: Tensor, F: int, HW: int) -> Tensor:
-        assert qkv.is_contiguous() and qkv.shape == (F * HW, 768)
+        _need(qkv.is_contiguous() and qkv.shape == (F * HW, 768), "sla: qkv.is_contiguous() and qkv.shape == (F * HW, 768)")
         ctx = self.empty(F, 8, 32, 32, like=qkv)
         out = self.empty(F * HW, 256, like=qkv)
         s = self._stream()
@@ -436,18 +451,18 @@ class HipOps:
     def sla_layer_c64(self, x: Tensor, F: int, HW: int, wqkv: Tensor, wout: Tensor, bias: Tensor,
                       eps: float = 1e-5, wqkv_bf3: Optional[Tensor] = None, out: Optional[Tensor] = None) -> Tensor:
         """out = x + to_out(linear_attention(LayerNorm(x))) for 64-channel levels (two kernels, no qkv tensor)."""
-        assert x.is_contiguous() and x.shape == (F * HW, 64)
+        _need(x.is_contiguous() and x.shape == (F * HW, 64), "sla_layer_c64: x.is_contiguous() and x.shape == (F * HW, 64)")
         self._require(x, wqkv, wout, bias)
         ws = self.empty(self.L.dawn_sla_ws_floats(F, HW, int(wqkv_bf3 is not None)), like=x)
         if out is None:
             out = self.empty(F * HW, 64, like=x)
-        assert out.is_contiguous() and out.shape == (F * HW, 64)
+        _need(out.is_contiguous() and out.shape == (F * HW, 64), "sla_layer_c64: out.is_contiguous() and out.shape == (F * HW, 64)")
         check(self.L.dawn_sla_layer_c64(_p(x), F, HW, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(bias), eps, _p(ws), _p(out),
                                         self._stream()), "dawn_sla_layer_c64")
         return out
 
     def frame_attn(self, qkv: Tensor, F: int, N: int) -> Tensor:
-        assert qkv.is_contiguous() and qkv.shape == (F * N, 768)
+        _need(qkv.is_contiguous() and qkv.shape == (F * N, 768), "frame_attn: qkv.is_contiguous() and qkv.shape == (F * N, 768)")
         out = self.empty(F * N, 256, like=qkv)
         check(self.L.dawn_frame_attn(_p(qkv), F, N, _p(out), self._stream()), "dawn_frame_attn")
         return out
@@ -456,12 +471,12 @@ class HipOps:
     def init_conv_x(self, x: Tensor, w3: Tensor, fea_pre: Tensor, F: int, h: int, w: int, Co: int,
                     frames: Optional[Tuple[int, int]] = None, out: Optional[Tensor] = None) -> Tensor:
         """frames = (fa, fb): only that frame range of the (3, F, h, w) latent -> ((fb - fa)*h*w, Co) rows (T-shard: edge frames first)."""
-        assert x.is_contiguous() and x.shape == (3, F, h, w) and x.dtype == torch.float32     # (the frame offset below is in fp32 elements)
+        _need(x.is_contiguous() and x.shape == (3, F, h, w) and x.dtype == torch.float32, "init_conv_x: x.is_contiguous() and x.shape == (3, F, h, w) and x.dtype == torch.float32")     # (the frame offset below is in fp32 elements)
         self._require(x, w3, fea_pre, out)
         fa, fb = frames if frames is not None else (0, F)
         if out is None:
             out = self.empty((fb - fa) * h * w, Co, like=x)
-        assert out.is_contiguous() and out.shape == ((fb - fa) * h * w, Co)
+        _need(out.is_contiguous() and out.shape == ((fb - fa) * h * w, Co), "init_conv_x: out.is_contiguous() and out.shape == ((fb - fa) * h * w, Co)")
         check(self.L.dawn_init_conv_x_ex(x.data_ptr() + fa * h * w * 4, F * h * w, _p(w3), _p(fea_pre), fb - fa, h, w, Co, _p(out),
                                          self._stream()), "dawn_init_conv_x")
         return out
@@ -472,7 +487,7 @@ class HipOps:
         (long clips run the heads one after the other)."""
         ref = hg if hg is not None else ho
         rows, Co = ref.shape
-        assert (hg is None or hg.is_contiguous()) and (ho is None or ho.is_contiguous()) and (out is not None or (hg is not None and ho is not None))
+        _need((hg is None or hg.is_contiguous()) and (ho is None or ho.is_contiguous()) and (out is not None or (hg is not None and ho is not None)), "head_out: (hg is None or hg.is_contiguous()) and (ho is None or ho.is_contiguous()) and (out is not None or (hg is not None and ho is not None))")
         if out is None:
             out = self.empty(3, rows, like=ref)
         check(self.L.dawn_head_out(_p(hg), _p(ho), _p(wg), _p(bg), _p(wo), _p(bo), rows, Co, _p(out),
@@ -483,7 +498,7 @@ class HipOps:
                out: Optional[Tensor] = None) -> Tensor:
         M, K = x.shape
         N = W.shape[0]
-        assert W.is_contiguous() and W.shape[1] == K
+        _need(W.is_contiguous() and W.shape[1] == K, "linear: W.is_contiguous() and W.shape[1] == K")
         self._require(x, W, bias, out)
         if out is None:
             out = self.empty(M, N, like=x)
@@ -500,7 +515,7 @@ class HipOps:
     # ------------------------------------------------------------------ sampler
     def ddim_x0(self, x: Tensor, eps: Tensor, recip: float, recipm1: float) -> Tuple[Tensor, Tensor]:
         n = x.numel()
-        assert x.is_contiguous() and eps.is_contiguous()
+        _need(x.is_contiguous() and eps.is_contiguous(), "ddim_x0: x.is_contiguous() and eps.is_contiguous()")
         x0 = torch.empty_like(x)
         # selection scratch [hist1 2048 | hist2 1024 | hist3 1024 | state 4 | hmin 4]: ONE buffer per (device, stream), reset by two
         # stream-ordered fills per step (no allocation, no torch fill kernels inside the DDIM loop)
@@ -560,7 +575,7 @@ class HipOps:
     def ddim_update(self, x0: Tensor, eps: Tensor, s: Tensor, noise: Optional[Tensor], sqrt_alpha_next: float,
                     c: float, sigma: float) -> Tensor:
         x = torch.empty_like(x0)
-        assert noise is None or noise.is_contiguous()
+        _need(noise is None or noise.is_contiguous(), "ddim_update: noise is None or noise.is_contiguous()")
         check(self.L.dawn_ddim_update(_p(x0), _p(eps), _p(s), _p(noise), sqrt_alpha_next, c, sigma, x0.numel(),
                                       _p(x), self._stream()), "dawn_ddim_update")
         return x
@@ -591,7 +606,7 @@ class HipOps:
     def bn_relu_pool2(self, x: Tensor, a: Tensor, b: Tensor, F: int, H: int, W: int) -> Tensor:
         """(F*H*W, C) -> (F*H/2*W/2, C): AvgPool2x2(ReLU(x*a+b))  (DownBlock2d tail, UTIL:129-133)."""
         Cc = x.shape[1]
-        assert x.is_contiguous() and x.shape[0] == F * H * W
+        _need(x.is_contiguous() and x.shape[0] == F * H * W, "bn_relu_pool2: x.is_contiguous() and x.shape[0] == F * H * W")
         self._require(x, a, b)
         out = self.empty(F * (H // 2) * (W // 2), Cc, like=x)
         check(self.L.dawn_bn_relu_pool2(_p(x), _p(a), _p(b), _p(out), F, H, W, Cc, self._stream()), "dawn_bn_relu_pool2")
@@ -603,9 +618,9 @@ class HipOps:
         grid (2,T,h,w) view (planes may be strided: a frame range of a longer clip), conf (T,h,w) contiguous."""
         Cc = skip.shape[1]
         _, T, h, w = grid.shape
-        assert skip.is_contiguous() and skip.shape[0] == Hs * Ws and conf.is_contiguous() and conf.shape == (T, h, w)
-        assert grid.stride(3) == 1 and grid.stride(2) == w and grid.stride(1) == h * w
-        assert prev is None or (prev.is_contiguous() and prev.shape == (T * Hs * Ws, Cc))
+        _need(skip.is_contiguous() and skip.shape[0] == Hs * Ws and conf.is_contiguous() and conf.shape == (T, h, w), "warp_blend: skip.is_contiguous() and skip.shape[0] == Hs * Ws and conf.is_contiguous() and conf.shape == (T, h, w)")
+        _need(grid.stride(3) == 1 and grid.stride(2) == w and grid.stride(1) == h * w, "warp_blend: grid.stride(3) == 1 and grid.stride(2) == w and grid.stride(1) == h * w")
+        _need(prev is None or (prev.is_contiguous() and prev.shape == (T * Hs * Ws, Cc)), "warp_blend: prev is None or (prev.is_contiguous() and prev.shape == (T * Hs * Ws, Cc))")
         self._require(skip, grid, conf, prev)
         k = 2 if up2 else 1
         out = self.empty(T * Hs * k * Ws * k, Cc, like=skip)
@@ -620,11 +635,11 @@ class HipOps:
         src (3,H,W); out_vid / warped_vid: (3,T,H,W) views of the clip-sized outputs (frame range of (3,Ttot,H,W))."""
         _, T, h, w = grid.shape
         Cc = x.shape[1]
-        assert x.is_contiguous() and x.shape[0] == T * H * W and src.is_contiguous() and src.shape == (3, H, W)
-        assert grid.stride(3) == 1 and grid.stride(2) == w and grid.stride(1) == h * w and conf.is_contiguous()
+        _need(x.is_contiguous() and x.shape[0] == T * H * W and src.is_contiguous() and src.shape == (3, H, W), "final_conv_blend: x.is_contiguous() and x.shape[0] == T * H * W and src.is_contiguous() and src.shape == (3, H, W)")
+        _need(grid.stride(3) == 1 and grid.stride(2) == w and grid.stride(1) == h * w and conf.is_contiguous(), "final_conv_blend: grid.stride(3) == 1 and grid.stride(2) == w and grid.stride(1) == h * w and conf.is_contiguous()")
         for o in (out_vid, warped_vid):
-            assert o.shape == (3, T, H, W) and o.stride(3) == 1 and o.stride(2) == W and o.stride(1) == H * W
-        assert out_vid.stride(0) == warped_vid.stride(0)
+            _need(o.shape == (3, T, H, W) and o.stride(3) == 1 and o.stride(2) == W and o.stride(1) == H * W, "final_conv_blend: o.shape == (3, T, H, W) and o.stride(3) == 1 and o.stride(2) == W and o.stride(1) == H * W")
+        _need(out_vid.stride(0) == warped_vid.stride(0), "final_conv_blend: out_vid.stride(0) == warped_vid.stride(0)")
         self._require(x, w7, bias3, src, grid, conf, out_vid, warped_vid)
         check(self.L.dawn_final_conv_blend(_p(x), T, H, W, Cc, _p(w7), _p(bias3), _p(src), _p(grid), grid.stride(0),
                                            _p(conf), h, w, _p(out_vid), _p(warped_vid), out_vid.stride(0),
@@ -635,7 +650,7 @@ class HipOps:
         """(3,T,H,W) fp32 in [0,1] -> (T,H,W,3) uint8 with `_process_output_frame`'s arithmetic (UVG:533-548):
         trunc(clip(x + mean/255, 0, 1) * 255); `bgr=True` = the cv2 channel order."""
         _, T, H, W = vid.shape
-        assert vid.shape[0] == 3 and vid.stride(3) == 1 and vid.stride(2) == W and vid.stride(1) == H * W
+        _need(vid.shape[0] == 3 and vid.stride(3) == 1 and vid.stride(2) == W and vid.stride(1) == H * W, "frames_to_u8: vid.shape[0] == 3 and vid.stride(3) == 1 and vid.stride(2) == W and vid.stride(1) == H * W")
         self._require(vid)
         out = torch.empty(T, H, W, 3, device=vid.device, dtype=torch.uint8)
         m = [float(x) / 255.0 for x in mean]
@@ -646,7 +661,7 @@ class HipOps:
     # ------------------------------------------------------------------ HuBERT audio features
     def wave_normalize(self, x: Tensor) -> Tensor:
         """Wav2Vec2FeatureExtractor(do_normalize): (x - mean) / sqrt(var + 1e-7) over the utterance."""
-        assert x.is_contiguous() and x.dim() == 1
+        _need(x.is_contiguous() and x.dim() == 1, "wave_normalize: x.is_contiguous() and x.dim() == 1")
         self._require(x)
         st = torch.empty(2, dtype=torch.float64, device=x.device)
         out = torch.empty_like(x)
@@ -656,7 +671,7 @@ class HipOps:
     def hubert_conv0(self, x: Tensor, w: Tensor, bias: Optional[Tensor], stride: int) -> Tensor:
         """Conv1d(1, C, k, stride) of the waveform -> (T0, C) rows; w (C, k)."""
         Cc, k = w.shape
-        assert x.is_contiguous() and w.is_contiguous()
+        _need(x.is_contiguous() and w.is_contiguous(), "hubert_conv0: x.is_contiguous() and w.is_contiguous()")
         self._require(x, w, bias)
         T0 = (x.numel() - k) // stride + 1
         out = self.empty(T0, Cc, like=x)
@@ -666,7 +681,7 @@ class HipOps:
 
     def ln_affine_act(self, x: Tensor, gamma: Tensor, beta: Tensor, eps: float = 1e-5, act: int = 0) -> Tensor:
         """LayerNorm over the channels of every row, affine, act 0 none / 2 exact GELU."""
-        assert x.is_contiguous()
+        _need(x.is_contiguous(), "ln_affine_act: x.is_contiguous()")
         self._require(x, gamma, beta)
         out = torch.empty_like(x)
         check(self.L.dawn_ln_affine_act(_p(x), x.shape[0], x.shape[1], _p(gamma), _p(beta), eps, act, _p(out), self._stream()),
@@ -675,7 +690,7 @@ class HipOps:
 
     def add_act(self, a: Optional[Tensor], b: Tensor, act: int = 0, out: Optional[Tensor] = None) -> Tensor:
         """out = a + act(b) (a may be None); act 2 = exact GELU."""
-        assert b.is_contiguous() and (a is None or a.is_contiguous())
+        _need(b.is_contiguous() and (a is None or a.is_contiguous()), "add_act: b.is_contiguous() and (a is None or a.is_contiguous())")
         self._require(a, b)
         out = torch.empty_like(b) if out is None else out
         check(self.L.dawn_add_act(_p(a), _p(b), act, b.numel(), _p(out), self._stream()), "dawn_add_act")
@@ -684,7 +699,7 @@ class HipOps:
     def attn64(self, qkv: Tensor, heads: int) -> Tensor:
         """qkv (T, 3*heads*64) = [q | k | v] -> softmax(q k^T / 8) v per head, (T, heads*64)."""
         T = qkv.shape[0]
-        assert qkv.is_contiguous() and qkv.shape[1] == 3 * heads * 64
+        _need(qkv.is_contiguous() and qkv.shape[1] == 3 * heads * 64, "attn64: qkv.is_contiguous() and qkv.shape[1] == 3 * heads * 64")
         self._require(qkv)
         out = self.empty(T, heads * 64, like=qkv)
         check(self.L.dawn_attn64(_p(qkv), T, heads, _p(out), self._stream()), "dawn_attn64")
@@ -696,11 +711,11 @@ class HipOps:
         (heads, Tq, Tk) additive, rotary tables (>= max(Tq, Tk), nrot) for the first 2*nrot features of every head."""
         Tq, Tk = q.shape[0], k.shape[0]
         for t in (q, k, v):
-            assert t.stride(1) == 1 and t.shape[1] == heads * 32
+            _need(t.stride(1) == 1 and t.shape[1] == heads * 32, "attn_bias32: t.stride(1) == 1 and t.shape[1] == heads * 32")
         self._require(q, k, v, bias, rcos, rsin)
-        assert bias is None or (bias.is_contiguous() and tuple(bias.shape) == (heads, Tq, Tk))
+        _need(bias is None or (bias.is_contiguous() and tuple(bias.shape) == (heads, Tq, Tk)), "attn_bias32: bias is None or (bias.is_contiguous() and tuple(bias.shape) == (heads, Tq, Tk))")
         nrot = 0 if rcos is None else rcos.shape[1]
-        assert rcos is None or (rcos.is_contiguous() and rsin.is_contiguous() and rcos.shape[0] >= max(Tq, Tk))
+        _need(rcos is None or (rcos.is_contiguous() and rsin.is_contiguous() and rcos.shape[0] >= max(Tq, Tk)), "attn_bias32: rcos is None or (rcos.is_contiguous() and rsin.is_contiguous() and rcos.shape[0] >= max(Tq, Tk))")
         out = self.empty(Tq, heads * 32, like=q)
         check(self.L.dawn_attn_bias32(_p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), Tq, Tk, heads, _p(bias), _p(rcos),
                                       _p(rsin), nrot, float(scale), _p(out), heads * 32, self._stream()), "dawn_attn_bias32")
@@ -708,7 +723,7 @@ class HipOps:
 
     def interp_linear(self, y: Tensor, xi: Tensor) -> Tensor:
         """scipy interp1d(arange(n), y, kind='linear', axis=0)(xi) as float32; xi float64 positions on the device."""
-        assert y.is_contiguous() and xi.dtype == torch.float64 and xi.is_contiguous()
+        _need(y.is_contiguous() and xi.dtype == torch.float64 and xi.is_contiguous(), "interp_linear: y.is_contiguous() and xi.dtype == torch.float64 and xi.is_contiguous()")
         self._require(y, xi)
         out = self.empty(xi.numel(), y.shape[1], like=y)
         check(self.L.dawn_interp_linear(_p(y), y.shape[0], y.shape[1], _p(xi), xi.numel(), _p(out), self._stream()),

@@ -21,7 +21,8 @@ BRANCH_MLP = {"pose": "pose_mlp", "aud": "audio_mlp", "eye": "eye_mlp"}
 def pack_kn(w_kn: Tensor) -> Tensor:
     """(K, N) -> [K/4][N][4] contiguous fp32."""
     K, N = w_kn.shape
-    assert K % 4 == 0, K
+    if not (K % 4 == 0):
+        raise ValueError(f"K % 4 == 0: {K}")
     return w_kn.float().reshape(K // 4, 4, N).permute(0, 2, 1).contiguous()
 
 
@@ -29,7 +30,8 @@ def pack_bf3(w_kn: Tensor) -> Tensor:
     """(K, N) fp32 -> [K/16][3][2][N][8] int16: the exact three-way bf16 split w = w1 + w2 + w3 (round-to-nearest
     -even at every level; residuals are exact in fp32) consumed by the split-operand bf16-MFMA 3x3 kernel."""
     K, N = w_kn.shape
-    assert K % 16 == 0, K
+    if not (K % 16 == 0):
+        raise ValueError(f"K % 16 == 0: {K}")
     w = w_kn.float()
     w1 = w.to(torch.bfloat16)
     r1 = w - w1.float()
@@ -47,7 +49,8 @@ def pack_wino_bf3(w5: Tensor) -> Tensor:
         [Ci/16 chunks][16 positions p = 4 xi + nu][Co/16 blocks][2: W1 = [u1|u2], W2 = [u3|u1]][64 lanes][8] int16,
     lane = 16 kg + l15 -> output channel 16 cb + l15, input channels 16 chunk + 8 (kg & 1) + 0..7 of plane (kg < 2 ? first : second)."""
     Co, Ci = w5.shape[0], w5.shape[1]
-    assert w5.shape[2:] == (1, 3, 3) and Ci % 16 == 0 and Co % 16 == 0, tuple(w5.shape)
+    if not (w5.shape[2:] == (1, 3, 3) and Ci % 16 == 0 and Co % 16 == 0):
+        raise ValueError(f"w5.shape[2:] == (1, 3, 3) and Ci % 16 == 0 and Co % 16 == 0: {tuple(w5.shape)}")
     g = w5[:, :, 0].double()                                                        # (Co, Ci, 3, 3)
     G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w5.device)
     U = torch.einsum("xk,oikl,nl->oixn", G, g, G)                                   # (Co, Ci, xi, nu)
@@ -77,7 +80,8 @@ def pack_bf3_temporal_out(w_kn: Tensor) -> Tensor:
     of O^T, so that its registers feed the MFMA's B operand unshuffled -- slot (d-chunk kc, k-half hf, i) holds row
     head*32 + 16 kc + 8 (i >> 2) + 4 hf + (i & 3)."""
     K, N = w_kn.shape
-    assert K % 32 == 0
+    if not (K % 32 == 0):
+        raise ValueError("K % 32 == 0")
     idx = []
     for head in range(K // 32):
         for kc in range(2):
@@ -208,16 +212,30 @@ class PackedUNet:
     n_cond_blocks: int = 0
 
     def band(self, win: int) -> Tensor:
-        """bias by offset d = j - i in [-win, win] -> (2*win+1, 8) (MT:111-119 inside the window)."""
-        d = torch.arange(-win, win + 1, device=self.rel_emb.device)
-        return self.rel_emb[rel_pos_bucket(d)].contiguous()
+        """bias by offset d = j - i in [-win, win] -> (2*win+1, 8) (MT:111-119 inside the window).  Cached per window: a clip
+        costs no torch index / copy kernels for it (read-only table)."""
+        cache = self.__dict__.setdefault("_band_cache", {})
+        key = (win, self.rel_emb.data_ptr(), self.rel_emb._version)
+        if key not in cache:
+            cache.clear()
+            d = torch.arange(-win, win + 1, device=self.rel_emb.device)
+            cache[key] = self.rel_emb[rel_pos_bucket(d)].contiguous()
+        return cache[key]
 
     def rotary_tables(self, n: int):
-        """cos/sin (n,16) of rotary-embedding-torch 0.3.x: angle = pos * freqs (interleaved pairs)."""
-        pos = torch.arange(n, dtype=torch.float32)
-        ang = pos[:, None] * self.rot_freqs.detach().float().cpu()[None, :]
-        dev = self.rel_emb.device
-        return ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev)
+        """cos/sin (n,16) of rotary-embedding-torch 0.3.x: angle = pos * freqs (interleaved pairs).  Cached per length (the tables
+        depend on the clip length only): no host trigonometry and no host-to-device copies per clip."""
+        cache = self.__dict__.setdefault("_rot_cache", {})
+        fr = self.rot_freqs.detach().float().cpu()
+        key = (n, str(self.rel_emb.device), tuple(fr.tolist()))
+        if key not in cache:
+            if len(cache) > 8:
+                cache.clear()
+            pos = torch.arange(n, dtype=torch.float32)
+            ang = pos[:, None] * fr[None, :]
+            dev = self.rel_emb.device
+            cache[key] = (ang.cos().contiguous().to(dev), ang.sin().contiguous().to(dev))
+        return cache[key]
 
 
 def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn.") -> PackedUNet:
@@ -234,7 +252,8 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
     P = PackedUNet(dim=dim, dims=dims, n_levels=n_levels, fea_ch=w_init.shape[1] - 3,
                    cond_dims=[g("downs.0.0.audio_mlp.1.weight").shape[1], g("downs.0.0.pose_mlp.1.weight").shape[1],
                               g("downs.0.0.eye_mlp.1.weight").shape[1]], win=win)
-    assert w_init.shape[-1] == 7 and P.fea_ch % 16 == 0, "init conv: 7x7 kernel and fea channels % 16 == 0"
+    if not (w_init.shape[-1] == 7 and P.fea_ch % 16 == 0):
+        raise ValueError("init conv: 7x7 kernel and fea channels % 16 == 0")
     P.w3 = dev(conv_w_kn(w_init[:, :3]))                              # (147, dim)
     P.wfea = dev(pack_kn(conv_w_kn(w_init[:, 3:])))
     P.b_init = dev(g("init_conv.bias"))

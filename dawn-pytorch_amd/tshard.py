@@ -14,7 +14,7 @@ global element index, so results do not depend on the sharding.
 """
 from __future__ import annotations
 
-from typing import Tuple
+from typing import Optional, Tuple
 
 import torch
 
@@ -42,10 +42,19 @@ class TShardComm:
     the own rows -- is launched in between (unet_forward._temporal).  A halo wider than the neighbour's shard (F < win) is
     gathered from as many ranks as it spans.  Buffers are cached per shape (no allocation per layer and step)."""
 
-    def __init__(self, dist, rank: int, world: int, Ttotal: int, f0: int, F: int, group=None):
+    def __init__(self, dist, rank: int, world: int, Ttotal: int, f0: int, F: int, group=None, reduce_group=None):
+        """group = the process group of the halo point-to-point exchanges (None: the default group); reduce_group = the group of the
+        tiny GroupNorm / quantile all-reduces (None: the same as `group`).  With torch's NCCL (= RCCL) backend every collective of
+        one process group runs on that group's communicator stream: a 128-byte GroupNorm all-reduce issued while a 186 MB halo
+        transfer is in flight would queue BEHIND it -- exactly what the edge-first schedule (unet_forward._edge_first) tries to
+        overlap.  Two groups = two communicators = two streams: `TShardComm.two_groups(dist)` creates them."""
         self.dist, self.rank, self.world = dist, rank, world
         self.Ttotal, self.f0, self.F = Ttotal, f0, F
         self.group = group
+        self.reduce_group = group if reduce_group is None else reduce_group
+        self.timing = False           # measure what the stream waits for (HIP events around halo_end / the all-reduces): bench.py's
+        self._timed = []              # ... extra clip after the timed region; [(kind, start event, end event)] or host seconds on CPU
+        self._host_s = {"halo_wait": 0.0, "allreduce": 0.0}
         if world > 1 and (f0 != rank * F or Ttotal != world * F):
             raise ValueError("TShardComm expects equal contiguous shards: f0 == rank*F and Ttotal == world*F")
         self._bufs = {}
@@ -58,22 +67,63 @@ class TShardComm:
         self.n_halo_edge_first = 0    # exchanges posted by the PRODUCER of the layer input (unet_forward._edge_first), own rows in place
         self.halo_bytes_sent = self.halo_bytes_recv = self.allreduce_bytes = 0
 
+    @staticmethod
+    def two_groups(dist):
+        """(halo group, reduce group): two process groups over all ranks, so that the point-to-point halo transfers and the tiny
+        all-reduces get a communicator (and, on RCCL, a stream) each.  Collective: every rank calls it, in the same order."""
+        ranks = list(range(dist.get_world_size()))
+        return dist.new_group(ranks), dist.new_group(ranks)
+
     def stats(self) -> dict:
         """Counters since construction (bench.py reports them per rank: RCCL participation is checkable from the JSON)."""
         return {"rank": self.rank, "world": self.world, "halo_exchanges": self.n_halo, "halo_exchanges_edge_first": self.n_halo_edge_first,
                 "halo_bytes_sent": self.halo_bytes_sent, "halo_bytes_received": self.halo_bytes_recv,
-                "all_reduces": self.n_allreduce, "all_reduce_bytes": self.allreduce_bytes}
+                "all_reduces": self.n_allreduce, "all_reduce_bytes": self.allreduce_bytes,
+                "separate_groups": self.reduce_group is not self.group}
+
+    # ---- what the compute stream waits for (timing = True only; bench.py runs ONE extra clip with it after the timed region)
+    def _timed_call(self, kind: str, like: Optional[Tensor], fn) -> None:
+        if not self.timing:
+            fn()
+            return
+        if like is not None and like.is_cuda:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            fn()
+            e1.record()
+            self._timed.append((kind, e0, e1))
+        else:
+            import time
+            t0 = time.perf_counter()
+            fn()
+            self._host_s[kind] += time.perf_counter() - t0
+
+    def timing_ms(self, reset: bool = True) -> dict:
+        """{"halo_wait_ms", "allreduce_ms", ...}: time the compute stream spent between the HIP events recorded around every
+        halo_end (= how long it WAITED for the neighbours' frames: 0 when the transfer hid behind the producer) and around every
+        all-reduce (launch + latency of the collective on the critical path) since `timing` was switched on.  Synchronises."""
+        out = {"halo_wait_ms": self._host_s["halo_wait"] * 1e3, "allreduce_ms": self._host_s["allreduce"] * 1e3,
+               "halo_waits": 0, "allreduces_timed": 0}
+        if self._timed:
+            torch.cuda.synchronize()
+            for kind, e0, e1 in self._timed:
+                out["halo_wait_ms" if kind == "halo_wait" else "allreduce_ms"] += e0.elapsed_time(e1)
+                out["halo_waits" if kind == "halo_wait" else "allreduces_timed"] += 1
+        if reset:
+            self._timed = []
+            self._host_s = {"halo_wait": 0.0, "allreduce": 0.0}
+        return out
 
     # ---- tiny reductions
     def all_reduce_sum(self, t: Tensor) -> None:
         self.n_allreduce += 1
         self.allreduce_bytes += t.numel() * t.element_size()
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+        self._timed_call("allreduce", t, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.reduce_group))
 
     def all_reduce_min(self, t: Tensor) -> None:
         self.n_allreduce += 1
         self.allreduce_bytes += t.numel() * t.element_size()
-        self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+        self._timed_call("allreduce", t, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.reduce_group))
 
     def all_gather_cat(self, v: Tensor) -> Tensor:
         """Used only by the torch reference op set in tests (equal shard sizes)."""
@@ -162,9 +212,15 @@ class TShardComm:
         """Drop the cached extended buffers (they pin (Fext*HW, C) per level for the lifetime of the communicator)."""
         self._bufs.clear()
 
+    def wait_works(self, works, like: Optional[Tensor] = None) -> None:
+        """NCCL/RCCL: the current stream waits for the transfers; gloo: the host does (also the body of the C evaluator's halo_end)."""
+        def go():
+            for w in works:
+                w.wait()
+        self._timed_call("halo_wait", like, go)
+
     def halo_end(self, hx: HaloExchange) -> None:
-        for w in hx.works:
-            w.wait()          # NCCL/RCCL: the current stream waits for the transfer; gloo: the host does
+        self.wait_works(hx.works, hx.xe)
         hx.works = []
         if not self.keep_buffers:
             self._bufs.clear()        # (hx.xe keeps the buffer alive until the layer that reads it has been enqueued)
@@ -194,13 +250,13 @@ class SimulatedInteriorShard(TShardComm):
         self.n_allreduce += 1
         self.allreduce_bytes += t.numel() * t.element_size()
         if self.dist is not None:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+            self._timed_call("allreduce", t, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM))
 
     def all_reduce_min(self, t: Tensor) -> None:
         self.n_allreduce += 1
         self.allreduce_bytes += t.numel() * t.element_size()
         if self.dist is not None:
-            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+            self._timed_call("allreduce", t, lambda: self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN))
 
     def halo_begin(self, x: Tensor, HW: int, win: int) -> HaloExchange:
         F = x.shape[0] // HW

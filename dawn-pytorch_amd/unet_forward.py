@@ -161,7 +161,8 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
     a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows, part=part2)
     if rb.wr is not None:
         return ops.conv_gemm(x, rb.wr, Co, in1=x2, bias=rb.br, tr=(c2, a2, b2), w_bf3=rb.wrs, **g)
-    assert x2 is None
+    if not (x2 is None):
+        raise ValueError("x2 is None")
     return ops.gn_apply_res(c2, a2, b2, x, inplace=True)
 
 
@@ -353,6 +354,8 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
     null_cond_prob = 0 (MT:892-956).  `film_all` (the only t-dependent input besides x) may be supplied
     precomputed so that the rest of the evaluation is a fixed launch sequence (see GraphedForward)."""
     F, H, W = cs.F, cs.h, cs.w
+    if hasattr(ops, "begin_evaluation"):
+        ops.begin_evaluation(x3)      # (the fused GroupNorm hand-off starts every evaluation from a zeroed ticket)
     if film_all is None:
         film_all = time_film(ops, P, t, cs.fea_pre)
     if cs.comm is not None and hasattr(cs.comm, "keep_buffers"):
@@ -400,7 +403,8 @@ def unet_forward(ops, P: PackedUNet, cs: ClipState, x3: Tensor, t: float, film_a
     x = _resblock(ops, P.mid["rb2"], x, None, F, H, W, film_all, cs)
     for lvl in P.ups:
         skip, sh, sw = skips.pop()
-        assert (sh, sw) == (H, W)
+        if not ((sh, sw) == (H, W)):
+            raise ValueError("(sh, sw) == (H, W)")
         x = _resblock(ops, lvl["rb1"], x, skip, F, H, W, film_all, cs)       # torch.cat((x, h.pop())) MT:948
         del skip                     # (a loop variable would keep the level's skip tensor alive until the function returns)
         x = _resblock(ops, lvl["rb2"], x, None, F, H, W, film_all, cs)

@@ -213,7 +213,8 @@ def load_wav_16k(path: str) -> np.ndarray:
         subprocess.run(["ffmpeg", "-i", path, "-ar", "16000", "-y", tmp.name], check=True, stdout=subprocess.DEVNULL,
                        stderr=subprocess.DEVNULL)
         x, sr = read_pcm(tmp.name)
-    assert sr == 16000
+    if not (sr == 16000):
+        raise ValueError("sr == 16000")
     return x
 
 

@@ -74,7 +74,13 @@ typedef struct dawn_conv_desc {
     /* optional, with gn_part: finish the GroupNorm in the conv launch itself (dawn_gn_reduce_finalize's arguments: MT:230-248) -- the
      * workgroup that finishes last reduces the partial rows in fixed order and writes a[c] / b[c].  Honoured by the Winograd kernel
      * only; *gn_rows < 0 then says so (|*gn_rows| rows were written), otherwise call dawn_gn_reduce_finalize as before.  gn_ticket =
-     * one device word, zero before the first launch (the launch leaves it zero); one per stream. */
+     * one device word per stream.  HARD PRECONDITION: it is ZERO when the launch starts (dawn_gn_ticket_reset; a completed launch
+     * leaves it zero).  With a non-zero ticket (an aborted launch, an uninitialised word) no workgroup sees itself as the last one:
+     * gn_a / gn_b are then NOT written although *gn_rows reports them -- so reset it at the start of every evaluation, as both hosts
+     * do.  ISA-level assumption of the hand-off (conv3x3_wino.hip): the gn_part rows and the ticket are agent-scope RELAXED atomics
+     * (write-through to / read from the device-coherent level), ordered by `s_waitcnt vmcnt(0)` + a workgroup barrier before the
+     * ticket's read-modify-write; the last workgroup's row loads are agent-scope atomic loads issued after its own RMW returned.
+     * No release/acquire fence: on gfx950 a release writes back the XCD's whole L2 (measured -4.5 % on the benchmark). */
     const float* gn_gamma; const float* gn_beta; const float* gn_fs; const float* gn_fsh;
     double gn_count; float gn_eps;
     float* gn_a; float* gn_b;
@@ -108,6 +114,9 @@ int dawn_gn_finalize(const double* sums16, double count_per_group, const float* 
 int dawn_gn_reduce_finalize(const double* part, int nblk, double count_per_group, const float* gamma,
                             const float* beta, const float* film_scale, const float* film_shift, int C,
                             float eps, float* a, float* b, void* stream);
+/* zero the hand-off word(s) of the fused GroupNorm finalisation (dawn_conv_desc.gn_ticket; 16 bytes): stream-ordered fill, once per
+ * evaluation before its first conv launch (graph-capturable) */
+int dawn_gn_ticket_reset(unsigned* ticket, void* stream);
 /* out = silu(x*a[c]+b[c]) + res   (Block.act MT:248 + residual add MT:479); out may be x itself (in place) */
 int dawn_gn_apply_res(const float* x, const float* a, const float* b, const float* res, float* out,
                       long rows, int C, void* stream);

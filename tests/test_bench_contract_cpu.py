@@ -93,3 +93,24 @@ def test_launch_plan_never_downgrades_a_multi_gpu_request(tmp_path):
     cmd[cmd.index(os.path.join(ROOT, "bench.py"))] = str(probe)
     assert subprocess.call(cmd, timeout=300, env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK")}) == 0
     assert sorted(p.name for p in tmp_path.glob("rank*")) == ["rank0", "rank1"] and (tmp_path / "rank1").read_text() == "2"
+
+
+def test_tshard_preflight_failure_is_loud():
+    """VERDICT r4 #11: `--mode tshard` with a failed preflight exits with code 3 unless --allow-fallback was given."""
+    assert bench.resolve_mode("tshard", True, False) == "tshard"
+    assert bench.resolve_mode("replica", False, False) == "replica"
+    assert bench.resolve_mode("tshard", False, True) == "replica"
+    with pytest.raises(SystemExit) as e:
+        bench.resolve_mode("tshard", False, False)
+    assert e.value.code == 3
+
+
+def test_stdout_redirection_keeps_foreign_prints_off_the_json_stream(tmp_path):
+    """RCCL prints its banner with printf on fd 1 when a communicator is created; bench.py's stdout carries one JSON line.  The
+    fd-level redirection moves such output to stderr and restores stdout afterwards."""
+    import subprocess
+    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
+            "with bench.stdout_to_stderr():\n    os.write(1, b'RCCL version : banner\\n')\n"
+            "print('{\"metric\": 1}')\n" % ROOT)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.strip() == '{"metric": 1}' and "banner" in r.stderr

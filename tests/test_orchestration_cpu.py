@@ -177,3 +177,46 @@ def test_pack_bf3_is_an_exact_three_way_split():
     assert torch.equal(rec[2], (r1 - rec[1]).to(torch.bfloat16).float())
     # fp32 has a 24-bit significand = 3 x 8 bits: the split is exact (up to bf16 subnormal flushing, absent here)
     assert torch.equal(rec[0].double() + rec[1].double() + rec[2].double(), w.double())
+
+
+def test_long_clip_allocator_respects_user_configuration(monkeypatch):
+    """the process-global allocator setting is applied only when the caller configured nothing (the parser resets every
+    option its string does not name) and says what it did; a private-API failure is reported, not swallowed."""
+    import warnings
+    from dawn_pytorch_amd import diffusion as Dm
+
+    class Like:
+        is_cuda = True
+    calls = []
+    monkeypatch.setattr(torch.cuda.memory, "_set_allocator_settings", lambda s: calls.append(s), raising=False)
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        monkeypatch.setattr(Dm, "_ALLOC_SET", False)
+        assert Dm._long_clip_allocator(200, Like()) is None and not calls          # short clip: nothing to do
+        assert Dm._long_clip_allocator(5000, Like(), environ={"PYTORCH_HIP_ALLOC_CONF": "garbage_collection_threshold:0.8"}) == "kept user configuration"
+        assert not calls
+        assert Dm._long_clip_allocator(5000, Like(), environ={}) is None            # once per process
+        monkeypatch.setattr(Dm, "_ALLOC_SET", False)
+        assert Dm._long_clip_allocator(5000, Like(), environ={}) == "applied" and calls == ["max_split_size_mb:2048"]
+        monkeypatch.setattr(Dm, "_ALLOC_SET", False)
+
+        def boom(s):
+            raise RuntimeError("no such option")
+        monkeypatch.setattr(torch.cuda.memory, "_set_allocator_settings", boom, raising=False)
+        assert Dm._long_clip_allocator(5000, Like(), environ={}).startswith("unavailable")
+    assert len(w) == 3 and all("dawn_pytorch_amd" in str(x.message) for x in w)
+    monkeypatch.setattr(Dm, "_ALLOC_SET", False)
+
+
+def test_launch_preconditions_raise_not_assert():
+    """launch preconditions are raised (DawnHipError), not `assert`ed -- no `assert` statement is left in the
+    modules that hand raw pointers to the kernels, so `python -O` cannot strip a check."""
+    import ast
+    import pathlib
+    from dawn_pytorch_amd import _lib, ops
+    pkg = pathlib.Path(ops.__file__).parent
+    for name in ("ops.py", "pack.py", "tshard.py", "ctx.py", "unet_forward.py"):
+        tree = ast.parse((pkg / name).read_text())
+        assert not [n.lineno for n in ast.walk(tree) if isinstance(n, ast.Assert)], name
+    with pytest.raises(_lib.DawnHipError, match="precondition"):
+        ops._need(False, "x.is_contiguous()")

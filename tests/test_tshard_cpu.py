@@ -52,7 +52,25 @@ def _lean(on):
         UF.LONG_CLIP_FRAMES, UF.TEMPORAL_SEG_FRAMES, UF.FRAME_CHUNK = 4, 5, 7
 
 
-def _worker(rank, world, port, out_path, win=3, dim=16, lean=False, h=8):
+class _GroupSpy:
+    """torch.distributed with the process group of every collective / P2P op recorded (which communicator carried what)."""
+
+    def __init__(self, d):
+        self._d, self.used = d, {"all_reduce": [], "p2p": []}
+
+    def __getattr__(self, k):
+        return getattr(self._d, k)
+
+    def all_reduce(self, t, op=None, group=None):
+        self.used["all_reduce"].append(group)
+        return self._d.all_reduce(t, op=op, group=group)
+
+    def P2POp(self, fn, t, peer, group=None):
+        self.used["p2p"].append(group)
+        return self._d.P2POp(fn, t, peer, group=group)
+
+
+def _worker(rank, world, port, out_path, win=3, dim=16, lean=False, h=8, two_groups=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -62,11 +80,22 @@ def _worker(rank, world, port, out_path, win=3, dim=16, lean=False, h=8):
     F = TT // world
     diff = _build(F, win, dim, h)
     fea, bbox, cond = _inputs(h)
-    comm = TShardComm(dist, rank, world, TT, rank * F, F)
+    extra = {}
+    if two_groups:
+        spy = _GroupSpy(dist)
+        hg, rg = TShardComm.two_groups(dist)
+        comm = TShardComm(spy, rank, world, TT, rank * F, F, group=hg, reduce_group=rg)
+        comm.timing = True
+    else:
+        comm = TShardComm(dist, rank, world, TT, rank * F, F)
     out = diff.sample(fea, bbox, cond=cond[:, rank * F:(rank + 1) * F].contiguous(), cond_scale=1.0, comm=comm,
                       trace=True)
+    if two_groups:
+        extra = {"p2p_on_halo_group": all(g is hg for g in spy.used["p2p"]) and len(spy.used["p2p"]) > 0,
+                 "allreduce_on_reduce_group": all(g is rg for g in spy.used["all_reduce"]) and len(spy.used["all_reduce"]) > 0,
+                 "groups_differ": hg is not rg, "timing": comm.timing_ms()}
     qs = torch.stack([tr["s"][1] for tr in diff.last_trace[0]])
-    torch.save({"out": out, "qs": qs, "stats": comm.stats()}, f"{out_path}.{rank}")
+    torch.save({"out": out, "qs": qs, "stats": comm.stats(), **extra}, f"{out_path}.{rank}")
     dist.barrier()
     dist.destroy_process_group()
 
@@ -109,3 +138,25 @@ def test_tshard_equals_unsharded(tmp_path, world, win, dim, lean, h):
     # writes the edge frames into the extended buffer, posts the exchange and computes the interior behind it (unet_forward._edge_first:
     # init conv, spatial attention of the down / up level 0 = 3 of the 6 layers); elsewhere the temporal layer posts it
     assert all(s_["halo_exchanges_edge_first"] == (3 * S if (dim == 64 and h * h >= 1024 and TT // world > 2 * win) else 0) for s_ in st)
+
+
+def test_tshard_two_process_groups(tmp_path):
+    """VERDICT r4 #6a: halo point-to-point transfers on one process group, the GroupNorm / quantile all-reduces on another (on RCCL:
+    two communicators, two streams -- a 128-byte all-reduce no longer queues behind a halo transfer in flight).  World 3 (a rank
+    with two neighbours) over gloo: every P2P op went to the halo group, every all-reduce to the reduce group, the result equals
+    the unsharded clip, and the wait / all-reduce timers (bench.py's `comm.per_rank`) counted every exchange."""
+    world, win, dim, h = 3, 3, 16, 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out_path = str(tmp_path / "shard2g")
+    mp.spawn(_worker, args=(world, port, out_path, win, dim, False, h, True), nprocs=world, join=True)
+    parts = [torch.load(f"{out_path}.{r}") for r in range(world)]
+    diff = _build(TT, win, dim, h)
+    fea, bbox, cond = _inputs(h)
+    full = diff.sample(fea, bbox, cond=cond, cond_scale=1.0)
+    torch.testing.assert_close(torch.cat([p["out"] for p in parts], dim=2), full, atol=2e-5, rtol=1e-5)
+    for p in parts:
+        assert p["groups_differ"] and p["p2p_on_halo_group"] and p["allreduce_on_reduce_group"]
+        assert p["stats"]["separate_groups"] is True
+        assert p["timing"]["halo_wait_ms"] > 0 and p["timing"]["allreduce_ms"] > 0     # (gloo: host-side waits)
