@@ -216,6 +216,45 @@ def test_conv3x3_winograd(hip, ref, case):
         hip.conv_policy = 0
 
 
+def test_conv_wino_gn_handoff_stress(hip):
+    """the last-workgroup GroupNorm finalisation relies on write-through atomics + `s_waitcnt vmcnt(0)` instead of a
+    release / acquire pair (include/dawn_hip.h states the ISA-level assumption).  A stale partial row read by the last workgroup
+    would show up as coefficients that differ from launch to launch (which workgroup is last -- and on which XCD -- varies): both
+    reductions run in FIXED order, so on identical inputs the fused coefficients must be bit-identical on every one of many
+    back-to-back launches, whatever the last workgroup was, and equal the separate reduce + finalize launch over the same rows
+    to fp64-summation rounding.  Grids of 256 workgroups x 2 tiles, 256 x 1 and 16 x 1 (every XCD holds partial rows; short
+    launches: many hand-offs per millisecond), 200 launches per shape without a host synchronisation in between."""
+    from dawn_pytorch_amd.pack import pack_bf3, pack_wino_bf3, unpack_kn
+    try:
+        hip.conv_policy = WINO
+        for (F, H, W, Cc, N) in ((64, 32, 32, 32, 128), (32, 16, 16, 32, 512), (8, 8, 8, 64, 512)):
+            rows = F * H * W
+            x, w = rnd(rows, Cc, seed=21).cuda(), packw(9 * Cc, N, seed=22)
+            kw = dict(F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, w_bf3=pack_bf3(unpack_kn(w)).cuda(),
+                      w_wino=pack_wino_bf3(_w5_from_packed(w, Cc, N)).cuda())
+            wg = w.cuda()
+            gamma, beta = rnd(N, seed=14).cuda() * 0.2 + 1, rnd(N, seed=15).cuda() * 0.2
+            film = (rnd(N, seed=16).cuda() * 0.1, rnd(N, seed=17).cuda() * 0.1)
+            hip.begin_evaluation(x)
+            res = []
+            for rep in range(200):
+                part = hip.conv_gn_part(rows, N, x)
+                out = hip.conv_gemm(x, wg, N, gn_part=part, gn_fin=(gamma, beta, film, rows), **kw)
+                assert part.dawn_ab is not None, "the launch did not finalise the coefficients itself"
+                res.append(part.dawn_ab)
+            torch.cuda.synchronize()
+            a0, b0 = res[0]
+            for a, b in res[1:]:
+                assert torch.equal(a, a0) and torch.equal(b, b0), (F, H, W, Cc, N)
+            part = hip.conv_gn_part(rows, N, x)
+            out = hip.conv_gemm(x, wg, N, gn_part=part, **kw)
+            a1, b1 = hip.gn_coeffs(out, gamma, beta, film, rows, part=part)          # separate reduce + finalize over the same rows
+            check(f"wino_gn_handoff/{F}x{H}x{W}x{Cc}->{N}/a", a0, a1, 1e-6)
+            check(f"wino_gn_handoff/{F}x{H}x{W}x{Cc}->{N}/b", b0, b1, 1e-6)
+    finally:
+        hip.conv_policy = 0
+
+
 def test_conv_wino_is_fp32_accurate(hip, ref):
     """Against an fp64 convolution the Winograd split kernel's error is that of an fp32 Winograd F(2x2,3x3): within 3x the direct
     split kernel's on N(0,1) data with entries spread over 10 decades (the transform adds values of different magnitude in fp32,
