@@ -107,14 +107,26 @@ class stdout_to_stderr:
     """File-descriptor-level redirection of stdout to stderr: RCCL prints its version banner with printf on fd 1 when a communicator
     is created, and bench.py's stdout carries exactly ONE JSON line."""
 
+    @staticmethod
+    def _flush_c_stdio():
+        # RCCL's printf sits in the C library's buffer when stdout is a file or a pipe (fully buffered): without this flush the banner
+        # would leave the buffer at process exit -- AFTER the JSON line, on the restored fd 1
+        try:
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:                                     # noqa: BLE001
+            pass
+
     def __enter__(self):
         sys.stdout.flush()
+        self._flush_c_stdio()
         self._saved = os.dup(1)
         os.dup2(2, 1)
         return self
 
     def __exit__(self, *exc):
         sys.stdout.flush()
+        self._flush_c_stdio()
         os.dup2(self._saved, 1)
         os.close(self._saved)
         return False

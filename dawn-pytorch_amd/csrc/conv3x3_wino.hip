@@ -177,8 +177,12 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     unsigned char* raw0 = smem_b + DTG;
     unsigned char* dtB = smem_b + DTG + RAWB;
     unsigned char* raw1 = smem_b + 2 * DTG + RAWB;
-    float* wsum = reinterpret_cast<float*>(smem_b + 2 * DTG + 2 * RAWB);      // [8 waves][8 subgroups][sum, sumsq]
-    unsigned char* junk = smem_b + 2 * DTG + 2 * RAWB + 512;                   // 1 KB: destination of DMA slots past the end of the patch
+    // GroupNorm sums of this workgroup: [8 waves][8 channel subgroups of the 64-channel tile][sum, sumsq] in fp64, every wave adding
+    // ITS OWN row tile after tile (round 5; round 4 wrote fp32 sums per tile and had threads 0..15 of wave 0 add them up in a chain of
+    // 64 branch-guarded LDS reads per tile: ~5.6 k cycles on the one wave every barrier of the next tile waits for)
+    double* gsw = reinterpret_cast<double*>(smem_b + 2 * DTG + 2 * RAWB);
+    float* wsum = reinterpret_cast<float*>(gsw);                               // (the hand-off flag at the very end reuses the first word)
+    unsigned char* junk = smem_b + 2 * DTG + 2 * RAWB + 1024;                  // 1 KB: destination of DMA slots past the end of the patch
     unsigned char* ex = dtB;
 
     const int tid = threadIdx.x;
@@ -217,7 +221,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     // slot s = wave + 8 i -> 16-pixel segment; lane = (pixel l >> 2, LDS quad slot l & 3), fetching source quad (l & 3) ^ swizzle(column).
     // One register per slot: [31] invalid | [30:24] patch row | [23:22] source quad | [21:0] pixel offset in the window (pyy * W + x)
     // (kept in LDS, 4 B per thread and slot: read back when a piece is issued -- the main loop has no register to spare)
-    unsigned* dtab = reinterpret_cast<unsigned*>(smem_b + 2 * DTG + 2 * RAWB + 512 + 1024);       // [4 slots][512 threads]
+    unsigned* dtab = reinterpret_cast<unsigned*>(smem_b + 2 * DTG + 2 * RAWB + 1024 + 1024);      // [4 slots][512 threads]
     int ddst[4];                                       // (wave-uniform) LDS byte offset of the slot in a raw buffer; past-the-patch slots -> junk
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -314,7 +318,31 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
         for (int j = 0; j < 4; ++j)
 #pragma unroll
             for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
-    double gacc = 0.0;                                 // threads 0..15: this workgroup's GroupNorm partial (group tid >> 1, sum / sumsq), tiles in order
+    double gacc = 0.0;                                 // threads 0..15: this workgroup's GroupNorm partial (group tid >> 1, sum / sumsq)
+    if (tid < 128) gsw[tid] = 0.0;                     // (visible to every wave behind the prologue's barriers)
+    // gn_flush: fold the waves' subgroup sums (tiles of channel offset n0f) into the per-group partials of threads 0..15 and clear
+    // them.  Runs when the next tile has another channel offset and once at the end -- with a grid that is a multiple of N / 64 (256
+    // workgroups, N <= 512) a workgroup only ever sees ONE channel tile, i.e. once per launch.  Fixed order: deterministic.
+    auto gn_flush = [&](int n0f) {
+        __syncthreads();
+        if (tid < 16) {
+            const int which = tid & 1;
+            const int cpg = d.N >> 3;
+            const int lo = (tid >> 1) * cpg - n0f, hi = lo + cpg;            // this group's channel range relative to the tile
+            double a = 0.0;
+#pragma unroll
+            for (int w = 0; w < 8; ++w)
+#pragma unroll
+                for (int jg = 0; jg < 8; ++jg) {
+                    const int c = 8 * jg;
+                    if (c >= lo && c < hi) a += gsw[w * 16 + jg * 2 + which];
+                }
+            gacc += a;
+        }
+        __syncthreads();
+        if (tid < 128) gsw[tid] = 0.0;
+        __syncthreads();
+    };
 
     // weight fragments: one position = 4 fragments (16 registers), TWO positions live: w0 serves tile blocks 0..3 of a phase, w1 blocks
     // 4..7; the next phase's w0 is fetched into w0's registers once it is dead (after block 3), the next phase's w1 at the top of that
@@ -456,8 +484,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
                     a1 += __shfl_xor(a1, 32, 64);  a2 += __shfl_xor(a2, 32, 64);
                     a1 += __shfl_xor(a1, 1, 64);   a2 += __shfl_xor(a2, 1, 64);
                     if (lane < 8 && !(lane & 1)) {
-                        wsum[wave * 16 + (4 * hh + (lane >> 1)) * 2] = a1;
-                        wsum[wave * 16 + (4 * hh + (lane >> 1)) * 2 + 1] = a2;
+                        double* gp = gsw + wave * 16 + (4 * hh + (lane >> 1)) * 2;
+                        gp[0] += (double)a1;
+                        gp[1] += (double)a2;
                     }
                 }
             }
@@ -466,20 +495,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             __builtin_amdgcn_s_barrier();               // the exchange may be overwritten (next half / next tile's phase A)
             WSTAMP();   // epilogue half done
         }
-        if (d.gn_part && tid < 16) {
-            const int which = tid & 1;
-            const int cpg = d.N >> 3;
-            const int lo = (tid >> 1) * cpg - cur.n0, hi = lo + cpg;         // this group's channel range relative to the tile
-            double a = 0.0;
-#pragma unroll
-            for (int w = 0; w < 8; ++w)
-#pragma unroll
-                for (int jg = 0; jg < 8; ++jg) {
-                    const int c = 8 * jg;
-                    if (c >= lo && c < hi) a += (double)wsum[w * 16 + jg * 2 + which];
-                }
-            gacc += a;
-        }
+        if (d.gn_part && has_next && nxt.n0 != cur.n0) gn_flush(cur.n0);      // (wave-uniform; never taken when the grid is a multiple of N / 64)
 #pragma unroll
         for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -494,6 +510,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     // finishes last also reduces the rows (fixed order: deterministic whoever is last) and writes the per-channel coefficients --
     // the separate one-block reduce + finalize launch (40 per evaluation, on the critical path of every ResBlock) is gone
     if (d.gn_part) {
+        const int t_last = t_begin + (t_end - 1 - t_begin) / G * G;        // this workgroup's last tile (recomputed: no loop-carried register)
+        gn_flush((t_last - t_last / nNt * nNt) * 64);
         if (tid < 16) __hip_atomic_store(d.gn_part + (long)blockIdx.x * 16 + tid, gacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (d.gn_a) {
             // (no agent-scope fence: a release would write back the XCD's whole L2 -- the conv output the next kernel is about to read --
@@ -569,7 +587,7 @@ static bool wino_geometry(int F, int H, int W, int C0, int C1, int N, wino_geom&
     const int PI = (P + 15) / 16;                              // 16-pixel DMA segments of a patch
     int RAWB = PI * 1024;
     if (DTG + RAWB < EXHALF) RAWB = EXHALF - DTG;              // (the epilogue's exchange lives in one D~ region + one raw buffer)
-    const size_t lds = (size_t)2 * DTG + (size_t)2 * RAWB + 512 + 1024 + 8192;
+    const size_t lds = (size_t)2 * DTG + (size_t)2 * RAWB + 1024 + 1024 + 8192;
     if (PI > 32 || lds > 160 * 1024) return false;
     g.TR = TR; g.nf = nf; g.PI = PI; g.RAWB = RAWB; g.lds = lds;
     g.ntiles = (int)(M / 256) * (N / 64);
@@ -585,7 +603,8 @@ extern "C" int dawn_conv3x3_wino_ok(int F, int H, int W, int C0, int C1, int N) 
 
 // host-side geometry test + launch; 0 = the shape does not fit (the caller falls back to the direct split kernel)
 int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows) {
-    (void)policy; (void)M;
+    (void)M;
+    if ((policy & 0x4000000) && d.C0 + d.C1 < 128) return 0;      // per-shape policy bit: short-K convs on the direct kernel
     if (!d.w_wino || d.tr || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.mode != 0) return 0;
     if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3))) return 0;
     wino_geom g;

@@ -40,14 +40,16 @@ namespace {
 // 0x1000000 (shipped): conv3x3_bf16_v2_kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction).
 // 0x2000000: the Winograd F(2x2,3x3) form of the split 3x3 conv (conv3x3_wino.hip) where the caller supplies dawn_conv_desc.w_wino and
 // the geometry fits (image width <= 64, even sides): 2.25x fewer matrix-pipe flops.
+// 0x4000000 (A/B, round 5): per-shape choice -- with it, convs of fewer than 128 input channels (K = 576: 4 chunks per tile, the Winograd
+// epilogue is a fifth of such a tile) take the direct split kernel even where the Winograd form fits.
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
 // split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
 constexpr int DAWN_CONV_POLICY_DEFAULT = 0x300580D;
 #ifdef DAWN_ABLATION
-constexpr int DAWN_CONV_POLICY_MASK = 0x030FFFFF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x070FFFFF;
 #else
-constexpr int DAWN_CONV_POLICY_MASK = 0x03F3FFCF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x07F3FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
@@ -1484,13 +1486,17 @@ __global__ __launch_bounds__(256 * WN, K32 ? 2 / WN : 1) void conv3x3_bf16_v2_ke
                 const int which = tid & 1;
                 const int cpg = d.N >> 3;
                 const int lo = (tid >> 1) * cpg - n0, hi = lo + cpg;           // this group's channel range relative to the tile
+                // (branch-free: NW x 8 unconditional LDS reads issued back to back and a select each -- as `if (in range) a += ...` the
+                //  compiler emitted one exec-masked block with its own LDS wait per term, a chain of up to 64 dependent round trips
+                //  at the very end of the workgroup)
                 double a = 0.0;
 #pragma unroll
                 for (int w = 0; w < NW; ++w)
 #pragma unroll
                     for (int jg = 0; jg < 8; ++jg) {
                         const int c = (w % WN) * 64 + 8 * jg;
-                        if (c >= lo && c < hi) a += (double)wsum[w * 16 + jg * 2 + which];
+                        const unsigned keep = (c >= lo && c < hi) ? 0xffffffffu : 0u;       // (a bit mask, not a select: the load cannot sink under it)
+                        a += (double)__uint_as_float(__float_as_uint(wsum[w * 16 + jg * 2 + which]) & keep);
                     }
                 d.gn_part[(long)blockIdx.x * 16 + tid] = a;
             }

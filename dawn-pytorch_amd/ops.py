@@ -226,6 +226,8 @@ class HipOps:
         pol = self.conv_policy or 0x300580D
         if w_wino is None or tr is not None or not (pol & 0x2000000) or not (pol & 0x1000) or (pol & 0x2000):
             return False
+        if (pol & 0x4000000) and C0 + C1 < 128:
+            return False
         return KH == 3 and KW == 3 and stride == 1 and mode == 0 and bool(self.L.dawn_conv3x3_wino_ok(F, H, W, C0, C1, N))
 
     def ln_inline_ok(self, rows: int, N: int, C0: int, C1: int = 0) -> bool:

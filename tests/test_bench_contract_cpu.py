@@ -109,8 +109,11 @@ def test_stdout_redirection_keeps_foreign_prints_off_the_json_stream(tmp_path):
     """RCCL prints its banner with printf on fd 1 when a communicator is created; bench.py's stdout carries one JSON line.  The
     fd-level redirection moves such output to stderr and restores stdout afterwards."""
     import subprocess
-    code = ("import os, sys; sys.path.insert(0, %r); import bench\n"
-            "with bench.stdout_to_stderr():\n    os.write(1, b'RCCL version : banner\\n')\n"
+    # (the banner is written with the C library's buffered printf, as RCCL does: with stdout a pipe it would otherwise sit in the C
+    #  buffer and come out at process exit, AFTER the JSON line -- seen on the GPU box in round 5)
+    code = ("import os, sys, ctypes; sys.path.insert(0, %r); import bench\n"
+            "libc = ctypes.CDLL(None)\n"
+            "with bench.stdout_to_stderr():\n    os.write(1, b'RCCL version : banner\\n'); libc.printf(b'HIP version  : banner2\\n')\n"
             "print('{\"metric\": 1}')\n" % ROOT)
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
-    assert r.returncode == 0 and r.stdout.strip() == '{"metric": 1}' and "banner" in r.stderr
+    assert r.returncode == 0 and r.stdout.strip() == '{"metric": 1}' and "banner" in r.stderr and "banner2" in r.stderr
