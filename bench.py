@@ -590,6 +590,10 @@ def main():
                   "timed region (all 50 steps are timed; the events are sampled to keep their marker packets out of the way)")
 
         KINDS = {
+            "conv3x3_wino4": ("hbm_bytes_per_launch_conv3x3_wino4",
+                              "conv3x3_wino4_kernel (the 64-channel level-0 3x3 ResBlock convs in Winograd F(4x4,3x3) form on the points 0, +-3/4, +-3/2, inf: "
+                              "36 multiplies per 4x4 output tile instead of 144; transformed fp32 operands split exactly into 3 bf16 pieces, 6 cross terms, "
+                              "two per v_mfma_f32_16x16x32_bf16, fp32 accumulate)"),
             "conv3x3_wino": ("hbm_bytes_per_launch_conv3x3_wino",
                              "conv3x3_wino_kernel (3x3 ResBlock convs in Winograd F(2x2,3x3) form: 16 multiplies per 2x2 output tile instead of "
                              "36; transformed fp32 operands split exactly into 3 bf16 pieces, 6 cross terms, two per v_mfma_f32_16x16x32_bf16, "
@@ -619,7 +623,7 @@ def main():
                  "share_of_conv_time": None, "kernel": KINDS[kind][1]}
             if kind != "fp32":
                 # executed bf16 MFMA flops per algorithmic (direct-convolution) flop: 6 cross terms; the Winograd form multiplies 16 / 36 as often
-                ex = 6.0 * (16.0 / 36.0 if kind == "conv3x3_wino" else 1.0)
+                ex = 6.0 * {"conv3x3_wino": 16.0 / 36.0, "conv3x3_wino4": 36.0 / 144.0}.get(kind, 1.0)
                 r.update({"achieved": ex * alg, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": ex * alg / PEAK_BF16_MFMA_TFLOPS,
                           "frac_is": "frac_executed",
                           "frac_executed": ex * alg / PEAK_BF16_MFMA_TFLOPS,
@@ -633,7 +637,7 @@ def main():
                                   "time over the same peak (SURVEY 8d D3's literal definition; its ceiling with 6 terms is "
                                   "1/6); the reference's own arithmetic (fp32) is priced by frac_algorithmic_vs_fp32_mfma_peak; "
                                   "frac_direct_equivalent = the pipe utilisation a DIRECT 6-term conv would need for the same launch time "
-                                  "(= frac_executed unless the launch runs in Winograd form, which issues 16/36 of the direct form's MFMA flops: "
+                                  "(= frac_executed unless the launch runs in a Winograd form, which issues 16/36 -- F(2x2) -- or 36/144 -- F(4x4) -- of the direct form's MFMA flops: "
                                   "its frac_executed falls while its time falls -- compare rounds by avg_launch_us / algorithmic_tflops)"})
             else:
                 r.update({"achieved": alg, "peak": PEAK_FP32_MFMA_TFLOPS, "frac": alg / PEAK_FP32_MFMA_TFLOPS,
@@ -645,7 +649,7 @@ def main():
             if "split-bf16" not in label:
                 return "fp32"
             if " k=3x3 " in label:
-                return "conv3x3_wino" if "winograd" in label else "conv3x3"
+                return "conv3x3_wino4" if "winograd4" in label else ("conv3x3_wino" if "winograd" in label else "conv3x3")
             return "gemm1x1"
 
         groups = {}

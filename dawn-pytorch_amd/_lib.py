@@ -45,6 +45,7 @@ class ConvDesc(C.Structure):
         ("gn_count", C.c_double), ("gn_eps", _f),
         ("gn_a", c_f), ("gn_b", c_f),
         ("gn_ticket", c_f),
+        ("w_wino4", c_f),
     ]
 
 
@@ -53,6 +54,7 @@ SIGNATURES = {
     "dawn_conv_gemm": [C.POINTER(ConvDesc), c_f],
     "dawn_conv_gemm_nblocks": [_l, _i],
     "dawn_conv3x3_wino_ok": [_i, _i, _i, _i, _i, _i],
+    "dawn_conv3x3_wino4_ok": [_i, _i, _i, _i, _i, _i],
     "dawn_gn_partial": [c_f, _l, _i, _i, c_f, _i, c_f],
     "dawn_gn_reduce": [c_f, _i, c_f, c_f],
     "dawn_gn_finalize": [c_f, _d, c_f, c_f, c_f, c_f, _i, _f, c_f, c_f, c_f],

@@ -42,14 +42,17 @@ namespace {
 // the geometry fits (image width <= 64, even sides): 2.25x fewer matrix-pipe flops.
 // 0x4000000 (A/B, round 5): per-shape choice -- with it, convs of fewer than 128 input channels (K = 576: 4 chunks per tile, the Winograd
 // epilogue is a fifth of such a tile) take the direct split kernel even where the Winograd form fits.
+// 0x8000000 (opt-in, round 5): the Winograd F(4x4,3x3) form (conv3x3_wino4.hip) where dawn_conv_desc.w_wino4 is supplied and the geometry
+// fits (image width 64 / 32): 4x fewer matrix-pipe flops than the direct form, weights streamed at 2.25x the F(2x2) rate.  By itself the bit
+// takes the F(4x4) form only for the shape it measured faster on (64 input channels, 64-pixel-wide latent); with 0x10000000 wherever it fits.
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
 // split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
-constexpr int DAWN_CONV_POLICY_DEFAULT = 0x300580D;
+constexpr int DAWN_CONV_POLICY_DEFAULT = 0xB00580D;
 #ifdef DAWN_ABLATION
-constexpr int DAWN_CONV_POLICY_MASK = 0x070FFFFF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x1F0FFFFF;
 #else
-constexpr int DAWN_CONV_POLICY_MASK = 0x07F3FFCF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x1FF3FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)
@@ -2504,6 +2507,7 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 int dawn_conv3x3_sk_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows);   // tools/ubench/conv3x3_sk.hip (experimental build)
 #endif
 int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows); // conv3x3_wino.hip
+int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows); // conv3x3_wino4.hip
 
 #ifdef DAWN_ABLATION
 extern "C" int dawn_conv_set_debug(void* p) {
@@ -2566,6 +2570,14 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         d.Ho == d.Hi && d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
         const bool nine = (policy_of(d) & 0x2000) != 0;
         bool ok = false;
+        if ((policy_of(d) & 0x8000000) && !nine && d.w_wino4) {  // Winograd F(4x4,3x3) form (conv3x3_wino4.hip; opt-in)
+            int rows = 0;
+            if (dawn_conv3x3_wino4_try(d, M, policy_of(d), s, &rows)) {
+                if (d.gn_rows) *d.gn_rows = rows;
+                DAWN_LAUNCH_CHECK();
+                return 0;
+            }
+        }
         if ((policy_of(d) & 0x2000000) && !nine && d.w_wino) {   // Winograd F(2x2,3x3) form (conv3x3_wino.hip)
             int rows = 0;
             if (dawn_conv3x3_wino_try(d, M, policy_of(d), s, &rows)) {

@@ -43,7 +43,7 @@ struct RB {                       // pack.PackedResBlock
     int cond_index = -1, film_off = 0;
     const float *w1 = nullptr, *b1 = nullptr, *g1 = nullptr, *be1 = nullptr, *w2 = nullptr, *b2 = nullptr, *g2 = nullptr,
                 *be2 = nullptr, *wr = nullptr, *br = nullptr;
-    const void *w1s = nullptr, *w2s = nullptr, *wrs = nullptr, *wqs = nullptr, *w1w = nullptr, *w2w = nullptr;
+    const void *w1s = nullptr, *w2s = nullptr, *wrs = nullptr, *wqs = nullptr, *w1w = nullptr, *w2w = nullptr, *w1w4 = nullptr, *w2w4 = nullptr;
     const float *wq = nullptr, *q_scale = nullptr, *g3 = nullptr;
     const float* wo[3] = {nullptr, nullptr, nullptr};
     const void* wos[3] = {nullptr, nullptr, nullptr};
@@ -167,7 +167,7 @@ bool load_rb(dawn_ctx* c, const std::string& p, int Cin, int Co, bool conditione
     rb.Cin = Cin; rb.Co = Co; rb.conditioned = conditioned;
     rb.w1 = F("w1"); rb.b1 = F("b1"); rb.g1 = F("g1"); rb.be1 = F("be1");
     rb.w2 = F("w2"); rb.b2 = F("b2"); rb.g2 = F("g2"); rb.be2 = F("be2");
-    rb.w1s = V("w1s"); rb.w2s = V("w2s"); rb.w1w = V("w1w"); rb.w2w = V("w2w");
+    rb.w1s = V("w1s"); rb.w2s = V("w2s"); rb.w1w = V("w1w"); rb.w2w = V("w2w"); rb.w1w4 = V("w1w4"); rb.w2w4 = V("w2w4");
     if (Cin != Co) { rb.wr = F("wr"); rb.br = F("br"); rb.wrs = V("wrs"); }
     if (conditioned) {
         rb.cond_index = c->n_cond++;
@@ -310,7 +310,7 @@ struct Eval {
     struct ConvArgs {
         const float* in0 = nullptr; int C0 = 0; int ld0 = 0;
         const float* in1 = nullptr; int C1 = 0; int ld1 = 0;
-        const float* w = nullptr; const void* w_bf3 = nullptr; const void* w_wino = nullptr; const float* bias = nullptr; int N = 0;
+        const float* w = nullptr; const void* w_bf3 = nullptr; const void* w_wino = nullptr; const void* w_wino4 = nullptr; const float* bias = nullptr; int N = 0;
         int Fr = 0, Hi = 0, Wi = 0, Ho = 0, Wo = 0, KH = 1, KW = 1, stride = 1, pad = 0, mode = 0;
         const float *row_mean = nullptr, *row_rstd = nullptr;
         float ln_eps = 0.f;
@@ -331,7 +331,7 @@ struct Eval {
         d.KH = a.KH; d.KW = a.KW; d.stride = a.stride; d.pad = a.pad; d.mode = a.mode;
         d.w = a.w; d.bias = a.bias; d.N = a.N; d.row_mean = a.row_mean; d.row_rstd = a.row_rstd; d.ln_eps = a.ln_eps;
         d.res = a.res; d.ld_res = a.ld_res; d.tr = a.tr; d.ld_tr = a.ld_tr; d.tr_a = a.tr_a; d.tr_b = a.tr_b;
-        d.out = a.out; d.ld_out = a.ld_out; d.gn_part = a.gn_part; d.w_bf3 = a.w_bf3; d.w_wino = a.w_wino; d.gn_rows = a.gn_rows;
+        d.out = a.out; d.ld_out = a.ld_out; d.gn_part = a.gn_part; d.w_bf3 = a.w_bf3; d.w_wino = a.w_wino; d.w_wino4 = a.w_wino4; d.gn_rows = a.gn_rows;
         d.policy = c->conv_policy;
         if (a.gn_a && a.gn_part && !sc && gn_ticket) {       // (T-sharded: an all-reduce sits between reduce and finalize)
             d.gn_gamma = a.gn_gamma; d.gn_beta = a.gn_beta; d.gn_fs = a.gn_fs; d.gn_fsh = a.gn_fsh;
@@ -486,7 +486,7 @@ struct Eval {
         {
             ConvArgs a;
             a.in0 = x.p; a.C0 = x.C; a.ld0 = x.C; a.in1 = x2 ? x2->p : nullptr; a.C1 = x2 ? x2->C : 0; a.ld1 = a.C1;
-            a.w = rb.w1; a.w_bf3 = rb.w1s; a.w_wino = rb.w1w; a.bias = rb.b1; a.N = Co; a.Fr = Fr; a.Hi = H; a.Wi = W; a.KH = 3; a.KW = 3; a.pad = 1;
+            a.w = rb.w1; a.w_bf3 = rb.w1s; a.w_wino = rb.w1w; a.w_wino4 = rb.w1w4; a.bias = rb.b1; a.N = Co; a.Fr = Fr; a.Hi = H; a.Wi = W; a.KH = 3; a.KW = 3; a.pad = 1;
             a.out = c1.p; a.ld_out = Co; a.gn_part = part; a.gn_rows = &nblk;
             a.gn_gamma = rb.g1; a.gn_beta = rb.be1; a.gn_fs = fs; a.gn_fsh = fsh; a.gn_a = ab1; a.gn_b = ab1 + Co; a.gn_total_rows = total_rows;
             conv(a);
@@ -515,7 +515,7 @@ struct Eval {
         float* ab2 = falloc(2 * (size_t)Co);
         {
             ConvArgs a;
-            a.in0 = h1.p; a.C0 = Co; a.ld0 = Co; a.w = rb.w2; a.w_bf3 = rb.w2s; a.w_wino = rb.w2w; a.bias = rb.b2; a.N = Co;
+            a.in0 = h1.p; a.C0 = Co; a.ld0 = Co; a.w = rb.w2; a.w_bf3 = rb.w2s; a.w_wino = rb.w2w; a.w_wino4 = rb.w2w4; a.bias = rb.b2; a.N = Co;
             a.Fr = Fr; a.Hi = H; a.Wi = W; a.KH = 3; a.KW = 3; a.pad = 1; a.out = c2.p; a.ld_out = Co; a.gn_part = part2; a.gn_rows = &nblk2;
             a.gn_gamma = rb.g2; a.gn_beta = rb.be2; a.gn_a = ab2; a.gn_b = ab2 + Co; a.gn_total_rows = total_rows;
             conv(a);

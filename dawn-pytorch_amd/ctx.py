@@ -121,7 +121,7 @@ def named_weights(P: PackedUNet) -> Dict[str, Tensor]:
             put(p + f, getattr(a, f))
 
     def rb(p: str, r: PackedResBlock):
-        for f in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "wr", "br", "w1s", "w2s", "w1w", "w2w", "wrs", "wq", "wqs", "q_scale", "g3"):
+        for f in ("w1", "b1", "g1", "be1", "w2", "b2", "g2", "be2", "wr", "br", "w1s", "w2s", "w1w", "w2w", "w1w4", "w2w4", "wrs", "wq", "wqs", "q_scale", "g3"):
             put(p + f, getattr(r, f))
         for f in ("wo", "wos", "mlp_w", "mlp_b", "kv_w", "k_scale", "null_kv"):
             lst = getattr(r, f)

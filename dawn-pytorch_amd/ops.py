@@ -137,7 +137,7 @@ class HipOps:
                   pro_act: int = 0, pro_add: Optional[Tensor] = None, res: Optional[Tensor] = None,
                   tr: Optional[Tuple[Tensor, Tensor, Tensor]] = None, out: Optional[Tensor] = None,
                   gn_part: Optional[Tensor] = None, w_bf3: Optional[Tensor] = None, ln_eps: float = 0.0,
-                  w_wino: Optional[Tensor] = None, gn_fin: Optional[tuple] = None) -> Tensor:
+                  w_wino: Optional[Tensor] = None, gn_fin: Optional[tuple] = None, w_wino4: Optional[Tensor] = None) -> Tensor:
         """gn_fin = (gamma, beta, film or None, total_rows[, eps]) with gn_part: ask the launch to finish the GroupNorm itself (the
         Winograd 3x3 kernel's last workgroup reduces and finalises); gn_coeffs(part=...) then returns its coefficients without a launch."""
         Ho = Hi if Ho is None else Ho
@@ -166,6 +166,7 @@ class HipOps:
         d.gn_part = _p(gn_part)
         d.w_bf3 = _p(w_bf3)
         d.w_wino = _p(w_wino)
+        d.w_wino4 = _p(w_wino4)
         d.policy = self.conv_policy
         d.ln_eps = ln_eps
         if self.sk_ws is not None and w_bf3 is not None and KH == 3 and KW == 3 and stride == 1 and mode == 0:
@@ -199,7 +200,8 @@ class HipOps:
                               f"pro={'r' if row_stats else ('n' if ln_eps else '')}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}"
                               + (" split-bf16" if self._runs_split_kernel(w_bf3, KH, KW, stride, mode, rows_out, N, d.C0, d.C1, tr,
                                                                           gn_part) else "")
-                              + (" winograd" if self._runs_winograd(w_wino, KH, KW, stride, mode, F, Hi, Wi, N, d.C0, d.C1, tr) else ""),
+                              + (" winograd4" if self._runs_winograd4(w_wino4, KH, KW, stride, mode, F, Hi, Wi, N, d.C0, d.C1, tr)
+                                 else (" winograd" if self._runs_winograd(w_wino, KH, KW, stride, mode, F, Hi, Wi, N, d.C0, d.C1, tr) else "")),
                               4.0 * (F * Hi * Wi * (d.C0 + d.C1) + rows_out * N + KH * KW * (d.C0 + d.C1) * N * (4 if mode else 1))))
             return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
@@ -221,9 +223,18 @@ class HipOps:
             return True
         return KH == 1 and KW == 1 and gn_part is None and self.split_gemm_ok(rows, N, C0, C1)
 
+    def _runs_winograd4(self, w_wino4, KH, KW, stride, mode, F, H, W, N, C0, C1, tr) -> bool:
+        """Profiling label only: does this 3x3 launch take the Winograd F(4x4,3x3) form (the library's predicate + its per-shape policy)?"""
+        pol = self.conv_policy or 0xB00580D
+        if w_wino4 is None or tr is not None or not (pol & 0x8000000) or not (pol & 0x1000) or (pol & 0x2000):
+            return False
+        if not (pol & 0x10000000) and not (W == 64 and C0 + C1 == 64):
+            return False
+        return KH == 3 and KW == 3 and stride == 1 and mode == 0 and bool(self.L.dawn_conv3x3_wino4_ok(F, H, W, C0, C1, N))
+
     def _runs_winograd(self, w_wino, KH, KW, stride, mode, F, H, W, N, C0, C1, tr) -> bool:
         """Profiling label only: does this 3x3 launch take the Winograd form (the library's own predicate + the policy bit)?"""
-        pol = self.conv_policy or 0x300580D
+        pol = self.conv_policy or 0xB00580D
         if w_wino is None or tr is not None or not (pol & 0x2000000) or not (pol & 0x1000) or (pol & 0x2000):
             return False
         if (pol & 0x4000000) and C0 + C1 < 128:

@@ -41,27 +41,26 @@ def pack_bf3(w_kn: Tensor) -> Tensor:
     return planes.reshape(3, K // 16, 2, 8, N).permute(1, 0, 2, 4, 3).contiguous()
 
 
-def pack_wino_bf3(w5: Tensor) -> Tensor:
-    """Conv3d weight (Co, Ci, 1, 3, 3) -> the Winograd F(2x2, 3x3) image the split-operand kernel conv3x3_wino_kernel consumes:
-    U = G g G^T per (co, ci) in fp64 (G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]], Lavin & Gray), split into three bf16 planes
-    u = u1 + u2 + u3 (round-to-nearest at every level, residuals exact in fp64: ~26 significant bits), laid out as MFMA A-operand
-    fragments of v_mfma_f32_16x16x32_bf16 in lane order:
-        [Ci/16 chunks][16 positions p = 4 xi + nu][Co/16 blocks][2: W1 = [u1|u2], W2 = [u3|u1]][64 lanes][8] int16,
+def _pack_wino_fragments(w5: Tensor, G: Tensor) -> Tensor:
+    """U = G g G^T per (co, ci) in fp64 (G: (P, 3)), split into three bf16 planes u = u1 + u2 + u3 (round-to-nearest at every level,
+    residuals exact in fp64: ~26 significant bits), laid out as MFMA A-operand fragments of v_mfma_f32_16x16x32_bf16 in lane order:
+        [Ci/16 chunks][P*P positions p = P xi + nu][Co/16 blocks][2: W1 = [u1|u2], W2 = [u3|u1]][64 lanes][8] int16,
     lane = 16 kg + l15 -> output channel 16 cb + l15, input channels 16 chunk + 8 (kg & 1) + 0..7 of plane (kg < 2 ? first : second)."""
     Co, Ci = w5.shape[0], w5.shape[1]
     if not (w5.shape[2:] == (1, 3, 3) and Ci % 16 == 0 and Co % 16 == 0):
         raise ValueError(f"w5.shape[2:] == (1, 3, 3) and Ci % 16 == 0 and Co % 16 == 0: {tuple(w5.shape)}")
+    P = G.shape[0]
     g = w5[:, :, 0].double()                                                        # (Co, Ci, 3, 3)
-    G = torch.tensor([[1.0, 0.0, 0.0], [0.5, 0.5, 0.5], [0.5, -0.5, 0.5], [0.0, 0.0, 1.0]], dtype=torch.float64, device=w5.device)
+    G = G.to(dtype=torch.float64, device=w5.device)
     U = torch.einsum("xk,oikl,nl->oixn", G, g, G)                                   # (Co, Ci, xi, nu)
     u1 = U.float().to(torch.bfloat16)
     r1 = U - u1.double()
     u2 = r1.float().to(torch.bfloat16)
     r2 = r1 - u2.double()
     u3 = r2.float().to(torch.bfloat16)
-    planes = torch.stack((u1, u2, u3), 0).view(torch.int16)                         # (3, Co, Ci, 4, 4)
+    planes = torch.stack((u1, u2, u3), 0).view(torch.int16)                         # (3, Co, Ci, P, P)
     # -> (3, chunk, kh, e, cb, l15, pos)
-    pl = planes.reshape(3, Co // 16, 16, Ci // 16, 2, 8, 16).permute(0, 3, 4, 5, 1, 2, 6)
+    pl = planes.reshape(3, Co // 16, 16, Ci // 16, 2, 8, P * P).permute(0, 3, 4, 5, 1, 2, 6)
     sel = ((0, 1), (2, 0))                                                          # planes of the two k-halves of W1 / W2
     frags = []
     for f in range(2):
@@ -71,7 +70,65 @@ def pack_wino_bf3(w5: Tensor) -> Tensor:
     fr = torch.stack(frags, 0)                                                      # (f, hh, chunk, kh, e, cb, l15, pos)
     # target [chunk][pos][cb][f][kg = 2 hh + kh][l15][e]
     out = fr.permute(2, 7, 5, 0, 1, 3, 6, 4).contiguous()
-    return out.reshape(Ci // 16, 16, Co // 16, 2, 64, 8)
+    return out.reshape(Ci // 16, P * P, Co // 16, 2, 64, 8)
+
+
+WINO2_G = ((1.0, 0.0, 0.0), (0.5, 0.5, 0.5), (0.5, -0.5, 0.5), (0.0, 0.0, 1.0))
+
+# F(4x4, 3x3) on the interpolation points (0, +-3/4, +-3/2, inf): same op count as Lavin's (0, +-1, +-2, inf), every coefficient of
+# B^T / A^T a dyadic rational (exact in fp32), and a third of the rounding error (measured against an fp64 convolution: 1.9e-6 vs
+# 6.3e-6 relative, the direct fp32 form 1.3e-6 -- tools/wino4_points.py).  G[j][k] = p_j^k / prod_{i != j}(p_j - p_i).
+WINO4_POINTS = (0.0, 0.75, -0.75, 1.5, -1.5)
+
+
+def wino4_matrices():
+    """(A^T (4, 6), G (6, 3), B^T (6, 6)) of F(4x4, 3x3) on WINO4_POINTS + infinity, in exact rational arithmetic -> fp64."""
+    from fractions import Fraction as Fr
+    p = [Fr(x) for x in WINO4_POINTS]
+
+    def polymul(a, b):
+        out = [Fr(0)] * (len(a) + len(b) - 1)
+        for i, x in enumerate(a):
+            for j, y in enumerate(b):
+                out[i + j] += x * y
+        return out
+
+    def pw(x, k):
+        return Fr(1) if k == 0 else x ** k
+    M = [Fr(1)]
+    for x in p:
+        M = polymul(M, [-x, Fr(1)])
+    AT = [[pw(p[j], i) for j in range(5)] + [Fr(1 if i == 3 else 0)] for i in range(4)]
+    Gm = []
+    for j in range(5):
+        N = Fr(1)
+        for k in range(5):
+            if k != j:
+                N *= p[j] - p[k]
+        Gm.append([pw(p[j], k) / N for k in range(3)])
+    Gm.append([Fr(0), Fr(0), Fr(1)])
+    BT = []
+    for j in range(5):
+        q = [Fr(1)]
+        for k in range(5):
+            if k != j:
+                q = polymul(q, [-p[k], Fr(1)])
+        BT.append(q + [Fr(0)])
+    BT.append(M)
+    cv = lambda A: torch.tensor([[float(x) for x in row] for row in A], dtype=torch.float64)
+    return cv(AT), cv(Gm), cv(BT)
+
+
+def pack_wino_bf3(w5: Tensor) -> Tensor:
+    """Conv3d weight (Co, Ci, 1, 3, 3) -> the Winograd F(2x2, 3x3) image conv3x3_wino_kernel consumes (G of Lavin & Gray):
+    [Ci/16][16 positions p = 4 xi + nu][Co/16][2][64 lanes][8] int16 (_pack_wino_fragments)."""
+    return _pack_wino_fragments(w5, torch.tensor(WINO2_G, dtype=torch.float64))
+
+
+def pack_wino4_bf3(w5: Tensor) -> Tensor:
+    """Conv3d weight (Co, Ci, 1, 3, 3) -> the Winograd F(4x4, 3x3) image conv3x3_wino4_kernel consumes:
+    [Ci/16][36 positions p = 6 xi + nu][Co/16][2][64 lanes][8] int16 (_pack_wino_fragments with wino4_matrices()'s G)."""
+    return _pack_wino_fragments(w5, wino4_matrices()[1])
 
 
 def pack_bf3_temporal_out(w_kn: Tensor) -> Tensor:
@@ -150,6 +207,8 @@ class PackedResBlock:
     w2s: Optional[Tensor] = None
     w1w: Optional[Tensor] = None          # pack_wino_bf3 images of w1 / w2 (Winograd F(2x2,3x3) form of the split-operand conv)
     w2w: Optional[Tensor] = None
+    w1w4: Optional[Tensor] = None         # pack_wino4_bf3 images (F(4x4,3x3) form; 64-channel convs only; used under policy bit 0x8000000)
+    w2w4: Optional[Tensor] = None
     wrs: Optional[Tensor] = None          # ... of the 1x1 res_conv, of to_q and of the three to_out projections
     wqs: Optional[Tensor] = None
     wos: Optional[List[Tensor]] = None
@@ -299,6 +358,11 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
             rb.w1w = pack_wino_bf3(w1).to(device)
         if Co % 64 == 0:
             rb.w2w = pack_wino_bf3(g(p + "block2.proj.weight")).to(device)
+        # F(4x4,3x3) images (opt-in kernel, policy bit 0x8000000): only for the 64 -> 64 convs it is selected for (1.2 MB each)
+        if Cin == 64 and Co == 64:
+            rb.w1w4 = pack_wino4_bf3(w1).to(device)
+        if Co == 64:
+            rb.w2w4 = pack_wino4_bf3(g(p + "block2.proj.weight")).to(device)
         if has(p + "res_conv.weight"):
             rb.wr = dev(pack_kn(conv_w_kn(g(p + "res_conv.weight"))))
             rb.br = dev(g(p + "res_conv.bias"))

@@ -129,7 +129,7 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
         # GroupNorm partial sums come out of the conv epilogue (no separate statistics pass over c)
         part = ops.conv_gn_part(F * H * W, Co, x)
         c = ops.conv_gemm(x, rb.w1, Co, in1=x2, bias=rb.b1, KH=3, KW=3, pad=1, gn_part=part, w_bf3=rb.w1s, w_wino=rb.w1w,
-                          gn_fin=(rb.g1, rb.be1, film, total_rows), **g)
+                          gn_fin=(rb.g1, rb.be1, film, total_rows), w_wino4=getattr(rb, "w1w4", None), **g)
         return c, ops.gn_coeffs(c, rb.g1, rb.be1, film, total_rows, part=part)
 
     h1 = None
@@ -156,7 +156,7 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
         del c1, hcond
     part2 = ops.conv_gn_part(F * H * W, Co, x)
     c2 = ops.conv_gemm(h1, rb.w2, Co, bias=rb.b2, KH=3, KW=3, pad=1, gn_part=part2, w_bf3=rb.w2s, w_wino=rb.w2w,
-                       gn_fin=(rb.g2, rb.be2, None, total_rows), **g)
+                       gn_fin=(rb.g2, rb.be2, None, total_rows), w_wino4=getattr(rb, "w2w4", None), **g)
     del h1
     a2, b2 = ops.gn_coeffs(c2, rb.g2, rb.be2, None, total_rows, part=part2)
     if rb.wr is not None:

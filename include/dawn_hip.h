@@ -85,20 +85,30 @@ typedef struct dawn_conv_desc {
     double gn_count; float gn_eps;
     float* gn_a; float* gn_b;
     unsigned* gn_ticket;
+    /* round 5 (ABI 7), optional: the Winograd F(4x4,3x3) image of a 3x3 / stride-1 / pad-1 conv (pack.pack_wino4_bf3: [(C0+C1)/16][36
+     * positions][N/16][2][64 lanes][8] bf16 planes of U = G g G^T on the points 0, +-3/4, +-3/2, inf).  With policy bit 0x8000000 (in the
+     * shipped default: it selects the form only for the shape it measured faster on, 64 input channels at image width 64; 0x10000000 adds
+     * every shape dawn_conv3x3_wino4_ok accepts) the conv runs as conv3x3_wino4_kernel (4x fewer
+     * matrix-pipe flops than the direct form, fp32 results to fp32-F(4x4) accuracy: ~2x the direct form's rounding error); the gn_* fields
+     * above are honoured exactly as by the F(2x2) kernel */
+    const void* w_wino4;
 } dawn_conv_desc;
 int dawn_conv_gemm(const dawn_conv_desc* d, void* stream);
 /* 1 when a 3x3 / stride 1 / pad 1 conv of this shape (F frames of H x W pixels, C0 + C1 input channels, N output channels) runs in the
  * Winograd F(2x2,3x3) form once dawn_conv_desc.w_wino is supplied (policy bit 0x2000000, in the shipped default): image width a power
  * of two <= 64, even height, 256-pixel tiles, an even number of 16-channel chunks, N a multiple of 64 */
 int dawn_conv3x3_wino_ok(int F, int H, int W, int C0, int C1, int N);
+/* the same question for the F(4x4,3x3) form (dawn_conv_desc.w_wino4, policy bit 0x8000000): image width 64 or 32, H a multiple of
+ * 256 / W, an even number of 16-channel chunks, N a multiple of 64 */
+int dawn_conv3x3_wino4_ok(int F, int H, int W, int C0, int C1, int N);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;
  * the launch reports the exact count through dawn_conv_desc.gn_rows */
 int dawn_conv_gemm_nblocks(long M, int N);
-/* dawn_conv_desc.policy bits (0 = shipped policy 0x300580D; per call, no process-global state): bit0 BK=32 tiles,
+/* dawn_conv_desc.policy bits (0 = shipped policy 0xB00580D; per call, no process-global state): bit0 BK=32 tiles,
  * bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel,
  * 0x1000 split-operand (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000
  * second-generation split 3x3 kernel, 0x1000000 that kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction: less energy per
- * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops); 0x400 is ignored (round 3's opt-in stream-K variant: experimental builds only).  Every combination computes the same function (tests run the kernel families
+ * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops); 0x4000000 (A/B) the direct kernel for convs of fewer than 128 input channels even where the Winograd form fits (measured slower, not shipped); 0x8000000 (shipped) the Winograd F(4x4,3x3) form where w_wino4 is supplied, dawn_conv3x3_wino4_ok and the shape is the one it measured faster on (64 input channels, image width 64) -- with 0x10000000 wherever it fits; 0x400 is ignored (round 3's opt-in stream-K variant: experimental builds only).  Every combination computes the same function (tests run the kernel families
  * against each other); perf-ablation / s_memtime builds exist only under -DDAWN_ABLATION (tools/build_timing_lib.sh). */
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --

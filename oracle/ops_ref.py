@@ -43,7 +43,7 @@ class RefOps:
     # ------------------------------------------------------------------ conv / linear
     def conv_gemm(self, in0, w, N, *, F, Hi, Wi, Ho=None, Wo=None, KH=1, KW=1, stride=1, pad=0, mode=0, in1=None,
                   bias=None, row_stats=None, ch_ab=None, pro_act=0, pro_add=None, res=None, tr=None, out=None, w_bf3=None,
-                  gn_part=None, ln_eps=0.0, w_wino=None, gn_fin=None):
+                  gn_part=None, ln_eps=0.0, w_wino=None, gn_fin=None, w_wino4=None):
         Ho = Hi if Ho is None else Ho
         Wo = Wi if Wo is None else Wo
         x = in0 if in1 is None else torch.cat((in0, in1), dim=1)

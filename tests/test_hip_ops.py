@@ -286,6 +286,104 @@ def test_conv_wino_is_fp32_accurate(hip, ref):
 
 
 
+# ---------------------------------------------------------------------------------------------- Winograd F(4x4,3x3) split conv (opt-in)
+WINO4 = WINO | 0x8000000 | 0x10000000          # the F(4x4) form wherever its geometry fits (0x8000000 alone: only the shape it wins on)
+WINO4_CASES = [
+    # name, F, H, W, C0, C1, N, extras
+    ("L0_64x64", 3, 64, 64, 64, 0, 64, {"bias": True, "gn": True}),                         # tile = 4 rows x 64 columns: 1 x 16 Winograd tiles
+    ("L0_cat_64p64", 2, 64, 64, 64, 64, 64, {"bias": True, "gn": True}),                    # two sources (skip concat), 8 chunks
+    ("L0_two_chunks_res", 1, 64, 64, 32, 0, 64, {"res": True}),                             # the shortest K; residual epilogue
+    ("L1_32x32_N128", 5, 32, 32, 64, 0, 128, {"bias": True, "gn": True}),                   # tile = 8 rows x 32 columns: 2 x 8 tiles, two channel tiles
+    ("L1_32x32_K1152", 3, 32, 32, 128, 0, 128, {"bias": True, "gn": True}),
+    ("many_tiles_L0", 50, 64, 64, 64, 0, 64, {"bias": True, "gn": True}),                   # 800 tiles on 256 CUs: the flat loop crosses tiles
+    ("many_tiles_L1_N128", 80, 32, 32, 32, 0, 128, {"bias": True, "gn": True}),             # 640 tiles, n0 alternates between the workgroups
+    ("H_not_square_32x64", 2, 32, 64, 32, 0, 64, {"bias": True, "gn": True}),
+    ("H_128_W_32", 1, 128, 32, 32, 0, 64, {"bias": True}),
+]
+
+
+@pytest.mark.parametrize("case", WINO4_CASES, ids=[c[0] for c in WINO4_CASES])
+def test_conv3x3_winograd4(hip, ref, case):
+    """conv3x3_wino4_kernel (Winograd F(4x4,3x3) on the points 0, +-3/4, +-3/2, inf; bf16 pipe with exactly split operands) == the torch
+    conv to fp32-Winograd rounding, bit-deterministic, GroupNorm sums / fused coefficients == a statistics pass over its output, and
+    it really ran (its rounding differs from the F(2x2) kernel's)."""
+    from dawn_pytorch_amd.pack import pack_bf3, pack_wino_bf3, pack_wino4_bf3, unpack_kn
+    name, F, H, W, C0, C1, N, ex = case
+    rows = F * H * W
+    assert hip.L.dawn_conv3x3_wino4_ok(F, H, W, C0, C1, N) == 1
+    in0 = rnd(rows, C0, seed=1)
+    in1 = rnd(rows, C1, seed=2) if C1 else None
+    w = packw(9 * (C0 + C1), N, seed=3)
+    kw = dict(F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1)
+    if ex.get("bias"):
+        kw["bias"] = rnd(N, seed=4)
+    if ex.get("res"):
+        kw["res"] = rnd(rows, N, seed=8)
+    want = ref.conv_gemm(in0, w, N, in1=in1, **kw)
+    gkw = {k_: (v.cuda() if torch.is_tensor(v) else v) for k_, v in kw.items()}
+    w5 = _w5_from_packed(w, C0 + C1, N)
+    gkw.update(w_bf3=pack_bf3(unpack_kn(w)).cuda(), w_wino=pack_wino_bf3(w5).cuda(), w_wino4=pack_wino4_bf3(w5).cuda())
+    x0g, x1g, wg = in0.cuda(), None if in1 is None else in1.cuda(), w.cuda()
+    try:
+        hip.begin_evaluation(x0g)
+        outs = {}
+        for variant in (WINO4, WINO):
+            hip.conv_policy = variant
+            part = hip.conv_gn_part(rows, N, x0g) if ex.get("gn") else None
+            got = hip.conv_gemm(x0g, wg, N, in1=x1g, gn_part=part, **gkw)
+            torch.cuda.synchronize()
+            check(f"conv3x3_wino4/{name}/v{variant:#x}", got, want)
+            outs[variant] = got
+            if part is not None and variant == WINO4:
+                gamma, beta = rnd(N, seed=14).cuda() * 0.2 + 1, rnd(N, seed=15).cuda() * 0.2
+                a1, b1 = hip.gn_coeffs(got, gamma, beta, None, rows, part=part)
+                a2, b2 = hip.gn_coeffs(got, gamma, beta, None, rows)
+                check(f"conv3x3_wino4/{name}/gn_a", a1, a2, 1e-5)
+                check(f"conv3x3_wino4/{name}/gn_b", b1, b2, 1e-5)
+                film = (rnd(N, seed=16).cuda() * 0.1, rnd(N, seed=17).cuda() * 0.1)
+                a3, b3 = hip.gn_coeffs(got, gamma, beta, film, 3 * rows)
+                for rep in range(2):
+                    part2 = hip.conv_gn_part(rows, N, x0g)
+                    got2 = hip.conv_gemm(x0g, wg, N, in1=x1g, gn_part=part2, gn_fin=(gamma, beta, film, 3 * rows), **gkw)
+                    assert part2.dawn_ab is not None and torch.equal(got2, got)
+                    check(f"conv3x3_wino4/{name}/gn_fused_a/{rep}", part2.dawn_ab[0], a3, 1e-5)
+                    check(f"conv3x3_wino4/{name}/gn_fused_b/{rep}", part2.dawn_ab[1], b3, 1e-5)
+        scale = max(1.0, float(want.abs().max()))
+        assert float((outs[WINO4] - outs[WINO]).abs().max()) <= 5e-5 * scale
+        assert not torch.equal(outs[WINO4], outs[WINO])                       # (the F(4x4) kernel really ran: different rounding)
+    finally:
+        hip.conv_policy = 0
+
+
+def test_conv_wino4_is_fp32_accurate(hip, ref):
+    """VERDICT r4 #1b's gate: against an fp64 convolution the F(4x4,3x3) kernel's error stays within 5x the exact-fp32-MFMA kernel's
+    (policy 2061) on N(0,1) data and on data spread over 10 decades (measured ~2x: the points 0, +-3/4, +-3/2 -- tools/wino4_points.py)."""
+    import torch.nn.functional as F_
+    from dawn_pytorch_amd.pack import pack_bf3, pack_wino_bf3, pack_wino4_bf3, unpack_kn
+    F, H, W, Cc, N = 4, 32, 32, 128, 128
+    rows = F * H * W
+    errs = {}
+    for tag, spread in (("n01", False), ("spread", True)):
+        x, w = rnd(rows, Cc, seed=1), packw(9 * Cc, N, seed=2)
+        if spread:
+            x[::7, ::5] *= 1.0e4
+            x[::11, ::3] *= 1.0e-6
+        w4 = unpack_kn(w).double().reshape(3, 3, Cc, N).permute(3, 2, 0, 1)
+        want = F_.conv2d(x.double().reshape(F, H, W, Cc).permute(0, 3, 1, 2), w4, padding=1).permute(0, 2, 3, 1).reshape(rows, N)
+        w5 = _w5_from_packed(w, Cc, N)
+        ws, ww, ww4 = pack_bf3(unpack_kn(w)).cuda(), pack_wino_bf3(w5).cuda(), pack_wino4_bf3(w5).cuda()
+        for variant in (2061, 0x580D | 0x1000000, WINO, WINO4):
+            hip.conv_policy = variant
+            got = hip.conv_gemm(x.cuda(), w.cuda(), N, F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, w_bf3=ws, w_wino=ww, w_wino4=ww4)
+            torch.cuda.synchronize()
+            errs[(tag, variant)] = float((got.cpu().double() - want).abs().max() / want.abs().max())
+    hip.conv_policy = 0
+    with open(LOG, "a") as f:
+        f.write(json.dumps({"op": "conv_wino4/rel_err_vs_fp64", **{f"{t}/{v:#x}": e for (t, v), e in errs.items()}}) + "\n")
+    for tag in ("n01", "spread"):
+        assert errs[(tag, WINO4)] <= 5.0 * errs[(tag, 2061)] + 1e-7, errs
+
+
 @pytest.mark.parametrize("F,H,W,C0,N", [(3, 16, 16, 64, 64), (2, 8, 8, 128, 256), (5, 8, 8, 16, 16), (1, 40, 37, 32, 128),
                                        (12, 8, 8, 16, 32), (12, 4, 4, 64, 32), (12, 8, 8, 48, 16)])
 def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
