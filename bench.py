@@ -580,7 +580,7 @@ def main():
     # (`roofline`); the others are listed beside it (`roofline_other`).
     if prof:
         torch.cuda.synchronize()
-        tp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"))
+        tp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"))
                    if os.path.exists(q)), None)
         pmc = json.load(open(tp)) if (tp and (T, args.res) == (200, 256)) else None
         sampled = diff.use_graph and getattr(ops, "graph_error", None) is None

@@ -166,7 +166,7 @@ __device__ __forceinline__ void wino_phase(const wino_thread& t, const unsigned 
 
 template <int ABL>
 __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_desc d, const int ntiles, const int TR, const int nf,
-                                                              const int PI, const int rawb) {
+                                                              const int PI, const int rawb, const int stagger) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     const int RAWB = rawb;                             // bytes of one raw buffer: >= PI KB ([pixel][64 B], PI 16-pixel DMA segments)
@@ -215,6 +215,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     }
     const int t_end = ntiles;
     if (t_begin >= t_end) return;
+    // start delay (policy bits 20..23, A/B; conv3x3_wino4.hip): `stagger` units of ~1 us times ((workgroup / 8) & 3) de-phase the
+    // workgroups of the persistent launch, whose patch fetches and output stores otherwise hit HBM in lockstep bursts
+    for (int i = 0; i < stagger * ((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(32);
 
     // ---- raw-patch DMA slots of this wave: slot s = wave + 8 i -> (channel quad, 64-pixel segment); lane = pixel.  The patch geometry
     // is the same for every tile; which of its rows fall outside the image depends on the tile's first row y0
@@ -612,10 +615,12 @@ int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream
     const int ntiles = g.ntiles, TR = g.TR, nf = g.nf, PI = g.PI, RAWB = g.RAWB;
     const size_t lds = g.lds;
     const int grid = ntiles < wino_ncu() ? ntiles : wino_ncu();
+    const int sbits = (policy >> 20) & 15;
+    const int stagger = ntiles >= 4 * grid ? (sbits == 15 ? 0 : sbits) : 0;    // (A/B knob, default none)
 #define WINO_LAUNCH(A)                                                                                                      \
     do {                                                                                                                    \
         (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL(conv3x3_wino_kernel<A>, dim3(grid), dim3(512), lds, s, d, ntiles, TR, nf, PI, RAWB);             \
+        hipLaunchKernelGGL(conv3x3_wino_kernel<A>, dim3(grid), dim3(512), lds, s, d, ntiles, TR, nf, PI, RAWB, stagger);    \
     } while (0)
 #ifdef DAWN_ABLATION
     static const int abl = getenv("DAWN_WINO_ABL") ? atoi(getenv("DAWN_WINO_ABL")) : 0;     // perf ablations / s_memtime build (wrong results by design)

@@ -79,7 +79,7 @@ __device__ __forceinline__ w4_row w4_row_of(const int nu) {
 struct w4_thread {
     int ra[4];          // transform: byte offsets in a raw buffer of patch row 0 of this thread's tile at the four columns of its row nu
     int wbase;          // ... and of this thread's word in a D~ buffer at position (xi = 0, nu), plane 0
-    int xo1, xo2;       // MFMA: byte offsets of this lane's X1 = [v1 | v2] / X2 = [v3 | v1] fragments at position 0
+    int xo12, xo21, xo33;   // MFMA: byte offsets of this lane's pixel fragments [v1 | v2], [v2 | v1], [v3 | v3] at position 0
 };
 
 // column pass for patch rows i0 .. i0 + n - 1 of this thread's tile: tr[i] = sum_k k[k] * d[i][col k]   (ROWB = bytes of one patch row)
@@ -113,7 +113,7 @@ __device__ __forceinline__ void w4_store(unsigned char* dtw, const w4_thread& t,
 }
 
 template <int W, int ABL = 0>
-__global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_desc d, const int ntiles) {
+__global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_desc d, const int ntiles, const int stagger) {
 #if __HIP_DEVICE_COMPILE__
     // instrumented build only (-DDAWN_ABLATION, DAWN_WINO4_ABL = 64): s_memtime stamps of lane 0 of every wave, written over the output
     // as [workgroup][wave 12][96]; ABL bits 1 / 2 / 4: no epilogue / no transform / no patch DMA (wrong results by design)
@@ -155,6 +155,9 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
     }
     const int t_end = ntiles;
     if (t_begin >= t_end) return;
+    // start delay (policy bits 20..23, A/B): the workgroups of a persistent launch run in lockstep, so their patch fetches and epilogue
+    // stores hit HBM in bursts; `stagger` units of ~1 us times ((workgroup / 8) & 3) de-phase them in four groups per XCD
+    for (int i = 0; i < stagger * ((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(32);
 
     // ---- transform role: half-wave hw = tid >> 5 -> (tile group hw & 3, nu = hw >> 2 = wave >> 1: wave-uniform); lane & 31 -> (tile in
     // the group, channel pair)
@@ -173,8 +176,9 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
             t.ra[k] = 4 * ty * ROWB + 64 + 64 * tl + 768 * (tl >> 2) + 256 * (c & 3) + (cp >> 1) * 16 + (cp & 1) * 8;
         }
         t.wbase = nu_t * (6 * 256) + (cp >> 2) * 256 + tt * 16 + (cp & 3) * 4;
-        t.xo1 = (xi_w * 36 + kg) * 256 + l15 * 16;
-        t.xo2 = (xi_w * 36 + (kg < 2 ? kg + 4 : kg - 2)) * 256 + l15 * 16;
+        t.xo12 = (xi_w * 36 + kg) * 256 + l15 * 16;                   // D~ slot = 2 plane + k-half: [v1 | v2] = slots 0 1 | 2 3
+        t.xo21 = (xi_w * 36 + (kg ^ 2)) * 256 + l15 * 16;             // [v2 | v1] = slots 2 3 | 0 1
+        t.xo33 = (xi_w * 36 + 4 + (kg & 1)) * 256 + l15 * 16;         // [v3 | v3] = slots 4 5 | 4 5
     }
 
     // ---- raw-patch DMA slots of this wave: segment s = wave + 12 i = (patch row s / (W / 16), 16-pixel group s % (W / 16)); LDS slot = lane
@@ -186,7 +190,7 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
         const int q = i & 15, side = (i >> 4) & 1, r = (i >> 5) % (TR + 2), b = (i >> 5) / (TR + 2);
         *reinterpret_cast<unsigned*>(raw0 + b * RAWB + r * ROWB + side * (ROWB - 64) + q * 4) = 0u;
     }
-    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_wino4, 0, nC * 36 * nCB * 2 * 1024, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)d.w_wino4, 0, nC * 36 * nCB * 1536, 0x00020000);
 
     struct tile_t { int f0, y0, n0, valid; };
     auto setup = [&](int tile, bool valid, tile_t& T) {
@@ -254,16 +258,17 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
                                                      (row >= (unsigned)H || r >= TR + 2) ? OOB4 : voff, (src1 ? cbase - d.C0 : cbase) * 4, 0, 0);
         }
     };
-    // weight fragments of position (xi_w, nu) of chunk cc: [chunk][position 36][channel block N/16][W1 = [u1|u2], W2 = [u3|u1]][lane][16 B];
-    // a chunk index past the end (cc = nC) reads zeros (out of range)
+    // weight fragments of position (xi_w, nu) of chunk cc: [chunk][position 36][channel block N/16][W12 = [u1|u2]: 64 lanes x 16 B | W3 = u3:
+    // 32 lanes x 16 B] (pack.pack_wino4_bf3).  W3 is read with the lane address (lane & 31): both lane halves get u3 -- the fragment
+    // [u3|u3] for 512 unique bytes.  Every byte of the image crosses L2 -> CU once per tile: 221 KB per chunk instead of the 295 KB of
+    // an image that repeats u1 (the loop is bound by exactly that stream).  A chunk index past the end (cc = nC) reads zeros
     auto load_w = [&](int n0, int cc, int nu, bf16x8 (&w)[2][2]) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-            for (int f = 0; f < 2; ++f) {
-                const int fidx = ((cc * 36 + xi_w * 6 + nu) * nCB + (n0 >> 4) + coh * 2 + cb) * 2 + f;
-                w[cb][f] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, lane * 16, fidx * 1024, 0));
-            }
+        for (int cb = 0; cb < 2; ++cb) {
+            const int fbase = ((cc * 36 + xi_w * 6 + nu) * nCB + (n0 >> 4) + coh * 2 + cb) * 1536;
+            w[cb][0] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, lane * 16, fbase, 0));
+            w[cb][1] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rsw, (lane & 31) * 16, fbase + 1024, 0));
+        }
     };
 
     f32x4 acc[6][2];
@@ -353,14 +358,17 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
                 }
                 __builtin_amdgcn_sched_barrier(0);
                 bf16x8 (&w)[2][2] = wr[nu % (WD4 + 1)];
-                const bf16x8 x1 = *reinterpret_cast<const bf16x8*>(dtr + t.xo1 + nu * (6 * 256));
-                const bf16x8 x2 = *reinterpret_cast<const bf16x8*>(dtr + t.xo2 + nu * (6 * 256));
+                const bf16x8 x12 = *reinterpret_cast<const bf16x8*>(dtr + t.xo12 + nu * (6 * 256));
+                const bf16x8 x21 = *reinterpret_cast<const bf16x8*>(dtr + t.xo21 + nu * (6 * 256));
+                const bf16x8 x33 = *reinterpret_cast<const bf16x8*>(dtr + t.xo33 + nu * (6 * 256));
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
+                    // 8 of the 9 cross terms of (u1 + u2 + u3)(v1 + v2 + v3) (all but u3 v3, 2^-32 of the product), two per instruction
                     f32x4 a = acc[nu][cb];
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], x2, a, 0, 0, 0);     // [u1|u2].[v3|v1] = u1 v3 + u2 v1
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], x1, a, 0, 0, 0);     // [u3|u1].[v1|v2] = u3 v1 + u1 v2
-                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], x1, a, 0, 0, 0);     // [u1|u2].[v1|v2] = u1 v1 + u2 v2
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], x12, a, 0, 0, 0);    // [u3|u3].[v1|v2] = u3 v1 + u3 v2
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], x33, a, 0, 0, 0);    // [u1|u2].[v3|v3] = u1 v3 + u2 v3
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], x21, a, 0, 0, 0);    // [u1|u2].[v2|v1] = u1 v2 + u2 v1
+                    a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], x12, a, 0, 0, 0);    // [u1|u2].[v1|v2] = u1 v1 + u2 v2
                     acc[nu][cb] = a;
                 }
                 if (live1 && !(ABL & 2)) {              // (wave-uniform)
@@ -533,7 +541,7 @@ static bool wino4_geometry(int F, int H, int W, int C0, int C1, int N) {
     if ((W != 64 && W != 32) || M % 256 != 0 || C0 % 16 != 0 || C1 % 16 != 0 || N % 64 != 0) return false;
     if ((C0 + C1) % 32 != 0) return false;                     // an even number of 16-channel chunks (buffer parity across tiles)
     if (H % (256 / W) != 0) return false;                      // whole tiles of TR = 256 / W rows inside one frame
-    if ((long)288 * (C0 + C1) * N >= (1L << 31) || (long)F * H >= (1L << 31)) return false;
+    if ((long)216 * (C0 + C1) * N >= (1L << 31) || (long)F * H >= (1L << 31)) return false;   // (image bytes = 36 x 6 per (ci, co) pair)
     return true;
 }
 
@@ -552,12 +560,16 @@ int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStrea
     if (!wino4_geometry(d.F, d.Hi, d.Wi, d.C0, d.C1, d.N)) return 0;
     const int ntiles = (int)(M / 256) * (d.N / 64);
     const int grid = ntiles < wino4_ncu() ? ntiles : wino4_ncu();
+    // start stagger: 4 units by default where a workgroup walks >= 4 tiles (-5 % at the shipped shape, profiles/r5_wino4_stagger.txt);
+    // policy bits 20..23 override it (15 = none)
+    const int sbits = (policy >> 20) & 15;
+    const int stagger = ntiles >= 4 * grid ? (sbits == 15 ? 0 : (sbits ? sbits : 4)) : 0;
     const int W = d.Wi, RAWB = (256 / W + 2) * (W * 64 + 128);
     const size_t lds = (size_t)2 * DT4 + (size_t)2 * RAWB + 1024 + 256;
 #define W4_LAUNCH(WV, A)                                                                                                      \
     do {                                                                                                                     \
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<WV, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((conv3x3_wino4_kernel<WV, A>), dim3(grid), dim3(NT4), lds, s, d, ntiles);                            \
+        hipLaunchKernelGGL((conv3x3_wino4_kernel<WV, A>), dim3(grid), dim3(NT4), lds, s, d, ntiles, stagger);                   \
     } while (0)
 #ifdef DAWN_ABLATION
     static const int abl = getenv("DAWN_WINO4_ABL") ? atoi(getenv("DAWN_WINO4_ABL")) : 0;      // perf ablations / s_memtime build (wrong results by design)

@@ -126,9 +126,18 @@ def pack_wino_bf3(w5: Tensor) -> Tensor:
 
 
 def pack_wino4_bf3(w5: Tensor) -> Tensor:
-    """Conv3d weight (Co, Ci, 1, 3, 3) -> the Winograd F(4x4, 3x3) image conv3x3_wino4_kernel consumes:
-    [Ci/16][36 positions p = 6 xi + nu][Co/16][2][64 lanes][8] int16 (_pack_wino_fragments with wino4_matrices()'s G)."""
-    return _pack_wino_fragments(w5, wino4_matrices()[1])
+    """Conv3d weight (Co, Ci, 1, 3, 3) -> the Winograd F(4x4, 3x3) image conv3x3_wino4_kernel consumes.  U = G g G^T in fp64
+    (wino4_matrices()'s G), split into three bf16 planes u1 + u2 + u3, laid out per (16-channel chunk, position p = 6 xi + nu,
+    16-channel output block) as 768 int16 = 1536 bytes:
+        [ W12: 64 lanes x 8 = the MFMA A fragment [u1 | u2] in lane order | W3: 32 lanes x 8 = u3 for the k-groups 0, 1 ]
+    (lane = 16 kg + l15 -> output channel 16 cb + l15, input channels 16 chunk + 8 (kg & 1) + 0..7, plane u1 for kg < 2, u2 above).
+    The kernel reads W3 with the lane address (lane & 31): both lane halves get u3, i.e. the fragment [u3 | u3] for 512 unique bytes --
+    every byte of the image is fetched once per workgroup tile (the F(2x2) image repeats u1 in its second fragment), and the four
+    products W12.[v1|v2], W12.[v2|v1], W12.[v3|v3], W3.[v1|v2] are 8 of the 9 cross terms (all but u3 v3)."""
+    fr = _pack_wino_fragments(w5, wino4_matrices()[1])                              # (chunk, 36, cb, f, 64, 8): f 0 = [u1|u2], f 1 = [u3|u1]
+    w12 = fr[:, :, :, 0].reshape(*fr.shape[:3], 512)
+    w3 = fr[:, :, :, 1, :32].reshape(*fr.shape[:3], 256)                            # lanes 0..31 of [u3|u1] = u3 of k-groups 0, 1
+    return torch.cat((w12, w3), dim=-1).contiguous()                                # (chunk, 36, cb, 768)
 
 
 def pack_bf3_temporal_out(w_kn: Tensor) -> Tensor:

@@ -86,7 +86,8 @@ typedef struct dawn_conv_desc {
     float* gn_a; float* gn_b;
     unsigned* gn_ticket;
     /* round 5 (ABI 7), optional: the Winograd F(4x4,3x3) image of a 3x3 / stride-1 / pad-1 conv (pack.pack_wino4_bf3: [(C0+C1)/16][36
-     * positions][N/16][2][64 lanes][8] bf16 planes of U = G g G^T on the points 0, +-3/4, +-3/2, inf).  With policy bit 0x8000000 (in the
+     * positions][N/16][768 bf16 = the fragment [u1|u2] in lane order, then u3 of the k-groups 0, 1] of U = G g G^T on the points 0, +-3/4,
+     * +-3/2, inf: every plane once, 8 of the 9 cross terms).  With policy bit 0x8000000 (in the
      * shipped default: it selects the form only for the shape it measured faster on, 64 input channels at image width 64; 0x10000000 adds
      * every shape dawn_conv3x3_wino4_ok accepts) the conv runs as conv3x3_wino4_kernel (4x fewer
      * matrix-pipe flops than the direct form, fp32 results to fp32-F(4x4) accuracy: ~2x the direct form's rounding error); the gn_* fields

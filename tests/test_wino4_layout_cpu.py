@@ -108,14 +108,14 @@ def test_wino4_kernel_index_contract(W):
                 banks += [(a // 4) % 64, (a // 4 + 1) % 64]
             assert len(set(banks)) == 64, (W, hw, kk)
     # ---- MFMA: wave (xi_w, coh), fragments per the lane maps; weights from the packed image by fragment index
-    wimg = pack_wino4_bf3(torch.from_numpy(w5)).numpy()                           # (1, 36, N/16, 2, 64, 8) int16
+    wimg = pack_wino4_bf3(torch.from_numpy(w5)).numpy()                           # (1, 36, N/16, 768) int16
     acc = np.zeros((12, 6, 2, 64, 4))                                             # [wave][nu][cb][lane][e]
     for wave in range(12):
         xi_w, coh = wave >> 1, wave & 1
         for nu in range(6):
             pos = xi_w * 6 + nu
             X = {}
-            for name, sel in (("x1", lambda kg: kg), ("x2", lambda kg: kg + 4 if kg < 2 else kg - 2)):
+            for name, sel in (("x12", lambda kg: kg), ("x21", lambda kg: kg ^ 2), ("x33", lambda kg: 4 + (kg & 1))):
                 fr = np.zeros((64, 8))
                 for lane in range(64):
                     l15, kg = lane & 15, lane >> 4
@@ -123,7 +123,9 @@ def test_wino4_kernel_index_contract(W):
                     fr[lane] = bf16_to_f64(dt[a:a + 8].view(np.int16))
                 X[name] = fr
             for cb in range(2):
-                Wf = [bf16_to_f64(wimg[0, pos, coh * 2 + cb, f]) for f in range(2)]       # (64, 8)
+                img = wimg[0, pos, coh * 2 + cb]                                  # 768 int16: [W12 64 x 8 | W3 32 x 8]
+                W12 = bf16_to_f64(img[:512].reshape(64, 8))
+                W3 = bf16_to_f64(np.stack([img[512 + 8 * (lane & 31):512 + 8 * (lane & 31) + 8] for lane in range(64)]))   # lane address (lane & 31)
 
                 def mfma(A, B):          # D[co][tile] = sum_k A[co][k] B[k][tile]; lane = 16 kg + l15: A row l15 / B column l15, k = 8 kg + e
                     Am = np.zeros((16, 32)); Bm = np.zeros((32, 16))
@@ -132,7 +134,7 @@ def test_wino4_kernel_index_contract(W):
                         Bm[8 * (lane >> 4):8 * (lane >> 4) + 8, lane & 15] = B[lane]
                     D = Am @ Bm
                     return np.stack([D[4 * (lane >> 4):4 * (lane >> 4) + 4, lane & 15] for lane in range(64)])   # lane: tile l15, channels 4 kg + e
-                acc[wave, nu, cb] = mfma(Wf[0], X["x2"]) + mfma(Wf[1], X["x1"]) + mfma(Wf[0], X["x1"])
+                acc[wave, nu, cb] = mfma(W3, X["x12"]) + mfma(W12, X["x33"]) + mfma(W12, X["x21"]) + mfma(W12, X["x12"])
     # ---- epilogue: nu half in registers, xi half through the exchange, two halves of output columns
     out = np.full((TR, W, N), np.nan)
     A = AT

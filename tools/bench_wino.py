@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--wino-only", action="store_true")
     ap.add_argument("--extra-policy", type=lambda v: int(v, 0), default=0, help="a third policy to time (A/B of kernel variants)")
     ap.add_argument("--check", action="store_true", help="compare the extra policy's output with the Winograd one (bit-identical expected)")
+    ap.add_argument("--stagger", type=int, nargs="*", default=[], help="with --wino4: also time start-stagger units (policy bits 20..23)")
     ap.add_argument("--wino4", action="store_true", help="also time the F(4x4,3x3) kernel (policy bit 0x8000000) where its geometry fits")
     ap.add_argument("--stamps4", action="store_true", help="F(4x4) instrumented build (tools/build_wino4_timing_lib.sh, DAWN_WINO4_ABL=64): per-wave s_memtime timeline")
     ap.add_argument("--stamps", action="store_true", help="instrumented build (DAWN_WINO_ABL=64): print the s_memtime timeline of a few workgroups")
@@ -102,8 +103,12 @@ def main():
             pols = [("wino", WINO)] if a.wino_only else [("direct", DIRECT), ("wino", WINO)]
             if a.extra_policy:
                 pols.append(("extra", a.extra_policy))
+            for sg in a.stagger:
+                pols.append((f"wino+stagger{sg}", WINO | (sg << 20)))
             if w4ok:
                 pols.append(("wino4", WINO | 0x18000000))
+                for sg in a.stagger:
+                    pols.append((f"wino4+stagger{sg}", WINO | 0x18000000 | (sg << 20)))
             for name, pol in pols:
                 ops.conv_policy = pol
                 part = ops.conv_gn_part(rows, N, x0)
@@ -131,6 +136,10 @@ def main():
                 torch.cuda.synchronize()
                 same = f"  max|diff| {float((o1 - o2).abs().max()):.2e}"
             print(f"   extra policy {a.extra_policy:#x}: {ex_:8.1f} us  {(ex_ / wn - 1) * 100:+.1f} % vs winograd{same}")
+        for sg in a.stagger:
+            print(f"   F(2x2) + start stagger {sg}: {min(res[f'wino+stagger{sg}']):8.1f} us")
+        for sg in (a.stagger if w4ok else []):
+            print(f"   F(4x4) + start stagger {sg}: {min(res[f'wino4+stagger{sg}']):8.1f} us")
         if w4ok:
             w4t = min(res["wino4"])
             o1, o2 = torch.empty_like(out), torch.empty_like(out)

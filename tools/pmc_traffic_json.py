@@ -46,7 +46,8 @@ def main():
                        "half-count of MI355X_MICROARCH.md holds for 16 B/lane loads; WRITE_SIZE is exact",
         "hbm_bytes_per_launch": (2.0 * f + w) / n * 1024.0,
         "hbm_bytes_per_launch_split_bf16": per_class(lambda k: is_conv(k) and ("bf16" in k or "wino" in k)),
-        "hbm_bytes_per_launch_conv3x3_wino": per_class(lambda k: k.startswith("conv3x3_wino")),
+        "hbm_bytes_per_launch_conv3x3_wino": per_class(lambda k: k.startswith("conv3x3_wino_kernel")),
+        "hbm_bytes_per_launch_conv3x3_wino4": per_class(lambda k: k.startswith("conv3x3_wino4")),
         "hbm_bytes_per_launch_conv3x3_bf16": per_class(lambda k: k.startswith("conv3x3_bf16") or k.startswith("conv3x3_halo_bf16")),
         "hbm_bytes_per_launch_gemm1x1_bf16": per_class(lambda k: k.startswith("gemm1x1_")),
         "hbm_bytes_per_launch_fp32": per_class(lambda k: is_conv(k) and "bf16" not in k and "wino" not in k and not k.startswith("gemm1x1_")),

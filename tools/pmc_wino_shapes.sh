@@ -10,6 +10,8 @@ OUT=${1:-/root/repo/gpurun_out/pmc_wino_shapes}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace \
   -d $OUT/run -o p -- python /root/repo/tools/bench_wino.py --wino-only --iters 1 > $OUT/run.log 2>&1
+timeout 600 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA SQ_INSTS_VALU SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace \
+  -d $OUT/run4 -o p -- python /root/repo/tools/bench_wino.py --wino4 --iters 1 --only 0 1 2 3 > $OUT/run4.log 2>&1
 cd /root/repo
 python - "$OUT" <<'PY'
 import collections, glob, sqlite3, sys
@@ -51,10 +53,39 @@ for si, (F, H, W, C0, C1, N) in enumerate(SHAPES):
     lines.append(f"| {M} | {N} | {K} | {M // 256 * (N // 64)} | {m.get('SQ_INSTS_MFMA', 0):.4g} | {m.get('SQ_INSTS_VALU', 0):.4g} | "
                  f"{m.get('SQ_INSTS_VALU', 0) / max(m.get('SQ_INSTS_MFMA', 1), 1):.2f} | {busy:.4g} | {cyc:.4g} | {busy / (cyc * 1024) if cyc else float('nan'):.3f} | "
                  f"{ex / 1e12:.3f} | {alg / 1e9:.2f} | {ex / alg:.3f} |")
+# ---- the F(4x4,3x3) kernel on the four level-0 / level-1 shapes its geometry takes (shipped for the first one only)
+db4s = glob.glob(out + "/run4/**/*.db", recursive=True)
+if db4s:
+    db4 = sqlite3.connect(db4s[0])
+    per4 = collections.OrderedDict()
+    for r in db4.execute("select * from counters_collection order by dispatch_id"):
+        if "conv3x3_wino4" not in str(r[ci[name_col]]):
+            continue
+        per4.setdefault(r[ci["dispatch_id"]], {})
+        per4[r[ci["dispatch_id"]]][r[ci["counter_name"]]] = per4[r[ci["dispatch_id"]]].get(r[ci["counter_name"]], 0.0) + float(r[ci["value"]])
+    d4 = list(per4.values())
+    n4 = max(1, len(d4) // 4)
+    lines += ["", f"## conv3x3_wino4_kernel (F(4x4,3x3); {len(d4)} dispatches = {n4} per shape, medians; executed / algorithmic = 6 x 36/144 = 1.5 by construction)", "",
+              "| M | N | K | tiles | MFMA insts | VALU insts | VALU / MFMA | MFMA busy cycles | shader cycles | matrix pipe busy | executed TFLOP | algorithmic GFLOP | executed / algorithmic |",
+              "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
+    for si, (F, H, W, C0, C1, N) in enumerate(SHAPES[:4]):
+        g = d4[si * n4:(si + 1) * n4]
+        if not g:
+            continue
+        m = {k: med([d.get(k, 0.0) for d in g]) for k in g[0]}
+        M, K = F * H * W, 9 * (C0 + C1)
+        cyc = m.get("GRBM_GUI_ACTIVE", 0.0) / 8.0
+        busy = m.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+        ex = m.get("SQ_INSTS_MFMA", 0.0) * 16384.0
+        alg = 2.0 * M * N * K
+        lines.append(f"| {M} | {N} | {K} | {M // 256 * (N // 64)} | {m.get('SQ_INSTS_MFMA', 0):.4g} | {m.get('SQ_INSTS_VALU', 0):.4g} | "
+                     f"{m.get('SQ_INSTS_VALU', 0) / max(m.get('SQ_INSTS_MFMA', 1), 1):.2f} | {busy:.4g} | {cyc:.4g} | {busy / (cyc * 1024) if cyc else float('nan'):.3f} | "
+                     f"{ex / 1e12:.3f} | {alg / 1e9:.2f} | {ex / alg:.3f} |")
 lines += ["", "(executed / algorithmic = 6 cross terms x 16/36 Winograd multiplies = 2.667 by construction: a check that the counters see the whole launch;",
           " the HIP-event time of the same launches is in run.log -- frac_executed = executed TFLOP / time / 2.5 PFLOP/s)"]
 open(out + "/pmc_wino_shapes.md", "w").write("\n".join(lines) + "\n")
 print("\n".join(lines))
 PY
 cp $OUT/run.log $OUT/bench_wino_under_pmc.log 2>/dev/null
+cat $OUT/run4.log >> $OUT/bench_wino_under_pmc.log 2>/dev/null
 find $OUT -name "*.db" -delete

@@ -15,8 +15,8 @@ F=$(find $O/${TAG}_pmc/fetch -name "*.db" | head -1); W=$(find $O/${TAG}_pmc/wri
 python $R/tools/pmc_traffic_json.py $F $W $O/${TAG}_pmc_traffic.json > $O/${TAG}_pmc_traffic.log 2>&1
 python $R/tools/pmc_hbm_by_kernel.py $F $W 2 > $O/${TAG}_hbm_by_kernel.md 2>&1
 find $O/${TAG}_pmc -name "*.db" -delete
-bash $R/tools/pmc_mfma_util.sh $O/${TAG}_pmc_mfma > /dev/null 2>&1
-cp $O/${TAG}_pmc_mfma/mfma_util.md $O/${TAG}_pmc_mfma_util.md 2>/dev/null
+bash $R/tools/pmc_wino_shapes.sh $O/${TAG}_pmc_wino_shapes > /dev/null 2>&1
+cp $O/${TAG}_pmc_wino_shapes/pmc_wino_shapes.md $O/${TAG}_pmc_wino_by_shape.md 2>/dev/null
 cd $R
 (timeout 600 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|error" | tail -3) > $O/${TAG}_pytest.log
 head -12 $O/${TAG}_kernel_trace_summary.md; cat $O/${TAG}_pytest.log; head -5 $O/${TAG}_hbm_by_kernel.md
