@@ -157,7 +157,7 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
     if (t_begin >= t_end) return;
     // start delay (policy bits 20..23, A/B): the workgroups of a persistent launch run in lockstep, so their patch fetches and epilogue
     // stores hit HBM in bursts; `stagger` units of ~1 us times ((workgroup / 8) & 3) de-phase them in four groups per XCD
-    for (int i = 0; i < stagger * ((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(32);
+    for (int i = 0; i < (stagger & 7) * ((blockIdx.x >> 3) & ((stagger & 8) ? 7 : 3)); ++i) __builtin_amdgcn_s_sleep(32);   // (bit 3: eight phases)
 
     // ---- transform role: half-wave hw = tid >> 5 -> (tile group hw & 3, nu = hw >> 2 = wave >> 1: wave-uniform); lane & 31 -> (tile in
     // the group, channel pair)

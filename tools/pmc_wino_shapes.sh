@@ -65,7 +65,7 @@ if db4s:
         per4[r[ci["dispatch_id"]]][r[ci["counter_name"]]] = per4[r[ci["dispatch_id"]]].get(r[ci["counter_name"]], 0.0) + float(r[ci["value"]])
     d4 = list(per4.values())
     n4 = max(1, len(d4) // 4)
-    lines += ["", f"## conv3x3_wino4_kernel (F(4x4,3x3); {len(d4)} dispatches = {n4} per shape, medians; executed / algorithmic = 6 x 36/144 = 1.5 by construction)", "",
+    lines += ["", f"## conv3x3_wino4_kernel (F(4x4,3x3); {len(d4)} dispatches = {n4} per shape, medians; executed / algorithmic = 8 cross terms x 36/144 = 2.0 by construction)", "",
               "| M | N | K | tiles | MFMA insts | VALU insts | VALU / MFMA | MFMA busy cycles | shader cycles | matrix pipe busy | executed TFLOP | algorithmic GFLOP | executed / algorithmic |",
               "|---|---|---|---|---|---|---|---|---|---|---|---|---|"]
     for si, (F, H, W, C0, C1, N) in enumerate(SHAPES[:4]):
