@@ -1,25 +1,27 @@
 // Winograd F(4x4, 3x3) form of the split-operand 3x3 convolution (gfx950), round 5: 4x fewer matrix-pipe flops than the direct form
 // (36 multiplies per 4x4 output tile and (cin, cout) pair instead of 144), 1.78x fewer than conv3x3_wino.hip's F(2x2, 3x3) -- and
 // 2.25 instead of 4 transformed (and exactly split) input values per pixel.  Same function as conv3x3_bf16_v2_kernel / conv3x3_wino_kernel:
-// a stride-1 3x3 ResBlock conv (MT:229 Block.proj inside MT:233-248), fp32 in / fp32 out, channels-last.  Opt-in (policy bit 0x8000000
-// + dawn_conv_desc.w_wino4): whether it beats F(2x2) is a measurement (profiles/r5_wino4_*), see DESIGN 4.
+// a stride-1 3x3 ResBlock conv (MT:229 Block.proj inside MT:233-248), fp32 in / fp32 out, channels-last.  Policy bit 0x8000000 (in the
+// shipped default) + dawn_conv_desc.w_wino4 select it for the ONE shape it measured faster on -- 64 input channels at a 64-pixel-wide
+// latent: -8.7 % isolated, -3.5..-9 % in situ --, bit 0x10000000 wherever its geometry fits (profiles/r5_wino4_*).
 //
 // Arithmetic.  Y = A^T [ (G g G^T) . (B^T d B) ] A per 4x4 output tile on the interpolation points (0, +-3/4, +-3/2, inf)
 // (pack.wino4_matrices(): every coefficient of B^T / A^T is a dyadic rational, exact in fp32; a third of the rounding error of the
 // textbook points 0, +-1, +-2 -- tools/wino4_points.py):
 //   * weights: U = G g G^T on the HOST in fp64, split into three bf16 planes (pack.pack_wino4_bf3);
-//   * data:    V = B^T d B in fp32 FMAs here, then split EXACTLY into three bf16 planes (truncation split) -- the same 6 cross terms,
-//              two per v_mfma_f32_16x16x32_bf16, fp32 accumulate, as every split kernel of this library;
+//   * data:    V = B^T d B in fp32 FMAs here, then split EXACTLY into three bf16 planes (truncation split); 8 of the 9 cross terms
+//              (all but u3 v3), two per v_mfma_f32_16x16x32_bf16, fp32 accumulate -- the weight image holds every plane once
+//              ([u1|u2] + u3), the fourth instruction buys 25 % fewer weight bytes, which is what bounds this kernel;
 //   * output:  A^T M A in fp32.
 // Error vs an fp64 convolution: that of an fp32 F(4x4,3x3) on these points (tests/test_hip_ops.py::test_conv_wino4_is_fp32_accurate).
 //
 // Workgroup = 256 output pixels (16 Winograd tiles: TR = 256 / W rows x W columns of one frame) x 64 output channels, 12 waves
 // (3 per SIMD, 168 registers each), persistent over tiles like conv3x3_wino_kernel.  The accumulators of the 36 positions x 16 tiles x
 // 64 channels (147 KB) are what bounds the tile: every weight fragment feeds ONE 16-tile block, so the weights stream L2 -> registers at
-// 295 KB per 16-channel chunk and workgroup (tools/ubench/wino_stream.hip: the main loop is L2-bandwidth bound at ~27 TB/s).
+// 221 KB per 16-channel chunk and workgroup (tools/ubench/wino_stream.hip: the main loop is bound by the CU's vector-memory pipeline).
 // Per 16-channel chunk ONE step with ONE barrier:
-//   DMA        the raw patch rows (TR+2) x W x 16 fp32 of the chunk AFTER NEXT, global -> LDS (rows above / below the image = out-of-range
-//              offsets = zeros), one patch row = [64 B zero | W pixels | 64 B zero] (a tile spans the image width, so the halo COLUMNS are
+//   DMA        the raw patch rows (TR+2) x W x 16 fp32 of the chunk AFTER NEXT, global -> LDS, issued by the four OLDEST waves (rows above /
+//              below the image = out-of-range offsets = zeros), one patch row = [64 B zero | W pixels | 64 B zero] (a tile spans the image width, so the halo COLUMNS are
 //              always padding: zeroed once), the pixels in 16-pixel segments of 1 KB laid out [column & 3][tile & 3][channel quad], so
 //              that the transform's 8-byte reads -- four tiles 4 pixels apart x 8 channel pairs per half-wave -- cover 256 contiguous
 //              bytes (conflict-free) and a tile's neighbours (columns -1 and 4) are the adjacent 64-byte slots, halo included;
@@ -28,6 +30,10 @@
 //              18 ds_write_b32 into the NEXT chunk's D~ = [position][plane][k-half][tile][16 B], cut into slices between the MFMA blocks;
 //   MFMA       wave = (row position xi, 32-channel half): positions (xi, 0..5) x 16 tiles x 32 channels = 36 MFMAs; pixel fragments
 //              from the current D~, weight fragments straight from L2 two positions ahead.
+// Three facts of the CU's memory pipeline shape the rest (profiles/r5_wino4_stamps_and_ablations_v1.txt): VMEM returns in order per CU (an
+// HBM-missing patch piece delays every wave's weight fetches) -> every 128-byte line of the next tiles' patches is touched once in the
+// epilogue; the oldest wave of a SIMD reaches the barrier first -> it issues the patch DMA; 256 workgroups in lockstep hit HBM in
+// bursts -> a start stagger.
 // Epilogue: the nu half of A^T M A in registers (6 accumulators -> 4), the xi half across the six row-position waves through LDS in two
 // halves (output columns {0,1} / {2,3} of every tile: all 12 waves write, 8 read), bias (+ residual), 16-byte row-segment stores,
 // GroupNorm(8) sums per wave in fp64 across tiles, one gn_part row per workgroup and -- with dawn_conv_desc.gn_a -- the coefficients from
