@@ -34,6 +34,7 @@
 // Epilogue: the nu half of A^T M A in registers (4 accumulators -> 2), the xi half across the four row-position waves through
 // LDS (8 values per (tile, channel) instead of 16; one 32-channel half at a time in the D~ region + raw buffer the next tile does not
 // need yet), then bias (+ residual), 16-byte row-segment stores and GroupNorm(8) partials (one gn_part row per workgroup; optionally the coefficients themselves).
+#include <type_traits>
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 #include <cstdlib>
@@ -105,7 +106,8 @@ __device__ __forceinline__ void wino_transform(const wino_thread& t, const unsig
 // between them: raw reads up front, the column / row combinations behind the first two tile blocks, one row position's split +
 // stores behind each of the next four.  The three LDS regions are distinct (restrict: the scheduler may move the stores across the
 // fragment reads).
-template <int G, int ABL, typename MidLoad>
+// FIRST: the tile's first chunk -- the accumulators start from the instruction's zero operand (no clearing pass after the epilogue)
+template <int G, int ABL, bool FIRST, typename MidLoad>
 __device__ __forceinline__ void wino_phase(const wino_thread& t, const unsigned char* __restrict__ dtr, unsigned char* __restrict__ dtw,
                                            const unsigned char* __restrict__ raw, bf16x8 (&w0)[2][2], const bf16x8 (&w1)[2][2],
                                            f32x4 (&acc)[4][4][2], MidLoad mid_load) {
@@ -133,7 +135,9 @@ __device__ __forceinline__ void wino_phase(const wino_thread& t, const unsigned 
         }
 #pragma unroll
         for (int cb = 0; cb < 2; ++cb) {
-            f32x4 a = acc[2 * G + nl][b][cb];
+            f32x4 a;
+            if constexpr (FIRST) a = f32x4{0.f, 0.f, 0.f, 0.f};
+            else a = acc[2 * G + nl][b][cb];
             const bf16x8 wa = nl ? w1[cb][0] : w0[cb][0], wb = nl ? w1[cb][1] : w0[cb][1];
             if (ABL & 4) { a = a + __builtin_bit_cast(f32x4, wa) + __builtin_bit_cast(f32x4, x2) + __builtin_bit_cast(f32x4, wb) + __builtin_bit_cast(f32x4, x1); acc[2 * G + nl][b][cb] = a; continue; }
             a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, x2, a, 0, 0, 0);     // [u1|u2].[v3|v1] = u1 v3 + u2 v1
@@ -255,6 +259,23 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
         T.y0 = grow0 - T.f0 * H;
         T.valid = valid ? 1 : 0;
     };
+    // a workgroup's tiles are G apart: the column tile and the image row advance by constants (divisions once per launch, not per tile and
+    // wave: an integer division is ~30 vector instructions, and the epilogue is bound by the vector instructions of its two waves per
+    // SIMD -- profiles/r5_wino_valu_breakdown_static.md).  `valid` false: a copy of A that nobody fetches
+    const int trr_ = 256 / W;                                            // image rows per tile (several frames of a small image)
+    const int dmt_ = G / nNt, dn0_ = (G - dmt_ * nNt) * 64;
+    const int df_ = dmt_ * trr_ / H, dy_ = dmt_ * trr_ - df_ * H;
+    const int cf_ = trr_ / H, cy_ = trr_ - cf_ * H;                      // the carry of the column tile: one tile of rows
+    auto advance = [&](const tile_t& A, bool valid, tile_t& T) {
+        int n0 = A.n0 + dn0_, y0 = A.y0 + dy_, f0 = A.f0 + df_;
+        if (n0 >= d.N) { n0 -= d.N; y0 += cy_; f0 += cf_; }
+        if (y0 >= H) { y0 -= H; ++f0; }
+        if (y0 >= H) { y0 -= H; ++f0; }                  // (y0, dy_, cy_ < H: below 3 H)
+        T.n0 = valid ? n0 : A.n0;
+        T.f0 = valid ? f0 : A.f0;
+        T.y0 = valid ? y0 : A.y0;
+        T.valid = valid ? 1 : 0;
+    };
     // A patch fetch is issued in pieces right behind the weight fetches of a phase (see the main loop): an HBM-missing patch streams at
     // ~11 B/clk per CU, and a wave that issues its whole share at once sits at the issue port for that long (measured: +1.6..8 k cycles
     // on the phase) -- the MFMAs behind it wait.  `fetch_t` = what a piece needs, prepared outside the phases
@@ -300,6 +321,17 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
         t.xo2 = (xi_w * 6 + (kg < 2 ? kg + 4 : kg - 2)) * 1024 + l15 * 16;
     }
     const int eq = tid & 7;                            // epilogue unit: Winograd tile tid >> 3, 4-channel quad eq of the 32-channel half
+    int eoff;                                          // byte offset of the unit in an exchange plane
+    unsigned vo_out, vo_res;                           // byte offset of (pixel (0, 0) of the unit's tile, channel 4 eq) from the tile's first pixel
+    {
+        const int et = tid >> 3;
+        const int efi = et / TPF, erem = et - efi * TPF;
+        const int ety2 = erem / TX, etx2 = erem - ety2 * TX;
+        const int epix = (efi * H + 2 * ety2) * W + 2 * etx2;
+        eoff = et * EXROW + eq * 16;
+        vo_out = (unsigned)((epix * d.ld_out + 4 * eq) * 4);
+        vo_res = (unsigned)((epix * d.ld_res + 4 * eq) * 4);
+    }
 
     // ---- weight fragments: [chunk][position 16][channel block N/16][W1 = [u1|u2], W2 = [u3|u1]][lane][16 B]; an out-of-range chunk
     // (past the last tile) reads zeros
@@ -314,13 +346,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             }
     };
 
-    f32x4 acc[4][4][2];
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[4][4][2];                                // (every tile's first chunk starts them from zero)
     double gacc = 0.0;                                 // threads 0..15: this workgroup's GroupNorm partial (group tid >> 1, sum / sumsq)
     if (tid < 128) gsw[tid] = 0.0;                     // (visible to every wave behind the prologue's barriers)
     // gn_flush: fold the waves' subgroup sums (tiles of channel offset n0f) into the per-group partials of threads 0..15 and clear
@@ -354,7 +380,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     bf16x8 w0[2][2], w1[2][2];
     tile_t cur, nxt;
     setup(t_begin, true, cur);
-    setup(t_begin + G < t_end ? t_begin + G : t_begin, t_begin + G < t_end, nxt);
+    advance(cur, t_begin + G < t_end, nxt);
     fetch_t fn, ff;                                    // the patch of the next unit / of the unit after it
     fetch_of(cur, 0, fn);
     fetch_of(cur, 1, ff);                              // (nC >= 2)
@@ -376,7 +402,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     for (int tile = t_begin; tile < t_end; tile += G) {
         WSTAMP();   // tile start
         const bool has_next = tile + G < t_end;
-        for (int cc = 0; cc < nC; ++cc) {
+        // a chunk as a function of "first chunk of the tile" (see wino_phase)
+        auto chunk = [&](auto first_c, const int cc) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_c)::value;
             const bool last = cc == nC - 1;
             unsigned char* rawc = (cc & 1) ? raw1 : raw0;
             unsigned char* rawn = (cc & 1) ? raw0 : raw1;
@@ -389,7 +417,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             issue_slot(fn, rawn, 2);
             issue_slot(fn, rawn, 3);
             __builtin_amdgcn_sched_barrier(0);
-            wino_phase<0, ABL>(t, dtA, dtB, rawc, w0, w1, acc, [&]() { load_w(cur.n0, cc, 1, 0, w0); });
+            wino_phase<0, ABL, FIRST>(t, dtA, dtB, rawc, w0, w1, acc, [&]() { load_w(cur.n0, cc, 1, 0, w0); });
             if (cc + 2 >= nC) fetch_of(nxt, cc + 2 - nC, ff);                // (descriptor of the unit after next -- it may belong to the
             else fetch_of(cur, cc + 2, ff);                                  //  next tile --, prepared in the shadow of the barrier)
             WSTAMP();   // phase A issued
@@ -406,7 +434,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             //  use: held back until that tile's first phase)
             issue_slot(ff, rawc, 0, !last);
             __builtin_amdgcn_sched_barrier(0);
-            wino_phase<1, ABL>(t, dtB, dtA, rawn, w0, w1, acc, [&]() { load_w(nn0, ncc, 0, 0, w0); issue_slot(ff, rawc, 1, !last); });
+            wino_phase<1, ABL, FIRST>(t, dtB, dtA, rawn, w0, w1, acc, [&]() { load_w(nn0, ncc, 0, 0, w0); issue_slot(ff, rawc, 1, !last); });
             WSTAMP();   // phase B issued
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");               // (no VMEM wait: patch pieces and w0 stay in flight)
             __builtin_amdgcn_s_barrier();
@@ -415,19 +443,19 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             //  spilled register comes back from scratch there -- and would sit out this request's L2 round trip; its 16 registers are
             //  free for the epilogue meanwhile)
             if (!last) load_w(nn0, ncc, 0, 1, w1);
-        }
+        };
+        chunk(std::integral_constant<bool, true>{}, 0);
+        for (int cc = 1; cc < nC; ++cc) chunk(std::integral_constant<bool, false>{}, cc);
 
         // ---- epilogue of the tile.  Y = A^T M A, A^T = [1 1 1 0; 0 1 -1 -1].  nu half in registers: Z[zb] over this wave's 4 column
         // positions; xi half through LDS, one 32-channel half (the waves with coh == h) at a time
         float sv[2], sq[2];
-        int epix, eoff;                                // pixel (a = 0, zb = 0) relative to the tile's first row; byte offset in an exchange plane
-        {
-            const int et = tid >> 3;
-            const int efi = et / TPF, erem = et - efi * TPF;
-            const int ety2 = erem / TX, etx2 = erem - ety2 * TX;
-            epix = (efi * H + 2 * ety2) * W + 2 * etx2;
-            eoff = et * EXROW + eq * 16;
-        }
+        // outputs leave through a buffer descriptor of the tile: the lane's share of the address (vo_out, fixed at launch) in the vector
+        // offset, row / column / channel half of the instruction in the scalar offset -- no 64-bit vector arithmetic per store
+        const long tb = ((long)cur.f0 * H + cur.y0) * W;                       // the tile's first pixel
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + tb * d.ld_out + cur.n0), 0, (255 * d.ld_out + 64) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((d.res ? d.res : d.out) + tb * d.ld_res + cur.n0), 0, d.res ? (255 * d.ld_res + 64) * 4 : 0, 0x00020000);
         const bool never = d.F < 0;                    // (ablation builds: work kept alive behind a condition that is never true)
         if ((ABL & 1) && never) {
             f32x4 sa = {0.f, 0.f, 0.f, 0.f};
@@ -455,9 +483,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            const int n = cur.n0 + 32 * h + 4 * eq;
             f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-            if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + n);
+            if (d.bias) bv = *reinterpret_cast<const f32x4*>(d.bias + cur.n0 + 32 * h + 4 * eq);
             float s1 = 0.f, s2 = 0.f;
 #pragma unroll
             for (int zb = 0; zb < 2; ++zb) {
@@ -467,10 +494,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
                 const f32x4 ya[2] = {(z[0] + z[1]) + z[2], (z[1] - z[2]) - z[3]};
 #pragma unroll
                 for (int a = 0; a < 2; ++a) {
-                    const long m = ((long)cur.f0 * H + cur.y0) * W + epix + a * W + zb;
-                    f32x4 o = ya[a] + bv;
-                    if (d.res) o = o + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n);
-                    if (!(ABL & (16 | 64)) || never) *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n) = o;
+                    f32x4 o = ya[a] + bv;             // pixel (row a, column zb) of the lane's Winograd tile, channels 32 h + 4 eq ..
+                    if (d.res) o = o + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, vo_res, ((a * W + zb) * d.ld_res + 32 * h) * 4, 0));
+                    if (!(ABL & (16 | 64)) || never)
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rso, vo_out, ((a * W + zb) * d.ld_out + 32 * h) * 4, 0);
                     s1 += (o.x + o.y) + (o.z + o.w);
                     s2 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
                 }
@@ -499,15 +526,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
             WSTAMP();   // epilogue half done
         }
         if (d.gn_part && has_next && nxt.n0 != cur.n0) gn_flush(cur.n0);      // (wave-uniform; never taken when the grid is a multiple of N / 64)
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-#pragma unroll
-                for (int k = 0; k < 2; ++k) acc[i][j][k] = f32x4{0.f, 0.f, 0.f, 0.f};
         load_w(nxt.n0, has_next ? 0 : nC, 0, 1, w1);       // the next tile's second position of phase A (needed from its tile block 4 on)
         cur = nxt;
-        setup(tile + 2 * G < t_end ? tile + 2 * G : tile, tile + 2 * G < t_end, nxt);
+        advance(cur, tile + 2 * G < t_end, nxt);
     }
     // ---- GroupNorm(8): one gn_part row per WORKGROUP (fp64, tiles in fixed order); with dawn_conv_desc.gn_a the workgroup that
     // finishes last also reduces the rows (fixed order: deterministic whoever is last) and writes the per-channel coefficients --

@@ -38,6 +38,7 @@
 // halves (output columns {0,1} / {2,3} of every tile: all 12 waves write, 8 read), bias (+ residual), 16-byte row-segment stores,
 // GroupNorm(8) sums per wave in fp64 across tiles, one gn_part row per workgroup and -- with dawn_conv_desc.gn_a -- the coefficients from
 // the workgroup that finishes last (exactly as conv3x3_wino.hip).
+#include <type_traits>
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 #include <cstdlib>
@@ -187,6 +188,17 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
         t.xo33 = (xi_w * 36 + 4 + (kg & 1)) * 256 + l15 * 16;         // [v3 | v3] = slots 4 5 | 4 5
     }
 
+    // ---- reader role of the epilogue (tid < 512): channel quad eq of the 32-channel half ec, output column ezb of the pair, tile et
+    const int eq = tid & 7, ec = (tid >> 3) & 1, ezb = (tid >> 4) & 1, et = tid >> 5;
+    const int nrl = 32 * ec + 4 * eq;                  // first channel inside the 64-channel column tile
+    unsigned vo_out, vo_res;                           // byte offset of (row 0 of tile et, column ezb, channel nrl) from the tile's first pixel
+    {
+        const int ety = et / TXW, etx = et - ety * TXW;
+        const int px = 4 * ety * W + 4 * etx + ezb;
+        vo_out = (unsigned)((px * d.ld_out + nrl) * 4);
+        vo_res = (unsigned)((px * d.ld_res + nrl) * 4);
+    }
+
     // ---- raw-patch DMA slots of this wave: segment s = wave + 12 i = (patch row s / (W / 16), 16-pixel group s % (W / 16)); LDS slot = lane
     // = [column & 3 = lane >> 4][tile & 3 = (lane >> 2) & 3][quad = lane & 3] -> image column 16 g + 4 ((lane >> 2) & 3) + (lane >> 4).
     // Per slot (wave-uniform): the patch row and the LDS byte offset; per lane: the pixel's float offset in the window
@@ -205,6 +217,21 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
         T.n0 = nt * 64;
         T.f0 = grow0 / H;
         T.y0 = grow0 - T.f0 * H;
+        T.valid = valid ? 1 : 0;
+    };
+    // a workgroup's tiles are G apart: the column tile and the image row advance by constants (two divisions per LAUNCH instead of two per
+    // tile and wave: wave-uniform, but an integer division is ~30 vector instructions + read-first-lanes, and the epilogue is bound by
+    // the vector instructions its three waves per SIMD issue -- tools/isa_breakdown.py).  `valid` false: a copy of A nobody fetches
+    const int dmt_ = G / nNt, dn0_ = (G - dmt_ * nNt) * 64;
+    const int df_ = dmt_ * TR / H, dy_ = dmt_ * TR - df_ * H;
+    auto advance = [&](const tile_t& A, bool valid, tile_t& T) {
+        int n0 = A.n0 + dn0_, y0 = A.y0 + dy_, f0 = A.f0 + df_;
+        if (n0 >= d.N) { n0 -= d.N; y0 += TR; }
+        if (y0 >= H) { y0 -= H; ++f0; }
+        if (y0 >= H) { y0 -= H; ++f0; }                  // (y0 < H, dy_ < H, TR <= H: below 3 H)
+        T.n0 = valid ? n0 : A.n0;
+        T.f0 = valid ? f0 : A.f0;
+        T.y0 = valid ? y0 : A.y0;
         T.valid = valid ? 1 : 0;
     };
     // fetch the raw patch of (tile T, chunk cc) into `rawdst` in 1 KB pieces (segment wave + 4 i), issued by the FOUR OLDEST waves only.
@@ -277,11 +304,7 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
         }
     };
 
-    f32x4 acc[6][2];
-#pragma unroll
-    for (int i = 0; i < 6; ++i)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc[6][2];                                   // (every tile's first step starts them from zero)
     double gacc = 0.0;                                 // threads 0..15: this workgroup's GroupNorm partial (group tid >> 1, sum / sumsq)
     if (tid < 128) gsw[tid] = 0.0;
     auto gn_flush = [&](int n0f) {                     // (conv3x3_wino.hip: fold the waves' subgroup sums into the per-group partials)
@@ -307,9 +330,10 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
 
     // ---- prologue: patches of the first two chunks, the first weight fragments, the first transform
     bf16x8 wr[WD4 + 1][2][2];
-    tile_t cur, nxt;
+    tile_t cur, nxt, nx2;                              // this tile, the next one, the one after (its first patch lines are touched ahead)
     setup(t_begin, true, cur);
-    setup(t_begin + G < t_end ? t_begin + G : t_begin, t_begin + G < t_end, nxt);
+    advance(cur, t_begin + G < t_end, nxt);
+    advance(nxt, t_begin + 2 * G < t_end, nx2);
     {
         dma_t D0, D1;
         dma_of(cur, 0, raw0, true, D0);
@@ -335,13 +359,15 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
     for (int tile = t_begin; tile < t_end; tile += G) {
         const bool has_next = tile + G < t_end;
         W4STAMP();   // tile start
-        for (int cc = 0; cc < nC; ++cc) {
+        // a step as a function of "first chunk of the tile": there the accumulators START from the instruction's zero operand instead
+        // of being cleared after every epilogue (48 vector moves per wave and tile; the epilogue is bound by its vector instructions)
+        auto step = [&](auto first_c, const int cc) __attribute__((always_inline)) {
+            constexpr bool FIRST = decltype(first_c)::value;
             const unsigned char* dtr = dt0 + (cc & 1) * DT4;                  // D~ of this chunk
             unsigned char* dtw = dt0 + ((cc + 1) & 1) * DT4;                  // D~ of the next unit (written by the transform)
             const unsigned char* rawt = raw0 + ((cc + 1) & 1) * RAWB;         // raw patch of the next unit (landed during the last step)
             unsigned char* rawd = raw0 + (cc & 1) * RAWB;                     // raw buffer of the unit after next (this chunk's is consumed)
             const bool last = cc == nC - 1;
-            const bool live1 = !last || has_next;                             // the next unit exists
             // the unit after next: chunk cc + 2 of this tile, or chunk cc + 2 - nC of the next one
             dma_t D;
             if (cc + 2 < nC) dma_of(cur, cc + 2, rawd, true, D);
@@ -370,14 +396,18 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
 #pragma unroll
                 for (int cb = 0; cb < 2; ++cb) {
                     // 8 of the 9 cross terms of (u1 + u2 + u3)(v1 + v2 + v3) (all but u3 v3, 2^-32 of the product), two per instruction
-                    f32x4 a = acc[nu][cb];
+                    f32x4 a;
+                    if constexpr (FIRST) a = f32x4{0.f, 0.f, 0.f, 0.f};
+                    else a = acc[nu][cb];
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][1], x12, a, 0, 0, 0);    // [u3|u3].[v1|v2] = u3 v1 + u3 v2
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], x33, a, 0, 0, 0);    // [u1|u2].[v3|v3] = u1 v3 + u2 v3
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], x21, a, 0, 0, 0);    // [u1|u2].[v2|v1] = u1 v2 + u2 v1
                     a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w[cb][0], x12, a, 0, 0, 0);    // [u1|u2].[v1|v2] = u1 v1 + u2 v2
                     acc[nu][cb] = a;
                 }
-                if (live1 && !(ABL & 2)) {              // (wave-uniform)
+                // (behind the workgroup's very last chunk there is no next unit: the transform then works on a stale patch and writes a D~
+                //  nobody multiplies -- cheaper than a branch around every slice, whose merge points cost 20 register moves per step)
+                if (!(ABL & 2)) {
                     if (nu == 0) w4_rows<ROWB>(rawt, t, rwk.k, 0, 2, tr_);
                     else if (nu == 1) w4_rows<ROWB>(rawt, t, rwk.k, 2, 2, tr_);
                     else if (nu == 2) { w4_rows<ROWB>(rawt, t, rwk.k, 4, 2, tr_); w4_cols(tr_, v_); }
@@ -391,7 +421,9 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
             W4STAMP();   // ... patch pieces landed, stores done
             __builtin_amdgcn_s_barrier();
             W4STAMP();   // ... barrier passed
-        }
+        };
+        step(std::integral_constant<bool, true>{}, 0);
+        for (int cc = 1; cc < nC; ++cc) step(std::integral_constant<bool, false>{}, cc);
 
         // ---- epilogue of the tile.  A^T = [1 1 1 1 1 0; 0 3/4 -3/4 3/2 -3/2 0; 0 9/16 9/16 9/4 9/4 0; 0 27/64 -27/64 27/8 -27/8 1].
         // nu half in registers: Z[zb] over this wave's six column positions
@@ -406,11 +438,14 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
             Z[3][cb] = (0.421875f * d1 + 3.375f * d2) + acc[5][cb];
         }
         // xi half through LDS, output columns {0,1} then {2,3} of every tile: ex[xi 6][zbl 2][tile 16][coh 2][EXROW4]
-        const int eq = tid & 7, ec = (tid >> 3) & 1, ezb = (tid >> 4) & 1, et = tid >> 5;     // reader (tid < 512): quad, half, column, tile
-        const int ety = et / TXW, etx = et - ety * TXW;
-        const int n_r = cur.n0 + 32 * ec + 4 * eq;
+        // outputs leave through a buffer descriptor of the tile: the lane's share of the address (vo_out, fixed at launch) in the vector
+        // offset, the row / column of the instruction in the scalar offset -- no 64-bit vector arithmetic per store
+        const long tb = ((long)cur.f0 * H + cur.y0) * W;                       // the tile's first pixel
+        const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)(d.out + tb * d.ld_out + cur.n0), 0, (255 * d.ld_out + 64) * 4, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rsr =
+            __builtin_amdgcn_make_buffer_rsrc((void*)((d.res ? d.res : d.out) + tb * d.ld_res + cur.n0), 0, d.res ? (255 * d.ld_res + 64) * 4 : 0, 0x00020000);
         f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-        if (d.bias && tid < 512) bv = *reinterpret_cast<const f32x4*>(d.bias + n_r);
+        if (d.bias && tid < 512) bv = *reinterpret_cast<const f32x4*>(d.bias + cur.n0 + nrl);
         float gs1 = 0.f, gs2 = 0.f;
         W4STAMP();   // nu half done
 #pragma unroll
@@ -432,10 +467,9 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
                 const f32x4 y[4] = {(z[0] + s1) + s2, 0.75f * d1 + 1.5f * d2, 0.5625f * s1 + 2.25f * s2, (0.421875f * d1 + 3.375f * d2) + z[5]};
 #pragma unroll
                 for (int za = 0; za < 4; ++za) {
-                    const long m = ((long)cur.f0 * H + cur.y0 + 4 * ety + za) * W + 4 * etx + 2 * hz + ezb;
-                    f32x4 o = y[za] + bv;
-                    if (d.res) o = o + *reinterpret_cast<const f32x4*>(d.res + m * d.ld_res + n_r);
-                    if (!(ABL & 64)) *reinterpret_cast<f32x4*>(d.out + m * d.ld_out + n_r) = o;
+                    f32x4 o = y[za] + bv;             // pixel (row za, column 2 hz + ezb) of tile et
+                    if (d.res) o = o + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, vo_res, (za * W + 2 * hz) * d.ld_res * 4, 0));
+                    if (!(ABL & 64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rso, vo_out, (za * W + 2 * hz) * d.ld_out * 4, 0);
                     gs1 += (o.x + o.y) + (o.z + o.w);
                     gs2 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
                 }
@@ -444,9 +478,7 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
                 // the L2 touches of the next tiles' patch lines go out HERE: behind the bias load and its first use (a wait for the bias
                 // would sit out the touches' HBM latency: measured 6 k cycles per tile), in front of nothing but stores and the second
                 // half -- the next weight fetch anybody waits for is ~5 k cycles away
-                tile_t nx2;                            // the tile after next (the same arithmetic as the loop's own setup below)
-                setup(tile + 2 * G < t_end ? tile + 2 * G : tile, tile + 2 * G < t_end, nx2);
-                touch_lines(nxt, has_next, nx2, tile + 2 * G < t_end);
+                touch_lines(nxt, has_next, nx2, nx2.valid != 0);
             }
             W4STAMP();   // half: outputs issued
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -473,12 +505,9 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
             }
         }
         if (d.gn_part && has_next && nxt.n0 != cur.n0) gn_flush(cur.n0);      // (wave-uniform; never taken when the grid is a multiple of N / 64)
-#pragma unroll
-        for (int i = 0; i < 6; ++i)
-#pragma unroll
-            for (int k = 0; k < 2; ++k) acc[i][k] = f32x4{0.f, 0.f, 0.f, 0.f};
         cur = nxt;
-        setup(tile + 2 * G < t_end ? tile + 2 * G : tile, tile + 2 * G < t_end, nxt);
+        nxt = nx2;
+        advance(nxt, tile + 3 * G < t_end, nx2);
     }
     // ---- GroupNorm(8): one gn_part row per workgroup; with gn_a the last workgroup finalises (conv3x3_wino.hip, include/dawn_hip.h)
     if (d.gn_part) {
