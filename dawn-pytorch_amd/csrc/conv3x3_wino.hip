@@ -221,7 +221,10 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     if (t_begin >= t_end) return;
     // start delay (policy bits 20..23, A/B; conv3x3_wino4.hip): `stagger` units of ~1 us times ((workgroup / 8) & 3) de-phase the
     // workgroups of the persistent launch, whose patch fetches and output stores otherwise hit HBM in lockstep bursts
-    for (int i = 0; i < stagger * ((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(32);
+    for (int i = 0; i < (stagger & 0xff) * ((blockIdx.x >> 3) & 3); ++i) __builtin_amdgcn_s_sleep(32);
+    // bit 8 (policy bit 0x20000000): the tiles in REVERSE order -- last frame first.  The kernel that wrote this conv's input wrote it front to
+    // back, so its END is what the memory-side cache still holds: read back to front, the most recently written part comes first
+    const bool rev = (stagger & 0x100) != 0;
 
     // ---- raw-patch DMA slots of this wave: slot s = wave + 8 i -> (channel quad, 64-pixel segment); lane = pixel.  The patch geometry
     // is the same for every tile; which of its rows fall outside the image depends on the tile's first row y0
@@ -267,10 +270,18 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     const int df_ = dmt_ * trr_ / H, dy_ = dmt_ * trr_ - df_ * H;
     const int cf_ = trr_ / H, cy_ = trr_ - cf_ * H;                      // the carry of the column tile: one tile of rows
     auto advance = [&](const tile_t& A, bool valid, tile_t& T) {
-        int n0 = A.n0 + dn0_, y0 = A.y0 + dy_, f0 = A.f0 + df_;
-        if (n0 >= d.N) { n0 -= d.N; y0 += cy_; f0 += cf_; }
-        if (y0 >= H) { y0 -= H; ++f0; }
-        if (y0 >= H) { y0 -= H; ++f0; }                  // (y0, dy_, cy_ < H: below 3 H)
+        int n0, y0, f0;
+        if (!rev) {
+            n0 = A.n0 + dn0_; y0 = A.y0 + dy_; f0 = A.f0 + df_;
+            if (n0 >= d.N) { n0 -= d.N; y0 += cy_; f0 += cf_; }
+            if (y0 >= H) { y0 -= H; ++f0; }
+            if (y0 >= H) { y0 -= H; ++f0; }              // (y0, dy_, cy_ < H: below 3 H)
+        } else {
+            n0 = A.n0 - dn0_; y0 = A.y0 - dy_; f0 = A.f0 - df_;
+            if (n0 < 0) { n0 += d.N; y0 -= cy_; f0 -= cf_; }
+            if (y0 < 0) { y0 += H; --f0; }
+            if (y0 < 0) { y0 += H; --f0; }
+        }
         T.n0 = valid ? n0 : A.n0;
         T.f0 = valid ? f0 : A.f0;
         T.y0 = valid ? y0 : A.y0;
@@ -379,7 +390,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     // both, has to have landed there)
     bf16x8 w0[2][2], w1[2][2];
     tile_t cur, nxt;
-    setup(t_begin, true, cur);
+    setup(rev ? ntiles - 1 - t_begin : t_begin, true, cur);
     advance(cur, t_begin + G < t_end, nxt);
     fetch_t fn, ff;                                    // the patch of the next unit / of the unit after it
     fetch_of(cur, 0, fn);
@@ -534,7 +545,8 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     // finishes last also reduces the rows (fixed order: deterministic whoever is last) and writes the per-channel coefficients --
     // the separate one-block reduce + finalize launch (40 per evaluation, on the critical path of every ResBlock) is gone
     if (d.gn_part) {
-        const int t_last = t_begin + (t_end - 1 - t_begin) / G * G;        // this workgroup's last tile (recomputed: no loop-carried register)
+        const int t_last_ = t_begin + (t_end - 1 - t_begin) / G * G;       // this workgroup's last tile (recomputed: no loop-carried register)
+        const int t_last = rev ? ntiles - 1 - t_last_ : t_last_;
         gn_flush((t_last - t_last / nNt * nNt) * 64);
         if (tid < 16) __hip_atomic_store(d.gn_part + (long)blockIdx.x * 16 + tid, gacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (d.gn_a) {
@@ -637,7 +649,8 @@ int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream
     const size_t lds = g.lds;
     const int grid = ntiles < wino_ncu() ? ntiles : wino_ncu();
     const int sbits = (policy >> 20) & 15;
-    const int stagger = ntiles >= 4 * grid ? (sbits == 15 ? 0 : sbits) : 0;    // (A/B knob, default none)
+    const int stagger = (ntiles >= 4 * grid ? (sbits == 15 ? 0 : sbits) : 0)   // (A/B knob, default none)
+                        | ((policy & 0x20000000) ? 0x100 : 0);                  // reverse tile order (see the kernel)
 #define WINO_LAUNCH(A)                                                                                                      \
     do {                                                                                                                    \
         (void)hipFuncSetAttribute((const void*)conv3x3_wino_kernel<A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \

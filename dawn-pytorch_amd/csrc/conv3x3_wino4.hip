@@ -165,6 +165,9 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
     // start delay (policy bits 20..23, A/B): the workgroups of a persistent launch run in lockstep, so their patch fetches and epilogue
     // stores hit HBM in bursts; `stagger` units of ~1 us times ((workgroup / 8) & 3) de-phase them in four groups per XCD
     for (int i = 0; i < (stagger & 7) * ((blockIdx.x >> 3) & ((stagger & 8) ? 7 : 3)); ++i) __builtin_amdgcn_s_sleep(32);   // (bit 3: eight phases)
+    // bit 8 (policy bit 0x20000000): the tiles in REVERSE order -- last frame first.  The kernel that wrote this conv's input wrote it front to
+    // back, so its END is what the memory-side cache still holds: read back to front, the most recently written part comes first
+    const bool rev = (stagger & 0x100) != 0;
 
     // ---- transform role: half-wave hw = tid >> 5 -> (tile group hw & 3, nu = hw >> 2 = wave >> 1: wave-uniform); lane & 31 -> (tile in
     // the group, channel pair)
@@ -225,10 +228,18 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
     const int dmt_ = G / nNt, dn0_ = (G - dmt_ * nNt) * 64;
     const int df_ = dmt_ * TR / H, dy_ = dmt_ * TR - df_ * H;
     auto advance = [&](const tile_t& A, bool valid, tile_t& T) {
-        int n0 = A.n0 + dn0_, y0 = A.y0 + dy_, f0 = A.f0 + df_;
-        if (n0 >= d.N) { n0 -= d.N; y0 += TR; }
-        if (y0 >= H) { y0 -= H; ++f0; }
-        if (y0 >= H) { y0 -= H; ++f0; }                  // (y0 < H, dy_ < H, TR <= H: below 3 H)
+        int n0, y0, f0;
+        if (!rev) {
+            n0 = A.n0 + dn0_; y0 = A.y0 + dy_; f0 = A.f0 + df_;
+            if (n0 >= d.N) { n0 -= d.N; y0 += TR; }
+            if (y0 >= H) { y0 -= H; ++f0; }
+            if (y0 >= H) { y0 -= H; ++f0; }              // (y0 < H, dy_ < H, TR <= H: below 3 H)
+        } else {
+            n0 = A.n0 - dn0_; y0 = A.y0 - dy_; f0 = A.f0 - df_;
+            if (n0 < 0) { n0 += d.N; y0 -= TR; }
+            if (y0 < 0) { y0 += H; --f0; }
+            if (y0 < 0) { y0 += H; --f0; }
+        }
         T.n0 = valid ? n0 : A.n0;
         T.f0 = valid ? f0 : A.f0;
         T.y0 = valid ? y0 : A.y0;
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
     // ---- prologue: patches of the first two chunks, the first weight fragments, the first transform
     bf16x8 wr[WD4 + 1][2][2];
     tile_t cur, nxt, nx2;                              // this tile, the next one, the one after (its first patch lines are touched ahead)
-    setup(t_begin, true, cur);
+    setup(rev ? ntiles - 1 - t_begin : t_begin, true, cur);
     advance(cur, t_begin + G < t_end, nxt);
     advance(nxt, t_begin + 2 * G < t_end, nx2);
     {
@@ -511,7 +522,8 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
     }
     // ---- GroupNorm(8): one gn_part row per workgroup; with gn_a the last workgroup finalises (conv3x3_wino.hip, include/dawn_hip.h)
     if (d.gn_part) {
-        const int t_last = t_begin + (t_end - 1 - t_begin) / G * G;
+        const int t_last_ = t_begin + (t_end - 1 - t_begin) / G * G;
+        const int t_last = rev ? ntiles - 1 - t_last_ : t_last_;
         gn_flush((t_last - t_last / nNt * nNt) * 64);
         if (tid < 16) __hip_atomic_store(d.gn_part + (long)blockIdx.x * 16 + tid, gacc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (d.gn_a) {
@@ -599,12 +611,13 @@ int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStrea
     // policy bits 20..23 override it (15 = none)
     const int sbits = (policy >> 20) & 15;
     const int stagger = ntiles >= 4 * grid ? (sbits == 15 ? 0 : (sbits ? sbits : 4)) : 0;
+    const int rev8 = (policy & 0x20000000) ? 0x100 : 0;                        // reverse tile order (see the kernel)
     const int W = d.Wi, RAWB = (256 / W + 2) * (W * 64 + 128);
     const size_t lds = (size_t)2 * DT4 + (size_t)2 * RAWB + 1024 + 256;
 #define W4_LAUNCH(WV, A)                                                                                                      \
     do {                                                                                                                     \
         (void)hipFuncSetAttribute((const void*)conv3x3_wino4_kernel<WV, A>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-        hipLaunchKernelGGL((conv3x3_wino4_kernel<WV, A>), dim3(grid), dim3(NT4), lds, s, d, ntiles, stagger);                   \
+        hipLaunchKernelGGL((conv3x3_wino4_kernel<WV, A>), dim3(grid), dim3(NT4), lds, s, d, ntiles, stagger | rev8);                   \
     } while (0)
 #ifdef DAWN_ABLATION
     static const int abl = getenv("DAWN_WINO4_ABL") ? atoi(getenv("DAWN_WINO4_ABL")) : 0;      // perf ablations / s_memtime build (wrong results by design)

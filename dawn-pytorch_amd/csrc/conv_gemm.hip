@@ -45,14 +45,18 @@ namespace {
 // 0x8000000 (opt-in, round 5): the Winograd F(4x4,3x3) form (conv3x3_wino4.hip) where dawn_conv_desc.w_wino4 is supplied and the geometry
 // fits (image width 64 / 32): 4x fewer matrix-pipe flops than the direct form, weights streamed at 2.25x the F(2x2) rate.  By itself the bit
 // takes the F(4x4) form only for the shape it measured faster on (64 input channels, 64-pixel-wide latent); with 0x10000000 wherever it fits.
+// 0x20000000 (shipped, round 5): both Winograd kernels walk their tiles back to front (last frame first).  Every kernel of an evaluation writes
+// its output front to back, so the END of a conv's input is what the memory-side cache still holds when the conv starts; front to back the
+// conv's own traffic evicts that part before reaching it.  Bit-identical outputs (tests: test_conv_wino_reverse_tile_order); +0.3..0.6 %
+// frames/s in the benchmark, alternating on one box (profiles/r5_ab_wino_reverse_order.txt).
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
 // split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
-constexpr int DAWN_CONV_POLICY_DEFAULT = 0xB00580D;
+constexpr int DAWN_CONV_POLICY_DEFAULT = 0x2B00580D;
 #ifdef DAWN_ABLATION
-constexpr int DAWN_CONV_POLICY_MASK = 0x1F0FFFFF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x3F0FFFFF;
 #else
-constexpr int DAWN_CONV_POLICY_MASK = 0x1FF3FFCF;
+constexpr int DAWN_CONV_POLICY_MASK = 0x3FF3FFCF;
 #endif
 static inline int policy_of(const dawn_conv_desc& d) { return (d.policy ? d.policy : DAWN_CONV_POLICY_DEFAULT) & DAWN_CONV_POLICY_MASK; }
 __device__ unsigned long long* g_dbg = nullptr;   // s_memtime stamps of the instrumented build (ABL bit 3)

@@ -225,7 +225,7 @@ class HipOps:
 
     def _runs_winograd4(self, w_wino4, KH, KW, stride, mode, F, H, W, N, C0, C1, tr) -> bool:
         """Profiling label only: does this 3x3 launch take the Winograd F(4x4,3x3) form (the library's predicate + its per-shape policy)?"""
-        pol = self.conv_policy or 0xB00580D
+        pol = self.conv_policy or 0x2B00580D
         if w_wino4 is None or tr is not None or not (pol & 0x8000000) or not (pol & 0x1000) or (pol & 0x2000):
             return False
         if not (pol & 0x10000000) and not (W == 64 and C0 + C1 == 64):
@@ -234,7 +234,7 @@ class HipOps:
 
     def _runs_winograd(self, w_wino, KH, KW, stride, mode, F, H, W, N, C0, C1, tr) -> bool:
         """Profiling label only: does this 3x3 launch take the Winograd form (the library's own predicate + the policy bit)?"""
-        pol = self.conv_policy or 0xB00580D
+        pol = self.conv_policy or 0x2B00580D
         if w_wino is None or tr is not None or not (pol & 0x2000000) or not (pol & 0x1000) or (pol & 0x2000):
             return False
         if (pol & 0x4000000) and C0 + C1 < 128:

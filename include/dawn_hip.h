@@ -105,11 +105,11 @@ int dawn_conv3x3_wino4_ok(int F, int H, int W, int C0, int C1, int N);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;
  * the launch reports the exact count through dawn_conv_desc.gn_rows */
 int dawn_conv_gemm_nblocks(long M, int N);
-/* dawn_conv_desc.policy bits (0 = shipped policy 0xB00580D; per call, no process-global state): bit0 BK=32 tiles,
+/* dawn_conv_desc.policy bits (0 = shipped policy 0x2B00580D; per call, no process-global state): bit0 BK=32 tiles,
  * bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel,
  * 0x1000 split-operand (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000
  * second-generation split 3x3 kernel, 0x1000000 that kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction: less energy per
- * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops); 0x4000000 (A/B) the direct kernel for convs of fewer than 128 input channels even where the Winograd form fits (measured slower, not shipped); 0x8000000 (shipped) the Winograd F(4x4,3x3) form where w_wino4 is supplied, dawn_conv3x3_wino4_ok and the shape is the one it measured faster on (64 input channels, image width 64) -- with 0x10000000 wherever it fits; 0x400 is ignored (round 3's opt-in stream-K variant: experimental builds only).  Every combination computes the same function (tests run the kernel families
+ * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops); 0x4000000 (A/B) the direct kernel for convs of fewer than 128 input channels even where the Winograd form fits (measured slower, not shipped); 0x8000000 (shipped) the Winograd F(4x4,3x3) form where w_wino4 is supplied, dawn_conv3x3_wino4_ok and the shape is the one it measured faster on (64 input channels, image width 64) -- with 0x10000000 wherever it fits; 0x20000000 (shipped) both Winograd kernels walk their tiles back to front -- last frame first: the end of the input, written last by the producer, is what the memory-side cache still holds (bit-identical outputs); 0x400 is ignored (round 3's opt-in stream-K variant: experimental builds only).  Every combination computes the same function (tests run the kernel families
  * against each other); perf-ablation / s_memtime builds exist only under -DDAWN_ABLATION (tools/build_timing_lib.sh). */
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --

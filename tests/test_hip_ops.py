@@ -355,6 +355,44 @@ def test_conv3x3_winograd4(hip, ref, case):
         hip.conv_policy = 0
 
 
+REV_CASES = [WINO_CASES[i] for i in (0, 1, 4, 6, 8, 11, 12, 13)] + [("F4:" + c[0],) + c[1:] for c in (WINO4_CASES[0], WINO4_CASES[1], WINO4_CASES[3], WINO4_CASES[5], WINO4_CASES[6])]
+
+
+@pytest.mark.parametrize("case", REV_CASES, ids=[c[0] for c in REV_CASES])
+def test_conv_wino_reverse_tile_order(hip, case):
+    """Policy bit 0x20000000: both Winograd kernels walk their tiles back to front (last frame first).  A tile's arithmetic does not depend
+    on the order: the outputs must be BIT-identical to the front-to-back launch; the GroupNorm partial sums of a workgroup add the
+    same tiles in the opposite order (fp64): fused coefficients equal to summation rounding."""
+    from dawn_pytorch_amd.pack import pack_bf3, pack_wino_bf3, pack_wino4_bf3, unpack_kn
+    name, F, H, W, C0, C1, N, ex = case
+    f4 = name.startswith("F4:")
+    rows = F * H * W
+    in0 = rnd(rows, C0, seed=1).cuda()
+    in1 = rnd(rows, C1, seed=2).cuda() if C1 else None
+    w = packw(9 * (C0 + C1), N, seed=3)
+    w5 = _w5_from_packed(w, C0 + C1, N)
+    kw = dict(F=F, Hi=H, Wi=W, KH=3, KW=3, pad=1, bias=rnd(N, seed=4).cuda(), w_bf3=pack_bf3(unpack_kn(w)).cuda(), w_wino=pack_wino_bf3(w5).cuda())
+    if f4:
+        kw["w_wino4"] = pack_wino4_bf3(w5).cuda()
+    gamma, beta = rnd(N, seed=14).cuda() * 0.2 + 1, rnd(N, seed=15).cuda() * 0.2
+    base = WINO4 if f4 else WINO
+    try:
+        hip.begin_evaluation(in0)
+        res = []
+        for pol in (base, base | 0x20000000):
+            hip.conv_policy = pol
+            part = hip.conv_gn_part(rows, N, in0)
+            got = hip.conv_gemm(in0, w.cuda(), N, in1=in1, gn_part=part, gn_fin=(gamma, beta, None, rows), **kw)
+            torch.cuda.synchronize()
+            assert part.dawn_ab is not None
+            res.append((got, part.dawn_ab[0].clone(), part.dawn_ab[1].clone()))
+        assert torch.equal(res[0][0], res[1][0])
+        check(f"conv_wino_reverse/{name}/gn_a", res[1][1], res[0][1], 1e-6)
+        check(f"conv_wino_reverse/{name}/gn_b", res[1][2], res[0][2], 1e-6)
+    finally:
+        hip.conv_policy = 0
+
+
 def test_conv_wino4_is_fp32_accurate(hip, ref):
     """VERDICT r4 #1b's gate: against an fp64 convolution the F(4x4,3x3) kernel's error stays within 5x the exact-fp32-MFMA kernel's
     (policy 2061) on N(0,1) data and on data spread over 10 decades (measured ~2x: the points 0, +-3/4, +-3/2 -- tools/wino4_points.py)."""
