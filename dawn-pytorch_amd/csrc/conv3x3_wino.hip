@@ -36,6 +36,9 @@
 // need yet), then bias (+ residual), 16-byte row-segment stores and GroupNorm(8) partials (one gn_part row per workgroup; optionally the coefficients themselves).
 #include <type_traits>
 #include "dawn_common.h"
+#ifndef DAWN_WINO_ST_AUX
+#define DAWN_WINO_ST_AUX 0          // cache-policy bits of the output stores (A/B builds: 2 = non-temporal)
+#endif
 #include "../../include/dawn_hip.h"
 #include <cstdlib>
 
@@ -508,7 +511,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
                     f32x4 o = ya[a] + bv;             // pixel (row a, column zb) of the lane's Winograd tile, channels 32 h + 4 eq ..
                     if (d.res) o = o + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, vo_res, ((a * W + zb) * d.ld_res + 32 * h) * 4, 0));
                     if (!(ABL & (16 | 64)) || never)
-                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rso, vo_out, ((a * W + zb) * d.ld_out + 32 * h) * 4, 0);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rso, vo_out, ((a * W + zb) * d.ld_out + 32 * h) * 4, DAWN_WINO_ST_AUX);
                     s1 += (o.x + o.y) + (o.z + o.w);
                     s2 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
                 }

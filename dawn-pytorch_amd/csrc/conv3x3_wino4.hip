@@ -40,6 +40,9 @@
 // the workgroup that finishes last (exactly as conv3x3_wino.hip).
 #include <type_traits>
 #include "dawn_common.h"
+#ifndef DAWN_WINO_ST_AUX
+#define DAWN_WINO_ST_AUX 0          // cache-policy bits of the output stores (A/B builds: 2 = non-temporal)
+#endif
 #include "../../include/dawn_hip.h"
 #include <cstdlib>
 
@@ -480,7 +483,7 @@ __global__ __launch_bounds__(NT4, 1) void conv3x3_wino4_kernel(const dawn_conv_d
                 for (int za = 0; za < 4; ++za) {
                     f32x4 o = y[za] + bv;             // pixel (row za, column 2 hz + ezb) of tile et
                     if (d.res) o = o + __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsr, vo_res, (za * W + 2 * hz) * d.ld_res * 4, 0));
-                    if (!(ABL & 64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rso, vo_out, (za * W + 2 * hz) * d.ld_out * 4, 0);
+                    if (!(ABL & 64)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(i32x4, o), rso, vo_out, (za * W + 2 * hz) * d.ld_out * 4, DAWN_WINO_ST_AUX);
                     gs1 += (o.x + o.y) + (o.z + o.w);
                     gs2 += (o.x * o.x + o.y * o.y) + (o.z * o.z + o.w * o.w);
                 }
