@@ -306,7 +306,9 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
         Fd.y0 = T.y0;
     };
     // `live` (wave-uniform) = false: nothing is fetched and the (zero) result goes to the junk area
+    bool abl_nodma = false;                            // (ablation builds, ABL bit 5: no patch DMA behind the prologue -- wrong results by design)
     auto issue_slot = [&](const fetch_t& Fd, unsigned char* rawdst, int i, bool live = true) {      // (branch-free: it sits inside a scheduling region)
+        if ((ABL & 32) && abl_nodma) return;
         const unsigned v = dtab[i * 512 + tid];
         const unsigned row = (unsigned)Fd.y0 + ((v >> 24) & 127u) - 1u;           // image row of the lane's pixel (wraps below 0)
         const unsigned bad = (v >> 31) | (unsigned)(row >= (unsigned)H) | (live ? 0u : 1u);
@@ -413,6 +415,7 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     // three pieces: slot 0 at the top of phase B(u-2), slot 1 in its middle, slots 2..3 at the top of phase A(u-1), each right behind
     // a weight fetch: VMEM returns in order, so a patch piece has to land before the next YOUNGER weight fetch is waited for, which
     // is one phase later at these positions
+    abl_nodma = true;
     for (int tile = t_begin; tile < t_end; tile += G) {
         WSTAMP();   // tile start
         const bool has_next = tile + G < t_end;
@@ -665,6 +668,8 @@ int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream
     else if (abl == 2) WINO_LAUNCH(2);
     else if (abl == 8) WINO_LAUNCH(8);
     else if (abl == 16) WINO_LAUNCH(16);
+    else if (abl == 32) WINO_LAUNCH(32);
+    else if (abl == 33) WINO_LAUNCH(33);
     else if (abl == 64) WINO_LAUNCH(64);
     else if (abl == 72) WINO_LAUNCH(72);
     else if (abl == 66) WINO_LAUNCH(66);
