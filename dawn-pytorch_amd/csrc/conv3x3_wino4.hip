@@ -601,10 +601,12 @@ extern "C" int dawn_conv3x3_wino4_ok(int F, int H, int W, int C0, int C1, int N)
 
 // host-side geometry test + launch; 0 = the shape does not fit (the caller falls back to the F(2x2) / direct kernels)
 int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows) {
-    // per-shape choice (measured, profiles/r5_wino4_*): the F(4x4) form is memory-pipeline bound (295 KB of weight fragments per 16-channel
-    // chunk and workgroup) and beats F(2x2) only where a tile has few chunks and the epilogue weighs most -- 64 input channels at a 64-pixel-wide
-    // latent (-7 %); policy bit 0x10000000 (tests, A/B) takes it wherever the geometry fits
-    if (!(policy & 0x10000000) && !(d.Wi == 64 && d.C0 + d.C1 == 64)) return 0;
+    // per-shape choice (measured in situ, profiles/r5_insitu_shapes_wino4_everywhere_vs_gated.txt): the F(4x4) form is bound by its weight
+    // stream (221 KB of fragments per 16-channel chunk and workgroup) and beats F(2x2) where a tile has few chunks and the epilogue weighs
+    // most -- 64 input channels at the 64-pixel-wide latent (-9 %), up to 128 at the 32-pixel-wide one (-3.5..-7 %); slower at 128 / 256 input
+    // channels there (+7 / +10 %).  Policy bit 0x10000000 (tests, A/B) takes it wherever the geometry fits
+    const int cin_ = d.C0 + d.C1;
+    if (!(policy & 0x10000000) && !((d.Wi == 64 && cin_ == 64) || (d.Wi == 32 && cin_ <= 128))) return 0;
     if (!d.w_wino4 || d.tr || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.mode != 0) return 0;
     if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3))) return 0;
     if (!wino4_geometry(d.F, d.Hi, d.Wi, d.C0, d.C1, d.N)) return 0;

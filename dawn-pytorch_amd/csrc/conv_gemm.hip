@@ -44,7 +44,7 @@ namespace {
 // epilogue is a fifth of such a tile) take the direct split kernel even where the Winograd form fits.
 // 0x8000000 (opt-in, round 5): the Winograd F(4x4,3x3) form (conv3x3_wino4.hip) where dawn_conv_desc.w_wino4 is supplied and the geometry
 // fits (image width 64 / 32): 4x fewer matrix-pipe flops than the direct form, weights streamed at 2.25x the F(2x2) rate.  By itself the bit
-// takes the F(4x4) form only for the shape it measured faster on (64 input channels, 64-pixel-wide latent); with 0x10000000 wherever it fits.
+// takes the F(4x4) form only for the shapes it measured faster on (64 input channels at the 64-pixel-wide latent, up to 128 at the 32-pixel-wide one); with 0x10000000 wherever it fits.
 // 0x20000000 (shipped, round 5): both Winograd kernels walk their tiles back to front (last frame first).  Every kernel of an evaluation writes
 // its output front to back, so the END of a conv's input is what the memory-side cache still holds when the conv starts; front to back the
 // conv's own traffic evicts that part before reaching it.  Bit-identical outputs (tests: test_conv_wino_reverse_tile_order); +0.3..0.6 %

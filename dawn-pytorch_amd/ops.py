@@ -228,7 +228,7 @@ class HipOps:
         pol = self.conv_policy or 0x2B00580D
         if w_wino4 is None or tr is not None or not (pol & 0x8000000) or not (pol & 0x1000) or (pol & 0x2000):
             return False
-        if not (pol & 0x10000000) and not (W == 64 and C0 + C1 == 64):
+        if not (pol & 0x10000000) and not ((W == 64 and C0 + C1 == 64) or (W == 32 and C0 + C1 <= 128)):
             return False
         return KH == 3 and KW == 3 and stride == 1 and mode == 0 and bool(self.L.dawn_conv3x3_wino4_ok(F, H, W, C0, C1, N))
 

@@ -367,10 +367,11 @@ def pack_unet(sd: Dict[str, Tensor], win: int, device, prefix: str = "denoise_fn
             rb.w1w = pack_wino_bf3(w1).to(device)
         if Co % 64 == 0:
             rb.w2w = pack_wino_bf3(g(p + "block2.proj.weight")).to(device)
-        # F(4x4,3x3) images (opt-in kernel, policy bit 0x8000000): only for the 64 -> 64 convs it is selected for (1.2 MB each)
-        if Cin == 64 and Co == 64:
+        # F(4x4,3x3) images (policy bit 0x8000000): only for the convs the library's per-shape gate can select (up to 128 input channels;
+        # 36 x 6 bytes per (cin, cout) pair: 0.9 .. 3.5 MB each)
+        if Cin % 32 == 0 and Cin <= 128 and Co % 64 == 0 and Co <= 128:
             rb.w1w4 = pack_wino4_bf3(w1).to(device)
-        if Co == 64:
+        if Co % 64 == 0 and Co <= 128:
             rb.w2w4 = pack_wino4_bf3(g(p + "block2.proj.weight")).to(device)
         if has(p + "res_conv.weight"):
             rb.wr = dev(pack_kn(conv_w_kn(g(p + "res_conv.weight"))))

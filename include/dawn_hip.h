@@ -88,7 +88,7 @@ typedef struct dawn_conv_desc {
     /* round 5 (ABI 7), optional: the Winograd F(4x4,3x3) image of a 3x3 / stride-1 / pad-1 conv (pack.pack_wino4_bf3: [(C0+C1)/16][36
      * positions][N/16][768 bf16 = the fragment [u1|u2] in lane order, then u3 of the k-groups 0, 1] of U = G g G^T on the points 0, +-3/4,
      * +-3/2, inf: every plane once, 8 of the 9 cross terms).  With policy bit 0x8000000 (in the
-     * shipped default: it selects the form only for the shape it measured faster on, 64 input channels at image width 64; 0x10000000 adds
+     * shipped default: it selects the form only for the shapes it measured faster on, 64 input channels at image width 64 and up to 128 at image width 32; 0x10000000 adds
      * every shape dawn_conv3x3_wino4_ok accepts) the conv runs as conv3x3_wino4_kernel (4x fewer
      * matrix-pipe flops than the direct form, fp32 results to fp32-F(4x4) accuracy: ~2x the direct form's rounding error); the gn_* fields
      * above are honoured exactly as by the F(2x2) kernel */
@@ -109,7 +109,7 @@ int dawn_conv_gemm_nblocks(long M, int N);
  * bit1 256x64 tile for N<=64, bit2 XCD-contiguous tile order, bit3 direct-to-LDS staging, 0x800 LDS-halo 3x3 kernel,
  * 0x1000 split-operand (bf16 pipe) kernels when w_bf3 is supplied, 0x2000 all 9 cross terms instead of 6, 0x4000
  * second-generation split 3x3 kernel, 0x1000000 that kernel on v_mfma_f32_16x16x32_bf16 (two cross terms per instruction: less energy per
- * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops); 0x4000000 (A/B) the direct kernel for convs of fewer than 128 input channels even where the Winograd form fits (measured slower, not shipped); 0x8000000 (shipped) the Winograd F(4x4,3x3) form where w_wino4 is supplied, dawn_conv3x3_wino4_ok and the shape is the one it measured faster on (64 input channels, image width 64) -- with 0x10000000 wherever it fits; 0x20000000 (shipped) both Winograd kernels walk their tiles back to front -- last frame first: the end of the input, written last by the producer, is what the memory-side cache still holds (bit-identical outputs); 0x400 is ignored (round 3's opt-in stream-K variant: experimental builds only).  Every combination computes the same function (tests run the kernel families
+ * flop on a power-limited chip), 0x2000000 the Winograd F(2x2,3x3) form of that conv where w_wino is supplied and the shape fits (2.25x fewer matrix-pipe flops); 0x4000000 (A/B) the direct kernel for convs of fewer than 128 input channels even where the Winograd form fits (measured slower, not shipped); 0x8000000 (shipped) the Winograd F(4x4,3x3) form where w_wino4 is supplied, dawn_conv3x3_wino4_ok and the shape is one it measured faster on (64 input channels at image width 64, up to 128 at image width 32) -- with 0x10000000 wherever it fits; 0x20000000 (shipped) both Winograd kernels walk their tiles back to front -- last frame first: the end of the input, written last by the producer, is what the memory-side cache still holds (bit-identical outputs); 0x400 is ignored (round 3's opt-in stream-K variant: experimental builds only).  Every combination computes the same function (tests run the kernel families
  * against each other); perf-ablation / s_memtime builds exist only under -DDAWN_ABLATION (tools/build_timing_lib.sh). */
 
 /* ---- A3 GroupNorm(8) statistics over (C/8, F, H, W) (MT:230,235; nn.GroupNorm on a 5-D tensor) --

@@ -287,7 +287,7 @@ def test_conv_wino_is_fp32_accurate(hip, ref):
 
 
 # ---------------------------------------------------------------------------------------------- Winograd F(4x4,3x3) split conv (opt-in)
-WINO4 = WINO | 0x8000000 | 0x10000000          # the F(4x4) form wherever its geometry fits (0x8000000 alone: only the shape it wins on)
+WINO4 = WINO | 0x8000000 | 0x10000000          # the F(4x4) form wherever its geometry fits (0x8000000 alone: only the shapes it wins on)
 WINO4_CASES = [
     # name, F, H, W, C0, C1, N, extras
     ("L0_64x64", 3, 64, 64, 64, 0, 64, {"bias": True, "gn": True}),                         # tile = 4 rows x 64 columns: 1 x 16 Winograd tiles
