@@ -229,30 +229,34 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     // back, so its END is what the memory-side cache still holds: read back to front, the most recently written part comes first
     const bool rev = (stagger & 0x100) != 0;
 
-    // ---- raw-patch DMA slots of this wave: slot s = wave + 8 i -> (channel quad, 64-pixel segment); lane = pixel.  The patch geometry
-    // is the same for every tile; which of its rows fall outside the image depends on the tile's first row y0
-    // slot s = wave + 8 i -> 16-pixel segment; lane = (pixel l >> 2, LDS quad slot l & 3), fetching source quad (l & 3) ^ swizzle(column).
-    // One register per slot: [31] invalid | [30:24] patch row | [23:22] source quad | [21:0] pixel offset in the window (pyy * W + x)
+    // ---- raw-patch DMA slots of this wave: slot s = wave + 8 i -> 16-pixel segment; lane = (pixel l >> 2, LDS quad slot l & 3), fetching source
+    // quad (l & 3) ^ swizzle(column).  The patch geometry is the same for every tile: per slot and lane ONE word, the byte offset of the lane's
+    // 16 bytes from the window's first pixel (row y0 - 1), or DINV for a lane outside the patch.  At issue time it takes one vector add: the
+    // tile's descriptor starts at ITS FRAME's first row and the window's row offset (y0 - 1) W ld -- negative at the top of a frame -- is added
+    // per lane, so the rows above / below the image leave the descriptor's range and the hardware writes the zero padding (round 5: the
+    // row test, multiply and select of the previous form were 11 vector instructions per slot, 44 of a chunk's 302).  Several frames per
+    // tile (8 x 8 / 16 x 16 images): the rows between frames are padding for every tile -- marked in the table.  Both sources of a
+    // concatenated input share the table: dawn_conv3x3_wino_try() demands ld0 == ld1 (else the direct kernel runs).
     // (kept in LDS, 4 B per thread and slot: read back when a piece is issued -- the main loop has no register to spare)
+    constexpr unsigned DINV = 0x40000000u;            // (+ the window offset: beyond any descriptor; twice: 0x80000000, still beyond)
     unsigned* dtab = reinterpret_cast<unsigned*>(smem_b + 2 * DTG + 2 * RAWB + 1024 + 1024);      // [4 slots][512 threads]
     int ddst[4];                                       // (wave-uniform) LDS byte offset of the slot in a raw buffer; past-the-patch slots -> junk
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int s = wave + 8 * i;
         const int pos = s * 16 + (lane >> 2);
-        unsigned v = 0x80000000u;
+        unsigned v = DINV;
         if (s < PI && pos < nf * PP) {
             const int fi = pos / PP;
             const int rem = pos - fi * PP;
             const int pyy = rem / PW, pxx = rem - pyy * PW;
             const int x = pxx - 1;
-            if (x >= 0 && x < W)
-                v = ((unsigned)pyy << 24) | ((unsigned)((lane & 3) ^ ((pxx >> 2) & 3)) << 22) | (unsigned)(fi * H * W + pyy * W + x);
+            if (x >= 0 && x < W && !(nf > 1 && (pyy == 0 || pyy == TR + 1)))
+                v = (unsigned)(fi * H * W + pyy * W + x) * (unsigned)(d.ld0 * 4) + (unsigned)((lane & 3) ^ ((pxx >> 2) & 3)) * 16u;
         }
         dtab[i * 512 + tid] = v;
         ddst[i] = s < PI ? s * 1024 : -1;
     }
-    const int ext = nf * H * W + (nf > 1 ? 2 * W : (TR + 2) * W - H * W);      // pixels spanned by a tile's patch window
     const __amdgpu_buffer_rsrc_t rsw =
         __builtin_amdgcn_make_buffer_rsrc((void*)d.w_wino, 0, nC * 16 * nCB * 2 * 1024, 0x00020000);
 
@@ -293,27 +297,25 @@ __global__ __launch_bounds__(512, 1) void conv3x3_wino_kernel(const dawn_conv_de
     // A patch fetch is issued in pieces right behind the weight fetches of a phase (see the main loop): an HBM-missing patch streams at
     // ~11 B/clk per CU, and a wave that issues its whole share at once sits at the issue port for that long (measured: +1.6..8 k cycles
     // on the phase) -- the MFMAs behind it wait.  `fetch_t` = what a piece needs, prepared outside the phases
-    struct fetch_t { __amdgpu_buffer_rsrc_t rs; int ldb, soff, y0; };
+    struct fetch_t { __amdgpu_buffer_rsrc_t rs; int soff, rowoff; };
+    const int frame_fl = H * W * d.ld0, row_b = W * d.ld0 * 4, range_b = nf * H * W * d.ld0 * 4;      // floats per frame, bytes per row / per tile's frames (ld0 == ld1)
     auto fetch_of = [&](const tile_t& T, int cc, fetch_t& Fd) {
         const int cbase = cc * 16;
         const bool src1 = cbase >= d.C0;
         const float* src = src1 ? d.in1 : d.in0;
-        const int ld = src1 ? d.ld1 : d.ld0;
-        const long pb = ((long)T.f0 * H + T.y0 - 1) * W;          // first pixel of the window = row y0 - 1 of frame f0
-        Fd.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + pb * ld), 0, T.valid ? ext * ld * 4 : 0, 0x00020000);
-        Fd.ldb = ld * 4;
+        // the descriptor covers the tile's frame(s), rows 0 .. H - 1: the window's rows -1 / H fall outside it
+        Fd.rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + (long)T.f0 * frame_fl), 0, range_b, 0x00020000);
         Fd.soff = (src1 ? cbase - d.C0 : cbase) * 4;
-        Fd.y0 = T.y0;
+        // the window's first pixel relative to the frame's; a tile past the end (a copy of a real one) fetches nothing: every lane out of range
+        // (through the OFFSET, not a zero-sized descriptor: a descriptor word that depends on the flag ends up in vector registers and
+        //  every DMA instruction in a waterfall loop)
+        Fd.rowoff = T.valid ? (T.y0 - 1) * row_b : (int)DINV;
     };
     // `live` (wave-uniform) = false: nothing is fetched and the (zero) result goes to the junk area
     bool abl_nodma = false;                            // (ablation builds, ABL bit 5: no patch DMA behind the prologue -- wrong results by design)
     auto issue_slot = [&](const fetch_t& Fd, unsigned char* rawdst, int i, bool live = true) {      // (branch-free: it sits inside a scheduling region)
         if ((ABL & 32) && abl_nodma) return;
-        const unsigned v = dtab[i * 512 + tid];
-        const unsigned row = (unsigned)Fd.y0 + ((v >> 24) & 127u) - 1u;           // image row of the lane's pixel (wraps below 0)
-        const unsigned bad = (v >> 31) | (unsigned)(row >= (unsigned)H) | (live ? 0u : 1u);
-        const unsigned off = (v & 0x3fffffu) * (unsigned)Fd.ldb + ((v >> 22) & 3u) * 16u;
-        const unsigned voff = bad ? OOB : off;
+        const unsigned voff = dtab[i * 512 + tid] + (live ? (unsigned)Fd.rowoff : DINV);
         unsigned char* dp = (live && ddst[i] >= 0) ? rawdst + ddst[i] : junk;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(Fd.rs, (__attribute__((address_space(3))) void*)dp, 16, voff, Fd.soff, 0, 0);
     };
@@ -651,6 +653,8 @@ int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream
     if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3))) return 0;
     wino_geom g;
     if (!wino_geometry(d.F, d.Hi, d.Wi, d.C0, d.C1, d.N, g)) return 0;
+    // one DMA offset table serves both sources; a tile's descriptor (its frame(s)) stays below the table's "outside the patch" mark
+    if ((d.in1 && d.ld1 != d.ld0) || (long)g.nf * d.Hi * d.Wi * d.ld0 * 4 >= (1L << 30)) return 0;
     const int ntiles = g.ntiles, TR = g.TR, nf = g.nf, PI = g.PI, RAWB = g.RAWB;
     const size_t lds = g.lds;
     const int grid = ntiles < wino_ncu() ? ntiles : wino_ncu();
