@@ -20,6 +20,7 @@ from two probe lengths against the HBM size) and `cpu_baseline` (the CPU oracle 
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -601,8 +602,16 @@ def main():
             "conv3x3": ("hbm_bytes_per_launch_conv3x3_bf16",
                         "conv3x3_bf16_v2_kernel (3x3 ResBlock convs: fp32 operands split exactly into 3 bf16 pieces, 6 cross "
                         "terms, two per v_mfma_f32_16x16x32_bf16, fp32 accumulate)"),
+            # the 1x1 family by KERNEL (the library's own choice, conv_gemm.hip gemm1x1_rowreg_ok / gemm1x1_rowacc_ok, restated in kind_of below):
+            # one `roofline` entry per kernel, not per family -- the dominant KERNEL is what `roofline` describes
+            "gemm1x1_rowreg": ("hbm_bytes_per_launch_gemm1x1_rowreg",
+                               "gemm1x1_rowreg_kernel (1x1 projections of 64 / 128 input channels: to_qkv / to_q / res_conv; rows split once into registers, "
+                               "same split-operand scheme)"),
+            "gemm1x1_rowacc": ("hbm_bytes_per_launch_gemm1x1_rowacc",
+                               "gemm1x1_rowacc_kernel (deep-K narrow 1x1 projections and the 4x4 / stride-2 and transposed 4x4 resampling convs as implicit GEMMs, "
+                               "same split-operand scheme)"),
             "gemm1x1": ("hbm_bytes_per_launch_gemm1x1_bf16",
-                        "gemm1x1_rowreg / gemm1x1_rowacc / gemm1x1_bf16 kernels (1x1 projections: to_qkv / to_out / to_q / res_conv, same split-operand scheme)"),
+                        "gemm1x1_bf16_kernel (tiled 1x1 projections: to_qkv / to_out of the 256 .. 1024-channel levels, same split-operand scheme)"),
             "fp32": ("hbm_bytes_per_launch_fp32",
                      "conv_gemm_glds_kernel / conv_gemm_kernel (fp32 MFMA implicit GEMM: thin N=64 1x1, 4x4/s2, transposed 4x4)"),
         }
@@ -612,7 +621,8 @@ def main():
             flops = sum(p[0] for p in entries)
             alg = flops / (t_ms * 1e-3) / 1e12
             # PMC counters cannot be read live: measured on this exact workload by tools/pmc_bench.sh
-            traffic = pmc.get(KINDS[kind][0], pmc.get("hbm_bytes_per_launch")) if pmc is not None else None
+            traffic = (pmc.get(KINDS[kind][0], pmc.get("hbm_bytes_per_launch_gemm1x1_bf16" if kind.startswith("gemm1x1") else "hbm_bytes_per_launch",
+                                                         pmc.get("hbm_bytes_per_launch"))) if pmc is not None else None)
             r = {"bound": "mfma", "unit": "TFLOP/s", "traffic": traffic,
                  "traffic_source": (f"NOT measured in this run: {os.path.relpath(tp, ROOT)} (builder's separate rocprofv3 --pmc "
                                     "FETCH_SIZE / WRITE_SIZE passes over this workload, gfx950 x2 fetch correction applied)"
@@ -651,6 +661,14 @@ def main():
                 return "fp32"
             if " k=3x3 " in label:
                 return "conv3x3_wino4" if "winograd4" in label else ("conv3x3_wino" if "winograd" in label else "conv3x3")
+            if " k=1x1 " not in label:
+                return "gemm1x1_rowacc"                       # the split resampling convs (4x4 / stride 2, transposed 4x4 as 2x2 phases)
+            mm = re.search(r"N=(\d+) K=(\d+)", label)
+            n_, k_ = int(mm.group(1)), int(mm.group(2))
+            if k_ in (64, 128):
+                return "gemm1x1_rowreg"
+            if k_ >= 256 and k_ % 128 == 0 and n_ <= 192:
+                return "gemm1x1_rowacc"
             return "gemm1x1"
 
         groups = {}

@@ -49,7 +49,10 @@ def main():
         "hbm_bytes_per_launch_conv3x3_wino": per_class(lambda k: k.startswith("conv3x3_wino_kernel")),
         "hbm_bytes_per_launch_conv3x3_wino4": per_class(lambda k: k.startswith("conv3x3_wino4")),
         "hbm_bytes_per_launch_conv3x3_bf16": per_class(lambda k: k.startswith("conv3x3_bf16") or k.startswith("conv3x3_halo_bf16")),
-        "hbm_bytes_per_launch_gemm1x1_bf16": per_class(lambda k: k.startswith("gemm1x1_")),
+        "hbm_bytes_per_launch_gemm1x1_bf16": per_class(lambda k: k.startswith("gemm1x1_bf16")),
+        "hbm_bytes_per_launch_gemm1x1_rowreg": per_class(lambda k: k.startswith("gemm1x1_rowreg")),
+        "hbm_bytes_per_launch_gemm1x1_rowacc": per_class(lambda k: k.startswith("gemm1x1_rowacc")),
+        "hbm_bytes_per_launch_gemm1x1_family": per_class(lambda k: k.startswith("gemm1x1_")),
         "hbm_bytes_per_launch_fp32": per_class(lambda k: is_conv(k) and "bf16" not in k and "wino" not in k and not k.startswith("gemm1x1_")),
         "per_kernel": {k: {"launches": fetch[k][0], "fetch_kib_raw_avg": fetch[k][1] / fetch[k][0],
                            "write_kib_avg": (write[k][1] / write[k][0]) if k in write else None}
