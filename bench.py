@@ -592,7 +592,7 @@ def main():
 
         KINDS = {
             "conv3x3_wino4": ("hbm_bytes_per_launch_conv3x3_wino4",
-                              "conv3x3_wino4_kernel (the 64-channel level-0 3x3 ResBlock convs in Winograd F(4x4,3x3) form on the points 0, +-3/4, +-3/2, inf: "
+                              "conv3x3_wino4_kernel (the 3x3 ResBlock convs of 64 input channels at level 0 and of up to 128 at level 1 in Winograd F(4x4,3x3) form on the points 0, +-3/4, +-3/2, inf: "
                               "36 multiplies per 4x4 output tile instead of 144; transformed fp32 operands split exactly into 3 bf16 pieces, 8 of the 9 cross terms, "
                               "two per v_mfma_f32_16x16x32_bf16, fp32 accumulate)"),
             "conv3x3_wino": ("hbm_bytes_per_launch_conv3x3_wino",
