@@ -619,13 +619,15 @@ struct Eval {
         rel(at);
         return o;
     }
-    T2 temporal(const AT& a, const T2& x, int Fr, int H, int W) {
+    // inplace: the caller owns x and drops it right after -- the fused single-launch layer then writes over it (include/dawn_hip.h: `out`
+    // may be `x` when the layer covers its whole frame buffer); the result aliases x, the caller must not release it (o.p == x.p)
+    T2 temporal(const AT& a, const T2& x, int Fr, int H, int W, bool inplace = false) {
         if (sc) return temporal_sharded(a, x, Fr, H, W);
         const int HW = H * W, win = c->cfg.win;
         T2 o;
         const bool seg_ok = a.C == 64 && win <= 40;
         if (can_fuse_temporal(a.C, Fr, Fr, win) && (Fr <= 200 || !seg_ok)) {
-            o = t2(x.rows, 64);
+            o = inplace ? x : t2(x.rows, 64);
             LAUNCH(dawn_temporal_layer_c64_ex(x.p, Fr, HW, 0, Fr, win, a.wqkv, a.wqkv_s, a.wout, a.wout_sp, clipf(L.rcos), clipf(L.rsin),
                                               clipf(L.band), 1e-5f, o.p, c->temporal_flags, cur));
             return o;
@@ -676,12 +678,12 @@ struct Eval {
         rel(at);
         return o;
     }
-    T2 spatial_linear(const AT& a, const T2& x, int Fr, int H, int W) {
+    T2 spatial_linear(const AT& a, const T2& x, int Fr, int H, int W, bool inplace = false) {
         const int HW = H * W;
         T2 o;
         if (a.C == 64) {
             float* ws = falloc((size_t)dawn_sla_ws_floats(Fr, HW, a.wqkv_s != nullptr));
-            o = t2(x.rows, 64);
+            o = inplace ? x : t2(x.rows, 64);                      // (as temporal(): `out` may be `x`)
             LAUNCH(dawn_sla_layer_c64(x.p, Fr, HW, a.wqkv, a.wqkv_s, a.wout, a.bout, 1e-5f, ws, o.p, cur));
             A.free(ws);
             return o;
@@ -749,8 +751,8 @@ struct Eval {
             Level& lv = c->downs[l];
             T2 y = resblock(lv.rb1, x, nullptr, F, H, W, film); rel(x); x = y;
             y = resblock(lv.rb2, x, nullptr, F, H, W, film); rel(x); x = y;
-            y = spatial_linear(lv.sla, x, F, H, W); rel(x); x = y;
-            y = temporal(lv.tattn, x, F, H, W); rel(x); x = y;
+            y = spatial_linear(lv.sla, x, F, H, W, !sc); if (y.p != x.p) rel(x); x = y;
+            y = temporal(lv.tattn, x, F, H, W, true); if (y.p != x.p) rel(x); x = y;
             skips.push_back({x, H, W});
             if (lv.rs_w) {
                 T2 dn = t2((long)F * (H / 2) * (W / 2), x.C);
@@ -780,8 +782,8 @@ struct Eval {
             T2 y = resblock(lv.rb1, x, &sk.t, F, H, W, film);     // torch.cat((x, h.pop())) MT:948
             rel(x); rel(sk.t); x = y;
             y = resblock(lv.rb2, x, nullptr, F, H, W, film); rel(x); x = y;
-            y = spatial_linear(lv.sla, x, F, H, W); rel(x); x = y;
-            y = temporal(lv.tattn, x, F, H, W); rel(x); x = y;
+            y = spatial_linear(lv.sla, x, F, H, W, !sc); if (y.p != x.p) rel(x); x = y;
+            y = temporal(lv.tattn, x, F, H, W, true); if (y.p != x.p) rel(x); x = y;
             if (lv.rs_w) {
                 T2 up = t2((long)F * (2 * H) * (2 * W), x.C);
                 ConvArgs a;

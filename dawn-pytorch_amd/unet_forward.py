@@ -170,14 +170,14 @@ def _chunks(a: int, b: int, n: int):
     return [(i, min(i + n, b)) for i in range(a, b, n)]
 
 
-def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState, hx=None) -> Tensor:
+def _temporal(ops, a: PackedAttn, x: Tensor, F: int, H: int, W: int, cs: ClipState, hx=None, inplace: bool = False) -> Tensor:
     HW = H * W
     if cs.comm is not None:
         return _temporal_sharded(ops, a, x, F, H, W, cs, hx)
     xe, q0, Fext = x, 0, F
     if ops.can_fuse_temporal(a.C, Fext, F, cs.win) and (Fext <= 200 or not ops.can_fuse_temporal_segmented(a.C, cs.win)):
         return ops.temporal_layer_c64(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
-                                      wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp)
+                                      wqkv_bf3=a.wqkv_s, wout_bf3p=a.wout_sp, out=xe if inplace else None)
     if ops.can_fuse_temporal_segmented(a.C, cs.win):
         # long frame buffers (clips > 200 frames): the fused layer, one launch per 120-query segment
         return ops.temporal_layer_c64_segmented(xe, Fext, HW, q0, F, cs.win, a.wqkv, a.wout, cs.rcos, cs.rsin, cs.band,
@@ -300,9 +300,13 @@ def _spatial_then_temporal(ops, sp, tattn: PackedAttn, holder: list, F: int, H: 
     one level-0 tensor more at the allocator peak of a long shard (5.8 instead of 4.8 MB per own frame at 256 x 256)."""
     x = holder.pop()
     if cs.comm is None or not hasattr(cs.comm, "own_view"):
-        y = spatial(ops, sp, x, F, H, W)
+        # the fused 64-channel layers run IN PLACE (this function holds the only reference to x): a workgroup of either kernel reads
+        # the rows of its own pixels before it writes them, nobody else touches them -- one level-0 tensor (210 MB) less through the
+        # caches per layer, +0.25 % frames/s (profiles/r5_ab_attention_layers_in_place.txt)
+        c64 = x.shape[1] == 64
+        y = spatial(ops, sp, x, F, H, W, out=x) if c64 else spatial(ops, sp, x, F, H, W)
         del x
-        return _temporal(ops, tattn, y, F, H, W, cs)
+        return _temporal(ops, tattn, y, F, H, W, cs, inplace=c64)
     HW, C = H * W, x.shape[1]
 
     def produce(fa, fb, o):

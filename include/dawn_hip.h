@@ -207,7 +207,10 @@ int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, in
  * the benchmark clip); flags & 16 adds explicit sched_group_barrier MFMA/VALU interleave hints to WMODE 3 (measured: within noise, 1550 vs 1513 us); flags & 32 keeps
  * the out-projection of WMODE 3 on the fp32 MFMA even when wout_bf3p is given.  wout_bf3p (optional, WMODE 3): the exact
  * 3-way bf16 split of to_out with the rows of every head permuted to the accumulator order of O^T, [256/16][3][2][64][8]
- * (pack.pack_bf3_temporal_out).  All families compute the same function to fp32 round-off. */
+ * (pack.pack_bf3_temporal_out).  All families compute the same function to fp32 round-off.
+ * `out` MAY BE `x` when the layer covers its whole frame buffer (q0 == 0, Fq == Fext): a workgroup reads the rows of its pixel
+ * before it writes them and no other workgroup touches them (the denoiser's unsharded 64-channel layers run that way:
+ * one tensor less through the caches). */
 int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
                                const void* wqkv_bf3, const float* wout, const void* wout_bf3p, const float* rot_cos,
                                const float* rot_sin, const float* band, float eps, float* out, int flags, void* stream);
@@ -222,7 +225,8 @@ int dawn_sla_apply(const float* qkv, const float* ctx, int F, int HW, float* out
  * wqkv_bf3 (optional): the exact 3-way bf16 split of wqkv, [64/16][3][2][768][8] (pack_bf3 order): the context
  * kernel then runs its K / V projections on the bf16 matrix pipe (fp32 results) in a single sweep with a running
  * column max, sliced over the frame's pixels so that every CU works (partials merged by a small second kernel), and the
- * apply kernel runs its Q projection there; NULL = two-sweep fp32-MFMA kernels. */
+ * apply kernel runs its Q projection there; NULL = two-sweep fp32-MFMA kernels.  `out` MAY BE `x`: the context kernel(s) have read
+ * every row before the apply kernel starts, and an apply workgroup reads its own rows before it writes them. */
 long dawn_sla_ws_floats(int F, int HW, int split);
 int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wqkv, const void* wqkv_bf3, const float* wout,
                        const float* bias, float eps, float* M_ws, float* out, void* stream);

@@ -958,6 +958,30 @@ def test_sla_layer_c64(hip, ref, F, HW):
     check(f"sla_layer_c64_split/F{F}_HW{HW}", got, want, 3e-5)
 
 
+@pytest.mark.parametrize("F,HW", [(200, 256), (96, 1024), (200, 100)])
+def test_c64_attention_layers_in_place(hip, F, HW):
+    """include/dawn_hip.h: `out` may be `x` for dawn_sla_layer_c64 and, when the layer covers its whole frame buffer, for
+    dawn_temporal_layer_c64_ex (the denoiser's unsharded 64-channel layers run in place).  In place == out of place, bit for bit, for
+    every kernel family the benchmark's shapes take (fp32-MFMA and split-operand forms; many workgroups per CU slot at HW = 1024)."""
+    from dawn_pytorch_amd.pack import pack_bf3, pack_bf3_temporal_out, unpack_kn
+    win = 40
+    x = (rnd(F * HW, 64, seed=1) * 1.3 + 0.2).cuda()
+    wqkv, wout, bias = packw(64, 768, seed=2), packw(256, 64, seed=3), rnd(64, seed=4)
+    ang = torch.arange(F).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
+    rc, rs, band = ang.cos().contiguous().cuda(), ang.sin().contiguous().cuda(), rnd(2 * win + 1, 8, seed=5).cuda()
+    wsplit, wosp = pack_bf3(unpack_kn(wqkv)).cuda(), pack_bf3_temporal_out(unpack_kn(wout)).cuda()
+    for kw in ({}, {"wqkv_bf3": wsplit, "wout_bf3p": wosp}):
+        want = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
+        xin = x.clone()
+        got = hip.temporal_layer_c64(xin, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, out=xin, **kw)
+        assert got is xin and torch.equal(got, want)
+    for kw in ({}, {"wqkv_bf3": wsplit}):
+        want = hip.sla_layer_c64(x, F, HW, *gpu(wqkv, wout, bias), **kw)
+        xin = x.clone()
+        got = hip.sla_layer_c64(xin, F, HW, *gpu(wqkv, wout, bias), out=xin, **kw)
+        assert got is xin and torch.equal(got, want)
+
+
 def test_sla_softmax_reference_is_shift_safe(hip, ref):
     """The single-sweep linear-attention kernels keep a lazily raised softmax reference (raised only when a tile exceeds it by
     2^8) and merge slices by their references: logits with a large dynamic range and a strong trend along the pixel axis (every
