@@ -494,7 +494,7 @@ struct Eval {
         gn_coeffs(part, nblk, total_rows, Co, rb.g1, rb.be1, fs, fsh, ab1, ab1 + Co);
         T2 h1;
         if (fuse_h1) {
-            h1 = t2(rows, Co);
+            h1 = c1;                                    // written OVER c1 (the epilogue reads an element of c1, writes the same element of h1)
             if (h1_c64) {
                 LAUNCH(dawn_xattn_layer_c64_h1(x.p, x.C, x.C, x2 ? x2->p : nullptr, x2 ? x2->C : 0, x2 ? x2->C : 0, rows, HW, rb.wq, rb.wqs,
                                                rb.g3, clipf(xt_h1), 1e-5f, c1.p, ab1, ab1 + Co, h1.p, cur));
@@ -507,7 +507,8 @@ struct Eval {
             if (rb.conditioned) join();
             h1 = gn_apply_res(c1, ab1, ab1 + Co, hcond.p);
         }
-        rel(c1); A.free(ab1); A.free(part);
+        if (h1.p != c1.p) rel(c1);
+        A.free(ab1); A.free(part);
         if (hcond.p) rel(hcond);
         double* part2 = gn_part_alloc(rows, Co);
         int nblk2 = 0;

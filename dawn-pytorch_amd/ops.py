@@ -358,17 +358,18 @@ class HipOps:
         return Co % 32 == 0 and 32 <= Co <= 512 and HW % 4 == 0
 
     def xattn_sigma_out(self, q: Tensor, HW: int, xtab: Tensor, g3: Tensor, Co: int, eps: float = 1e-5,
-                        gn: Optional[Tuple[Tensor, Tensor, Tensor]] = None) -> Tensor:
+                        gn: Optional[Tuple[Tensor, Tensor, Tensor]] = None, h1_over_c1: bool = False) -> Tensor:
         """q (rows,192) = raw to_q output -> h_cond (rows,Co): the 2-key attention, the three to_out projections, their
         LayerNorms and the branch sum in one pass (per-clip tables `xtab` from xattn_tables).  gn = (c1, a, b): returns the block's
-        h1 = SiLU(c1*a + b) + h_cond instead (MT:473-476: no h_cond tensor, no GroupNorm-apply pass)."""
+        h1 = SiLU(c1*a + b) + h_cond instead (MT:473-476: no h_cond tensor, no GroupNorm-apply pass); h1_over_c1: written over c1
+        (the epilogue reads an element of c1 and writes the same element of h1: include/dawn_hip.h)."""
         rows = q.shape[0]
         _need(q.is_contiguous() and q.shape[1] == 192 and xtab.is_contiguous() and xtab.shape[1:] == (3, 64 + 9 * Co), "xattn_sigma_out: q.is_contiguous() and q.shape[1] == 192 and xtab.is_contiguous() and xtab.shape[1:] == (3, 64 + 9 * Co)")
         _need(rows == xtab.shape[0] * HW, "xattn_sigma_out: rows == xtab.shape[0] * HW")
         self._require(q, xtab, g3)
-        out = self.empty(rows, Co, like=q)
         gx, ga, gb = gn if gn is not None else (None, None, None)
         _need(gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, Co)), "xattn_sigma_out: gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, Co))")
+        out = gx if (h1_over_c1 and gx is not None) else self.empty(rows, Co, like=q)
         self._require(gx, ga, gb)
         check(self.L.dawn_xattn_sigma_out_h1(_p(q), rows, HW, _p(xtab), _p(g3), Co, eps, _p(gx), _p(ga), _p(gb), _p(out),
                                              self._stream()), "dawn_xattn_sigma_out")
@@ -376,18 +377,20 @@ class HipOps:
 
     def xattn_layer_c64(self, x: Tensor, x2: Optional[Tensor], HW: int, wq: Tensor, wo, g3: Tensor, q_scale: Tensor,
                         kvtab: Tensor, nulltab: Tensor, eps: float = 1e-5, xtab: Optional[Tensor] = None,
-                        wq_bf3: Optional[Tensor] = None, gn: Optional[Tuple[Tensor, Tensor, Tensor]] = None) -> Tensor:
+                        wq_bf3: Optional[Tensor] = None, gn: Optional[Tuple[Tensor, Tensor, Tensor]] = None,
+                        h1_over_c1: bool = False) -> Tensor:
         """h_cond (rows,64) = sum over the three branches of LN(to_out(attn(LN(x)))) in one launch.  The kernel reads
         the per-clip tables `xtab` (xattn_tables of kvtab / nulltab / q_scale / wo); built here if not supplied.
-        `wq_bf3` (pack_bf3 of to_q) puts the Q projection on the bf16 matrix pipe (exact operand split)."""
+        `wq_bf3` (pack_bf3 of to_q) puts the Q projection on the bf16 matrix pipe (exact operand split).  h1_over_c1 (with gn): the
+        block's h1 is written over c1 (see xattn_sigma_out)."""
         rows = x.shape[0]
         if xtab is None:
             xtab = self.xattn_tables(kvtab, nulltab, q_scale, wo, 64)
         self._require(x, x2, wq, g3, xtab)
         _need(xtab.is_contiguous() and xtab.shape[1:] == (3, 640) and rows == xtab.shape[0] * HW, "xattn_layer_c64: xtab.is_contiguous() and xtab.shape[1:] == (3, 640) and rows == xtab.shape[0] * HW")
-        out = self.empty(rows, 64, like=x)
         gx, ga, gb = gn if gn is not None else (None, None, None)       # (c1, a, b): write h1 = SiLU(c1*a + b) + h_cond instead of h_cond
         _need(gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, 64)), "xattn_layer_c64: gx is None or (gx.is_contiguous() and tuple(gx.shape) == (rows, 64))")
+        out = gx if (h1_over_c1 and gx is not None) else self.empty(rows, 64, like=x)
         self._require(gx, ga, gb)
         check(self.L.dawn_xattn_layer_c64_h1(_p(x), x.shape[1], _ld(x), _p(x2), 0 if x2 is None else x2.shape[1], _ld(x2),
                                              rows, HW, _p(wq), _p(wq_bf3), _p(g3), _p(xtab), eps, _p(gx), _p(ga), _p(gb), _p(out),

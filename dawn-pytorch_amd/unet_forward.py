@@ -113,11 +113,11 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
         """h_cond -- or, with gn = (c1, a, b), the block's h1 = SiLU(GN(c1)) + h_cond straight from the kernel's epilogue."""
         if fused_c64:
             return ops.xattn_layer_c64(x, x2, H * W, rb.wq, rb.wo, rb.g3, rb.q_scale, cs.kvtab[rb.cond_index],
-                                       cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index], wq_bf3=rb.wqs, gn=gn)
+                                       cs.nulltab[rb.cond_index], xtab=cs.xtab[rb.cond_index], wq_bf3=rb.wqs, gn=gn, h1_over_c1=True)
         # LayerNorm_img is materialised (one streaming pass) so that to_q runs as a prologue-free GEMM
         q = _ln_gemm(ops, x, x2, rb.wq, 192, rb.wqs, **g)
         if fused_out:
-            return ops.xattn_sigma_out(q, H * W, cs.xtab[rb.cond_index], rb.g3, Co, gn=gn)
+            return ops.xattn_sigma_out(q, H * W, cs.xtab[rb.cond_index], rb.g3, Co, gn=gn, h1_over_c1=True)
         ops.xattn_core(q, H * W, cs.kvtab[rb.cond_index], cs.nulltab[rb.cond_index], rb.q_scale)
         y3 = ops.empty(F * H * W, 3 * Co, like=x)
         for b in range(3):
@@ -140,8 +140,8 @@ def _resblock(ops, rb: PackedResBlock, x: Tensor, x2: Optional[Tensor], F: int, 
             # no h_cond tensor, no GroupNorm-apply pass (20 launches and 0.42 GB per level-0 block less per evaluation).  The
             # two-stream overlap this replaces bought nothing on a power-limited chip (profiles/r3_*: 145.4 vs 140 frames/s without it)
             c1, ab1 = conv1_and_stats()
-            h1 = cross_attention(gn=(c1, ab1[0], ab1[1]))
-            del c1                   # (dropped as soon as its last reader is enqueued: peak memory, max clip length)
+            h1 = cross_attention(gn=(c1, ab1[0], ab1[1]))           # (written OVER c1: one tensor less through the caches)
+            del c1
         else:
             # the HBM-bound cross-attention chain and the MFMA-bound conv1 + GroupNorm statistics only meet at
             # h1 = SiLU(GN(c1)) + h_cond: run them on two HIP streams so that they overlap on the GPU

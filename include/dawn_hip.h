@@ -170,7 +170,8 @@ int dawn_xattn_sigma_out(const float* q, long rows, int HW, const float* xtab, c
  * wq_bf3 (optional): the exact 3-way bf16 split of wq, [Cin/16][3][2][192][8] (pack_bf3 order): to_q then runs on the bf16
  * matrix pipe (fp32 results, 6 cross terms); NULL = fp32-MFMA projection. */
 /* ... and the block's h1 = SiLU(FiLM(GroupNorm(c1))) + h_cond (MT:473-476) written straight from the epilogue: gn_x = c1 (rows, 64),
- * (gn_a, gn_b) = the per-channel coefficients of dawn_gn_finalize -- no h_cond tensor and no dawn_gn_apply_res pass (NULL: h_cond) */
+ * (gn_a, gn_b) = the per-channel coefficients of dawn_gn_finalize -- no h_cond tensor and no dawn_gn_apply_res pass (NULL: h_cond).
+ * `out` MAY BE `gn_x` (here and in dawn_xattn_sigma_out_h1): the epilogue reads an element of c1 and writes the same element of h1. */
 int dawn_xattn_layer_c64_h1(const float* in0, int C0, int ld0, const float* in1, int C1, int ld1, long rows, int HW,
                             const float* wq, const void* wq_bf3, const float* g3, const float* xtab, float eps, const float* gn_x,
                             const float* gn_a, const float* gn_b, float* out, void* stream);

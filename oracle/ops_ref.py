@@ -184,7 +184,7 @@ class RefOps:
     def can_fuse_xattn_out(Co, HW):
         return Co % 32 == 0 and 32 <= Co <= 512 and HW % 4 == 0
 
-    def xattn_sigma_out(self, q, HW, xtab, g3, Co, eps=1e-5, gn=None):
+    def xattn_sigma_out(self, q, HW, xtab, g3, Co, eps=1e-5, gn=None, h1_over_c1=False):
         """Reference of the one-pass kernel, evaluated from the per-clip tables (the tables themselves are checked
         against the definitions by test_xattn_tables, the whole chain against the original formulation by
         test_xattn_sigma_out_equals_unfused_chain)."""
@@ -217,7 +217,7 @@ class RefOps:
             out[:, b, 64 + 8 * Co:] = y0[None]
         return out.float().to(kvtab.device)
 
-    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5, xtab=None, wq_bf3=None, gn=None):
+    def xattn_layer_c64(self, x, x2, HW, wq, wo, g3, q_scale, kvtab, nulltab, eps=1e-5, xtab=None, wq_bf3=None, gn=None, h1_over_c1=False):
         """The ORIGINAL formulation (MT:516-559 op by op); `xtab` (the kernel's per-clip tables) is not used here, so the
         GPU test of the fused kernel also proves the table algebra."""
         rows = x.shape[0]

@@ -800,6 +800,9 @@ def test_xattn_h1_epilogue(hip, ref, Co, C0, Fn, HW):
             hc = hip.xattn_layer_c64(x.cuda(), None, HW, wq.cuda(), None, g3.cuda(), None, None, None, **kw)
             h1 = hip.xattn_layer_c64(x.cuda(), None, HW, wq.cuda(), None, g3.cuda(), None, None, None, gn=gn, **kw)
             check(f"xattn_h1/c64_C{C0}_split{int(bf3 is not None)}", h1, hip.gn_apply_res(*gn, hc), 2e-6)
+            c1g = gn[0].clone()                                      # ... and written OVER c1 (include/dawn_hip.h: out may be gn_x): the same bits
+            over = hip.xattn_layer_c64(x.cuda(), None, HW, wq.cuda(), None, g3.cuda(), None, None, None, gn=(c1g, gn[1], gn[2]), h1_over_c1=True, **kw)
+            assert over is c1g and torch.equal(over, h1)
         want = ref.xattn_layer_c64(x, None, HW, wq, wo, g3, qs, kvtab, nulltab, gn=(c1, ga, gb))
         check(f"xattn_h1/c64_C{C0}_vs_ref", h1, want, 3e-5)
     else:
@@ -807,6 +810,9 @@ def test_xattn_h1_epilogue(hip, ref, Co, C0, Fn, HW):
         hc = hip.xattn_sigma_out(q.cuda(), HW, xtab, g3.cuda(), Co)
         h1 = hip.xattn_sigma_out(q.cuda(), HW, xtab, g3.cuda(), Co, gn=gn)
         check(f"xattn_h1/sigma_out_Co{Co}", h1, hip.gn_apply_res(*gn, hc), 2e-6)
+        c1g = gn[0].clone()
+        over = hip.xattn_sigma_out(q.cuda(), HW, xtab, g3.cuda(), Co, gn=(c1g, gn[1], gn[2]), h1_over_c1=True)
+        assert over is c1g and torch.equal(over, h1)
         check(f"xattn_h1/sigma_out_Co{Co}_vs_ref", h1, ref.xattn_sigma_out(q, HW, ref.xattn_tables(kvtab, nulltab, qs, wo, Co), g3, Co, gn=(c1, ga, gb)), 3e-5)
 
 
