@@ -1891,6 +1891,19 @@ __global__ __launch_bounds__(512) void gemm1x1_rowreg_kernel(const dawn_conv_des
         // one per-lane byte offset per source (row l31, k-half); the channel chunk goes into the scalar / immediate offset (16 separate
         // offset registers otherwise, hoisted out of the unit loop)
         const unsigned vo0 = (unsigned)((l31 * d.ld0 + 8 * half) * 4), vo1 = (unsigned)((l31 * ld1 + 8 * half) * 4);
+#ifdef DAWN_ABLATION
+        // perf ablation (wrong results: the right bytes in the wrong lanes): 8 rows x 128 contiguous bytes per instruction instead of 32 rows x 32 bytes
+        if (d.policy & 0x40000000) {
+#pragma unroll
+            for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int j = kc * 2 + h2, row = (lane >> 3) + 8 * (j & 3), ch = 4 * ((lane & 7) + 8 * (j >> 2));
+                    raw[kc][h2] = __builtin_bit_cast(f32x4, ch < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((row * d.ld0 + ch) * 4), 0, 0)
+                                                                       : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((row * ld1 + ch - d.C0) * 4), 0, 0));
+                }
+        } else
+#endif
 #pragma unroll
         for (int kc = 0; kc < KS; ++kc) {
             const int cb = 16 * kc;                        // wave-uniform: C0 % 16 == 0
@@ -2088,14 +2101,31 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
             const __amdgpu_buffer_rsrc_t rb =
                 __builtin_amdgcn_make_buffer_rsrc((void*)((d.in1 ? d.in1 : d.in0) + r0 * ld1), 0, 32 * ld1 * 4, 0x00020000);
             if (kb == 0 && d.row_mean) { mu = d.row_mean[r0 + l31]; rs = d.row_rstd[r0 + l31]; }
+            const int lrow = l31;
+#ifdef DAWN_ABLATION
+            // perf ablation (wrong results: the right bytes in the wrong lanes): the same 32 rows x 64 channels, fetched as 8 rows x 128 contiguous
+            // bytes per instruction (8 line touches instead of 32) -- what would a coalesced fetch + a free transpose buy?
+            if (d.policy & 0x40000000) {
+#pragma unroll
+                for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int j = kc * 2 + h2, row = (lane >> 3) + 8 * (j & 3), piece = (lane & 7) + 8 * (j >> 2);
+                        const int cb = kb * KBC + 4 * piece;
+                        raw[kc][h2] = __builtin_bit_cast(
+                            f32x4, kb * KBC < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((row * d.ld0 + cb) * 4), 0, 0)
+                                                   : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((row * ld1 + cb - d.C0) * 4), 0, 0));
+                    }
+            } else
+#endif
 #pragma unroll
             for (int kc = 0; kc < KS; ++kc) {
                 const int cb = kb * KBC + 16 * kc;             // wave-uniform: C0 % 16 == 0
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2)
                     raw[kc][h2] = __builtin_bit_cast(
-                        f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((l31 * d.ld0 + cb + 8 * half + 4 * h2) * 4), 0, 0)
-                                         : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((l31 * ld1 + cb - d.C0 + 8 * half + 4 * h2) * 4), 0, 0));
+                        f32x4, cb < d.C0 ? __builtin_amdgcn_raw_buffer_load_b128(ra, (unsigned)((lrow * d.ld0 + cb + 8 * half + 4 * h2) * 4), 0, 0)
+                                         : __builtin_amdgcn_raw_buffer_load_b128(rb, (unsigned)((lrow * ld1 + cb - d.C0 + 8 * half + 4 * h2) * 4), 0, 0));
             }
         } else {
             // a 32-pixel tile lies in one frame (host check): frame-sized descriptor, the lane's offset = its tap pixel
@@ -2111,7 +2141,23 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
                 ix = px_ + ((tap & 1) ? (ppx ? 1 : -1) : 0);
             }
             const bool inb = iy >= 0 && iy < d.Hi && ix >= 0 && ix < d.Wi;
-            const unsigned off = inb ? (unsigned)(((iy * d.Wi + ix) * d.ld0 + c0 + 8 * half) * 4) : 0xffffff00u;   // padding reads 0
+            unsigned off = inb ? (unsigned)(((iy * d.Wi + ix) * d.ld0 + c0 + 8 * half) * 4) : 0xffffff00u;   // padding reads 0
+#ifdef DAWN_ABLATION
+            // perf ablation (wrong results by design): every lane gathers the pixel of lane 0 -- one cache line per instruction instead of 32:
+            // what do the scattered line touches of the gather cost?
+            if (d.policy & 0x40000000) {
+                // ... as MODE 0: 8 pixels x 128 contiguous bytes per instruction; the pixel's offset comes from the lane that owns it
+                const unsigned pbase = inb ? off - (unsigned)(8 * half * 4) : 0xffffff00u;
+#pragma unroll
+                for (int kc = 0; kc < KS; ++kc)
+#pragma unroll
+                    for (int h2 = 0; h2 < 2; ++h2) {
+                        const int j = kc * 2 + h2, row = (lane >> 3) + 8 * (j & 3), piece = (lane & 7) + 8 * (j >> 2);
+                        const unsigned pb = (unsigned)__shfl((int)pbase, row, 64);
+                        raw[kc][h2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, pb >= 0xffffff00u ? pb : pb + (unsigned)(16 * piece), 0, 0));
+                    }
+            } else
+#endif
 #pragma unroll
             for (int kc = 0; kc < KS; ++kc)
 #pragma unroll
