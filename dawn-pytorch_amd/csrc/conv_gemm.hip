@@ -2093,8 +2093,12 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
         if (MODE == 1) { const int oy = rem / d.Wo; py_ = 2 * oy - 1; px_ = 2 * (rem - oy * d.Wo) - 1; }
         else { py_ = rem / d.Wi; px_ = rem - py_ * d.Wi; }
     };
-    auto load_block = [&](long panel, int kb) __attribute__((always_inline)) {
-        f32x4 raw[KS][2];
+    // the rows of K block kb of the wave's 32 rows -> `raw` (2 KS loads per lane; split_rows() turns them into the operand planes).  In the
+    // implicit-GEMM modes the fetch of block kb + 1 is issued BEFORE the multiplies of block kb (round 5: fetch -> wait -> split -> multiply ran back to back
+    // per block, every wave of the workgroup at the same point -- the barrier per step keeps them in lockstep --, so each block sat out
+    // one full memory round trip: 10.7 k cycles per block against 3 k of matrix work at the level-0 resampling convs)
+    f32x4 raw[KS][2];
+    auto fetch_rows = [&](long panel, int kb) __attribute__((always_inline)) {
         if (MODE == 0) {
             const long r0 = panel * BM + wave * 32;
             const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc((void*)(d.in0 + r0 * d.ld0), 0, 32 * d.ld0 * 4, 0x00020000);
@@ -2164,6 +2168,11 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
                 for (int h2 = 0; h2 < 2; ++h2)
                     raw[kc][h2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ra, inb ? off + (unsigned)((16 * kc + 4 * h2) * 4) : off, 0, 0));
         }
+    };
+    auto split_rows = [&]() __attribute__((always_inline)) {
+        // (nothing of the split moves above this point: the scheduler otherwise hoists it -- and the wait for the rows in flight -- in front
+        //  of the previous block's multiplies once both sit in one basic block, which is exactly the overlap the prefetch is for)
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int kc = 0; kc < KS; ++kc) {
             float v8[8];
@@ -2222,20 +2231,44 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
             for (int r = 0; r < 16; ++r) acc[c][j][r] = 0.f;
     float* stg = reinterpret_cast<float*>(smem_b + 2 * CHB) + wave * (32 * 36);
     int buf = 0;
+    // (row prefetch: the resampling convs only -- the 1x1 variants hold 228..256 registers without the 32 / 64 of a block in flight)
+    constexpr bool PRE = MODE != 0;
+    // ... across units too for the transposed conv (K = 4 taps x C: 4..16 blocks per unit, the first one a quarter of them); the strided conv
+    // (16 taps) measured faster with its first block fetched at the top of the unit (profiles/r5_resample_row_prefetch.txt)
+    constexpr bool CROSS = MODE == 2;
     issueB(p0, 0, 0, 0);
+    if (CROSS) { locate(p0 / ngrp); fetch_rows(p0 / ngrp, 0); }     // the workgroup's very first block: nothing to hide it behind
     for (long unit = p0; unit < p1; ++unit) {
         const long panel = unit / ngrp;
         const int cg = (int)(unit - panel * ngrp) * NCH;
-        locate(panel);
+        if (!CROSS) locate(panel);
         if (MODE == 0 && d.ln_eps > 0.f) ln_stats(panel);
         for (int kb = 0; kb < nKB; ++kb) {
-            load_block(panel, kb);                          // the only VMEM loads of the loop besides the weight requests
+            if (!PRE || (!CROSS && kb == 0)) fetch_rows(panel, kb);
+            split_rows();
             const bool last_kb = kb == nKB - 1;
+            // the NEXT block's rows -- of this unit, or the first block of the next one (under this unit's last multiplies and epilogue) --
+            // go out here, in flight under this block's multiplies.  ONE fetch site in the loop: with two, the compiler copies the
+            // loaded registers into the loop-carried ones right away and waits for every load in front of the multiplies
+            bool pre_issued = false;
+            if (PRE) {
+                long npanel = panel;
+                int nkb = kb + 1;
+                pre_issued = true;
+                if (last_kb) {
+                    nkb = 0;
+                    pre_issued = CROSS && unit + 1 < p1;
+                    npanel = (unit + 1) / ngrp;
+                    if (pre_issued) locate(npanel);         // (locate() state is only read by fetch_rows: nothing of this unit needs it any more)
+                }
+                if (pre_issued) fetch_rows(npanel, nkb);
+            }
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 // weights of this step have landed (requested one step ago; VMEM completes in issue order: after an epilogue
-                // with no row fetch since, its 8 stores may stay in flight)
+                // with no row fetch since, its 8 stores may stay in flight; behind the row prefetch just issued, its 2 KS loads may)
                 if (c > 0 && last_kb && !(d.bias || d.res || d.tr)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+                else if (c == 0 && pre_issued) { if (KS == 4) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(16)" ::: "memory"); }
                 else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
                 {   // request the next step's chunk into the other buffer
