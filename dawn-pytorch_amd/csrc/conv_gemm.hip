@@ -2232,6 +2232,7 @@ __global__ __launch_bounds__(512) void gemm1x1_rowacc_kernel(const dawn_conv_des
     float* stg = reinterpret_cast<float*>(smem_b + 2 * CHB) + wave * (32 * 36);
     int buf = 0;
     // (row prefetch: the resampling convs only -- the 1x1 variants hold 228..256 registers without the 32 / 64 of a block in flight)
+    // (tried for the N = 128 projections as well: 10 spilled registers, -2 %: not worth the scratch)
     constexpr bool PRE = MODE != 0;
     // ... across units too for the transposed conv (K = 4 taps x C: 4..16 blocks per unit, the first one a quarter of them); the strided conv
     // (16 taps) measured faster with its first block fetched at the top of the unit (profiles/r5_resample_row_prefetch.txt)
