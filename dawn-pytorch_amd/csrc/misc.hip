@@ -57,9 +57,13 @@ __global__ __launch_bounds__(256) void init_conv_x_mfma_kernel(const float* __re
     float* Ps = sm + KP * Co;       // [3][TR+6][w+6]
     const int tid = threadIdx.x;
     const int tiles_per_frame = h / TR;
-    const int f = blockIdx.x / tiles_per_frame;
-    const int y0 = (blockIdx.x - f * tiles_per_frame) * TR;
+    // persistent: the 38 KB of weights are staged ONCE per workgroup (round 5: one tile per workgroup re-staged them 3,200 times per launch --
+    // 121 MB of L2 reads and a third of a tile's time in front of its 7.9 us of matrix work); a workgroup walks the tiles blockIdx.x, + grid, ...
     for (int i = tid; i < KP * Co; i += 256) Ws[i] = i < 147 * Co ? w3[i] : 0.f;
+    for (int tile = blockIdx.x; tile < F * tiles_per_frame; tile += gridDim.x) {
+    const int f = tile / tiles_per_frame;
+    const int y0 = (tile - f * tiles_per_frame) * TR;
+    __syncthreads();                                     // (the previous tile's patch is no longer read)
     for (int i = tid; i < 3 * PS; i += 256) {
         const int c = i / PS, rem = i - c * PS;
         const int py = rem / PW, px = rem - py * PW;
@@ -112,6 +116,7 @@ __global__ __launch_bounds__(256) void init_conv_x_mfma_kernel(const float* __re
                 *reinterpret_cast<f32x4*>(op + n) = v + *reinterpret_cast<const f32x4*>(fp + n);
             }
     }
+    }   // tile loop
 }
 
 // heads (MT:863, 876, 956): eps[0:2] = Wg.hg + bg ; eps[2] = Wo.ho + bo ; output layout (3, rows)
@@ -191,7 +196,9 @@ extern "C" int dawn_init_conv_x_ex(const float* x, long plane_stride, const floa
     if (Co == 64 && w <= 256 && 256 % w == 0 && h % (256 / w) == 0 && (256 / w) <= h) {
         const int TR = 256 / w;
         const int lds = (148 * 64 + 3 * (TR + 6) * (w + 6)) * (int)sizeof(float);
-        hipLaunchKernelGGL(init_conv_x_mfma_kernel, dim3(F * (h / TR)), dim3(256), lds, (hipStream_t)stream, x, w3, fea_pre,
+        const int ntiles = F * (h / TR);
+        const int slots = 3 * 256;                       // 46 KB of LDS: three workgroups per CU
+        hipLaunchKernelGGL(init_conv_x_mfma_kernel, dim3(ntiles < slots ? ntiles : slots), dim3(256), lds, (hipStream_t)stream, x, w3, fea_pre,
                            F, h, w, out, plane_stride);
         DAWN_LAUNCH_CHECK();
         return 0;
