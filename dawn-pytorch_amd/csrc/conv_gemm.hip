@@ -51,7 +51,9 @@ namespace {
 // frames/s in the benchmark, alternating on one box (profiles/r5_ab_wino_reverse_order.txt).
 // The policy travels in dawn_conv_desc.policy (0 = the shipped default): there is no process-global tuning state.  The
 // perf-ablation kernels (0x10 / 0x20: wrong results by design; (n << 16): ablated / s_memtime-instrumented builds of the
-// split 3x3 kernel) exist only in -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
+// split 3x3 kernel; 0x40000000, read from dawn_conv_desc.policy directly: the row-stationary GEMM kernels fetch their rows in a
+// line-coalesced pattern -- the right bytes in the wrong lanes, profiles/r5_row_fetch_pattern_ablation.txt) exist only in
+// -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
 constexpr int DAWN_CONV_POLICY_DEFAULT = 0x2B00580D;
 #ifdef DAWN_ABLATION
 constexpr int DAWN_CONV_POLICY_MASK = 0x3F0FFFFF;
