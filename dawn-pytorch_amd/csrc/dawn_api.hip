@@ -15,4 +15,4 @@ extern "C" int dawn_set_error_msg(int code, const char* msg) {
     return code;
 }
 extern "C" const char* dawn_last_error(void) { return g_err; }
-extern "C" int dawn_abi_version(void) { return 7; }
+extern "C" int dawn_abi_version(void) { return 8; }

@@ -211,10 +211,21 @@ int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, in
  * (pack.pack_bf3_temporal_out).  All families compute the same function to fp32 round-off.
  * `out` MAY BE `x` when the layer covers its whole frame buffer (q0 == 0, Fq == Fext): a workgroup reads the rows of its pixel
  * before it writes them and no other workgroup touches them (the denoiser's unsharded 64-channel layers run that way:
- * one tensor less through the caches). */
+ * one tensor less through the caches).
+ * Round 6 (ABI 8): WMODE 4 = the WINDOW-tiled kernel (csrc/temporal_layer16.hip): 16-query tiles against the 16 + 2 win <= 96 keys
+ * of their window (only the key blocks that exist at the clip ends) on v_mfma_f32_16x16x32_bf16, 12 waves, the head's work split
+ * into two SIMD-balanced phases by dawn_tl16_schedule.  Automatic (flags & 7 == 0) whenever both split weight images are given,
+ * win <= 40 and Fext <= 208; flags & 7 == 5 forces it (error if the shape is outside), flags & 256 keeps the 32 x 32 kernel. */
 int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
                                const void* wqkv_bf3, const float* wout, const void* wout_bf3p, const float* rot_cos,
                                const float* rot_sin, const float* band, float eps, float* out, int flags, void* stream);
+
+/* The work split of the window-tiled layer (host code, no GPU): per wave of the 12-wave workgroup one word --
+ * bits 0..4 / 5..9 its query tiles (31 = none), 10..12 its K / V projection group (0 K features 0..15, 1 K 16..31, 2 / 3 V; 7 = none),
+ * 13..17 / 18..22 the group's 16-row tiles [t0, t1).  Waves w, w + 4, w + 8 share a SIMD; simd_units (optional, 8 ints) receives the
+ * MFMA count per SIMD and head of phase A (projections) and phase B (attention).  Returns 0 when the shape is outside the kernel. */
+typedef struct dawn_tl16_sched { unsigned w[12]; } dawn_tl16_sched;
+int dawn_tl16_schedule(int Fext, int q0, int Fq, int win, dawn_tl16_sched* sched, int* simd_units);
 
 /* ---- A8 SpatialLinearAttention core (MT:611-627) ---------------------------------------------- */
 int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);     /* ctx (F,8,32,32) */

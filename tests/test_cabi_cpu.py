@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     declared = set(names) - {"dawn_last_error", "dawn_abi_version"} - CTX
     assert CTX <= set(names)
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
-    assert L.dawn_abi_version() == 7
+    assert L.dawn_abi_version() == 8
     # no process-global tuning hooks / ablation entry points in the shipped library (policy travels in dawn_conv_desc)
     for gone in ("dawn_conv_set_variant", "dawn_conv_set_debug"):
         assert not hasattr(L, gone), gone

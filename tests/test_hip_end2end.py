@@ -37,7 +37,7 @@ def tiny_unet(sd):
 
 def test_loaded_native_library():
     from dawn_pytorch_amd import _lib
-    assert _lib.lib().dawn_abi_version() == 7
+    assert _lib.lib().dawn_abi_version() == 8
 
 
 def test_tiny_unet_golden(tiny):

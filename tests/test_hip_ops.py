@@ -877,7 +877,9 @@ def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
     # every kernel family explicitly (flags: m + 1 forces WMODE m; 16 = WMODE 3 without the interleave hints)
     try:
         for flags, name in ((1, "wmode0"), (2, "wmode1"), (3, "wmode2"), (4, "wmode3"), (4 | 16, "wmode3_hints"),
-                            (4 | 32, "wmode3_out_fp32")):
+                            (4 | 32, "wmode3_out_fp32"), (5, "wmode4_window_tiled"), (256, "auto_without_wmode4")):
+            if flags == 5 and (win > 40 or Fext > 208):
+                continue                                         # outside the window-tiled kernel's instantiation
             if flags & 7 == 4 and (Fext * 576 + ((Fext + 31) // 32) * 6144 + 8 * (32 * ((32 + 2 * win + 31) // 32) + 32) * 4 > 163840
                                    or Fq + (q0 - win) % 16 > 256):
                 continue                                         # WMODE 3 does not fit this shape (LDS)
@@ -907,7 +909,7 @@ def test_temporal_attention_trained_weight_like_range(hip, ref):
     want = ref.temporal_layer_c64(x, Fext, HW, q0, Fq, win, wqkv, wout, rc, rs, band)
     wsplit, wosp = pack_bf3(unpack_kn(wqkv)).cuda(), pack_bf3_temporal_out(unpack_kn(wout)).cuda()
     try:
-        for flags, name in ((0, "default"), (1, "wmode0"), (3, "wmode2"), (4, "wmode3")):
+        for flags, name in ((0, "default"), (1, "wmode0"), (3, "wmode2"), (4, "wmode3"), (5, "wmode4_window_tiled")):
             hip.temporal_flags = flags
             got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band), wqkv_bf3=wsplit,
                                          wout_bf3p=wosp)
@@ -919,6 +921,32 @@ def test_temporal_attention_trained_weight_like_range(hip, ref):
     want = ref.temporal_attn(qkv, Fext, HW, q0, Fq, win, rc, rs, band)
     check("temporal_attn/wide_range", hip.temporal_attn(qkv.cuda(), Fext, HW, q0, Fq, win, rc.cuda(), rs.cuda(), band.cuda()),
           want, 1e-4)
+
+
+@pytest.mark.parametrize("F", [200, 184, 120])
+def test_temporal_layer16_is_run_to_run_deterministic(hip, F):
+    """The window-tiled layer (WMODE 4) on many workgroups, eight times on the same input: bit-identical, and equal to the 32 x 32
+    kernel to round-off.  Guards the rule its regions implement (csrc/temporal_layer16.hip "REGIONS"): a load issued right behind an
+    MFMA whose operand registers it overwrites corrupted one (pixel, head, tile) in ~300, a different one every run -- at 256 pixels
+    x 8 heads x 13 tiles per run that is ~99.9 % per run to show up here."""
+    from dawn_pytorch_amd.pack import pack_bf3, pack_bf3_temporal_out, unpack_kn
+    HW, win = 256, 40
+    x = (rnd(F * HW, 64, seed=1) * 1.3 + 0.2).cuda()
+    wqkv, wout = packw(64, 768, seed=2), packw(256, 64, seed=3)
+    ang = torch.arange(F).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
+    rc, rs, band = ang.cos().contiguous().cuda(), ang.sin().contiguous().cuda(), rnd(2 * win + 1, 8, seed=5).cuda()
+    kw = dict(wqkv_bf3=pack_bf3(unpack_kn(wqkv)).cuda(), wout_bf3p=pack_bf3_temporal_out(unpack_kn(wout)).cuda())
+    try:
+        hip.temporal_flags = 4
+        want = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
+        hip.temporal_flags = 5
+        first = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
+        check(f"temporal_layer16_vs_wmode3/F{F}", first, want.cpu(), 3e-5)
+        for rep in range(7):
+            again = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
+            assert torch.equal(again, first), f"run {rep + 1} differs from run 0 in {int((again != first).sum())} elements"
+    finally:
+        hip.temporal_flags = 0
 
 
 @pytest.mark.parametrize("Fext,HW,q0,Fq", [(400, 8, 0, 400), (280, 8, 40, 200), (330, 4, 17, 301), (240, 8, 0, 200)])
@@ -976,11 +1004,15 @@ def test_c64_attention_layers_in_place(hip, F, HW):
     ang = torch.arange(F).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
     rc, rs, band = ang.cos().contiguous().cuda(), ang.sin().contiguous().cuda(), rnd(2 * win + 1, 8, seed=5).cuda()
     wsplit, wosp = pack_bf3(unpack_kn(wqkv)).cuda(), pack_bf3_temporal_out(unpack_kn(wout)).cuda()
-    for kw in ({}, {"wqkv_bf3": wsplit, "wout_bf3p": wosp}):
-        want = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
-        xin = x.clone()
-        got = hip.temporal_layer_c64(xin, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, out=xin, **kw)
-        assert got is xin and torch.equal(got, want)
+    try:
+        for kw, flags in (({}, 0), ({"wqkv_bf3": wsplit, "wout_bf3p": wosp}, 0), ({"wqkv_bf3": wsplit, "wout_bf3p": wosp}, 4)):
+            hip.temporal_flags = flags                                # 0 with both images: the window-tiled kernel; 4: the 32 x 32 one
+            want = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
+            xin = x.clone()
+            got = hip.temporal_layer_c64(xin, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, out=xin, **kw)
+            assert got is xin and torch.equal(got, want)
+    finally:
+        hip.temporal_flags = 0
     for kw in ({}, {"wqkv_bf3": wsplit}):
         want = hip.sla_layer_c64(x, F, HW, *gpu(wqkv, wout, bias), **kw)
         xin = x.clone()
