@@ -29,8 +29,9 @@
 //     (chunk g >> 1, k-half g & 1) of pack.pack_bf3_temporal_out's image -- the images of the 32 x 32 kernel are reused as they are.
 // LDS (FA = 208 row slots: a multiple of 16, so that the four k-groups of a fragment read fall on disjoint banks):
 //   X planes [3][8 channel octets][FA] x 16 B = 79,872; K planes [3][4 k-groups][FA] x 16 B = 39,936;
-//   V^T [3][13 blocks][2 m-blocks][64 lanes] x 8 B = 39,936; the head's bias table in 4 shifted copies (16-byte aligned reads for
-//   every query column) 2,048: 161,792 B.
+//   V^T [3][2 m-blocks][64 lanes][13 blocks] x 8 B = 39,936 (a lane's blocks are contiguous: ONE ds_read2_b64 fetches the A fragment
+//   [block b | block b + 1] for either parity of b); the head's bias table in 4 shifted copies (16-byte aligned reads for every query
+//   column) 2,112: 161,856 B.
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
 #include "temporal_layer16.h"
@@ -58,7 +59,9 @@ constexpr float LOG2E = 1.4426950408889634f;
 constexpr int XP_BYTES = 3 * 8 * FA * 16;
 constexpr int KP_BYTES = 3 * 4 * FA * 16;
 constexpr int VP_BYTES = 3 * NB * 2 * 512;
-constexpr int BAND_BYTES = 4 * 128 * 4;
+constexpr int BLD = 132;                     // floats between the shifted bias-table copies: +4 banks per copy (the four lanes of a
+                                            // query quad read four copies: 4-way conflicts at a stride of 128)
+constexpr int BAND_BYTES = 4 * BLD * 4;
 constexpr int LDS_BYTES = XP_BYTES + KP_BYTES + VP_BYTES + BAND_BYTES;
 static_assert(LDS_BYTES == TL16_LDS_BYTES, "LDS layout");
 
@@ -111,14 +114,20 @@ __device__ __forceinline__ bf16x8t join8(const uint2 lo, const uint2 hi) {
     return __builtin_bit_cast(bf16x8t, u32x4{lo.x, lo.y, hi.x, hi.y});
 }
 
+// v_max3_f32 on values that are never NaN (fmaxf would first quiet each operand with a v_max x, x: two extra instructions per call)
+__device__ __forceinline__ float max3_nc(float a, float b, float c) {
+    float r;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
 // max / sum over the four lanes {n, n + 16, n + 32, n + 48} that share a query column, result in all four: two gfx950 row swaps
 // (v_permlane16_swap / v_permlane32_swap: vector instructions) instead of two ds_bpermute round trips; the pairing of the xor butterfly
 __device__ __forceinline__ float rows4_max(float v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
     u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    v = max3_nc(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[1]));
     r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-    return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    return max3_nc(__uint_as_float(r[0]), __uint_as_float(r[1]), __uint_as_float(r[1]));
 }
 __device__ __forceinline__ float rows4_sum(float v) {
     typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -140,8 +149,8 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
     extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
     unsigned char* Xp = smem16;                               // [3][8][FA] x 16 B
     unsigned char* Kp = Xp + XP_BYTES;                        // [3][4][FA] x 16 B
-    unsigned char* Vp = Kp + KP_BYTES;                        // [3][NB][2][64] x 8 B
-    float* band4 = reinterpret_cast<float*>(Vp + VP_BYTES);   // [4 shifts][128]
+    unsigned char* Vp = Kp + KP_BYTES;                        // [3][2][64][NB] x 8 B
+    float* band4 = reinterpret_cast<float*>(Vp + VP_BYTES);   // [4 shifts][BLD]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
             for (int t = 0; t < NR; ++t) {
                 uint2 p1, p2, p3;
                 split3_quad(d2[t][0] + d2[t][1], p1, p2, p3);
-                unsigned char* dst = Vp + ((size_t)((rt + t) * 2 + kmb) * 64 + lane) * 8;
+                unsigned char* dst = Vp + ((size_t)(kmb * 64 + lane) * NB + rt + t) * 8;
                 *reinterpret_cast<uint2*>(dst) = p1;
                 *reinterpret_cast<uint2*>(dst + (size_t)NB * 2 * 512) = p2;
                 *reinterpret_cast<uint2*>(dst + (size_t)2 * NB * 2 * 512) = p3;
@@ -360,7 +369,7 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
         // ---- phase A.  LOAD region: the head's bias table (log2 units; NEG outside the window: the lookup is the window mask; a lane
         // reads float4 at copy[(15 - n) & 3][((15 - n) & ~3) + 4 g + 16 b] = entries 15 - n + 4 g + 16 b + r), the X fragments of the
         // own query rows and of the group's first row tile
-        band4[tid] = bok ? bandv * LOG2E : NEG;
+        band4[(tid >> 7) * BLD + (tid & 127)] = bok ? bandv * LOG2E : NEG;
         bf16x8t xfq[NTILE][2][3];
 #pragma unroll
         for (int k = 0; k < NTILE; ++k) {
@@ -405,6 +414,9 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
                     qr[4 * mb + 3] = d[k][mb][3] * cs.y + d[k][mb][2] * sn.y;
                 }
                 dawn_split3_oct(qr, qp[k][0], qp[k][1], qp[k][2]);
+                // (pinned: without it the compiler sinks rotary + split below barrier A, where Q is first used -- and the Q MFMAs'
+                //  results would be read only after the K / V group's loads had been issued)
+                asm volatile("" :: "v"(qp[k][0]), "v"(qp[k][1]), "v"(qp[k][2]));
             }
         }
         if (h < 2) TSTAMP();   // Q done
@@ -458,9 +470,9 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
                 const int blo = max(0, -B0), bhi = min(nkb, nblk - B0);             // the blocks that exist
                 const int Bf = B0 + blo;                                            // first existing block
                 const int sh = (15 - n) & 3;
-                const float* bb = band4 + sh * 128 + ((15 - n) - sh) + 4 * g + 16 * blo;
+                const float* bb = band4 + sh * BLD + ((15 - n) - sh) + 4 * g + 16 * blo;
                 const unsigned char* kbase = Kp + ((size_t)g * FA + 16 * Bf + n) * 16;
-                const unsigned char* vbase = Vp + ((size_t)(Bf * 2) * 64 + lane) * 8;
+                const unsigned char* vbase = Vp + ((size_t)lane * NB + Bf) * 8;
                 const int klast = Fext - 16 * (Bf + (bhi - blo) - 1) - 4 * g;       // slots of the last block that are frames: r < klast
                 f32x4 o[2][2] = {{zero4(), zero4()}, {zero4(), zero4()}};
                 float l = 0.f;
@@ -487,8 +499,13 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
 #pragma unroll
                     for (int r = 0; r < 4; ++r) st[NV - 1][r] = r < klast ? st[NV - 1][r] : NEG;
                     float m = NEG;
+                    // (first level = v_med3(a, b, +inf) through the builtin: the compiler must SEE the reads of the MFMA results to pad
+                    //  them; behind it the inline-asm max3 works on vector results)
 #pragma unroll
-                    for (int j = 0; j < NV; ++j) m = fmaxf(m, fmaxf(fmaxf(st[j][0], st[j][1]), fmaxf(st[j][2], st[j][3])));
+                    for (int j = 0; j < NV; ++j)
+                        m = max3_nc(m, __builtin_amdgcn_fmed3f(st[j][0], st[j][1], __builtin_inff()),
+                                    __builtin_amdgcn_fmed3f(st[j][2], st[j][3], __builtin_inff()));
+                    asm volatile("" :: "v"(m));      // the region's closing read stays here (machine sinking moves unpinned vector work down)
                     REGION();
                     // LOAD: V^T fragments of the block pairs (they land under the softmax) [+ the to_out fragments].  Waves with two query
                     // tiles hold two pairs at a time (24 registers less where the stage peaks): the third follows in a region of its own
@@ -500,8 +517,8 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
                         for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                             for (int pl = 0; pl < 3; ++pl) {
-                                const uint2 lo = *reinterpret_cast<const uint2*>(vbase + (size_t)((2 * kk) * 2 + mb) * 512 + (size_t)pl * NB * 2 * 512);
-                                const uint2 hi = *reinterpret_cast<const uint2*>(vbase + (size_t)(jb * 2 + mb) * 512 + (size_t)pl * NB * 2 * 512);
+                                const uint2 lo = *reinterpret_cast<const uint2*>(vbase + (size_t)(2 * kk) * 8 + (size_t)(pl * 2 + mb) * NB * 512);
+                                const uint2 hi = *reinterpret_cast<const uint2*>(vbase + (size_t)jb * 8 + (size_t)(pl * 2 + mb) * NB * 512);
                                 v[mb][pl] = join8(lo, hi);
                             }
                     };
