@@ -1096,8 +1096,11 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 //   X1 = [x1 | x2], X2 = [x3 | x1] (pixels)   W1 = [w1 | w2], W2 = [w3 | w1] (weights)
 // the three products X2.W1 = x3 w1 + x1 w2, X1.W2 = x1 w3 + x2 w1, X1.W1 = x1 w1 + x2 w2 are exactly the 6 cross terms: 3 half-size
 // MFMAs per 16 x 16 block instead of 6 full-size ones per 32 x 32, 16 fragment reads per tap instead of 12, same LDS layout.
-template <int WN, int NT, int ABL, bool K32 = false>
-__global__ __launch_bounds__(256 * WN, K32 ? 2 / WN : 1) void conv3x3_bf16_v2_kernel(const dawn_conv_desc d, const int xcd_remap,
+// PSEG (round 6) = 16-pixel segments of the halo patch the instantiation holds: 28 (P16 <= 448) everywhere but at 4 x 4-pixel frames
+// (BASELINE configs[1]'s deepest level: 16 frames x 6 x 6 = 576 patch pixels per 256-pixel tile), which ran on the round-1 kernel with
+// 128-row tiles -- 200 four-wave workgroups two per CU, i.e. 100 of 256 CUs busy, 58..123 TF/s (profiles/r6_config1_insitu_shapes.txt)
+template <int WN, int NT, int ABL, bool K32 = false, int PSEG = 28>
+__global__ __launch_bounds__(256 * WN, (K32 && PSEG == 28) ? 2 / WN : 1) void conv3x3_bf16_v2_kernel(const dawn_conv_desc d, const int xcd_remap,
                                                                     const int TR, const int nf, const int P16,
                                                                     const int WT, const int stagger) {
 #if __HIP_DEVICE_COMPILE__   // (the host pass only needs the launch stub; buffer-resource builtins are device-only)
@@ -1109,7 +1112,7 @@ __global__ __launch_bounds__(256 * WN, K32 ? 2 / WN : 1) void conv3x3_bf16_v2_ke
         for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
     constexpr int NTHR = 256 * WN, BM = 256, BN = 64 * WN;
     constexpr int TM = 2, TN = 2;
-    constexpr int MAXQ = (28 * 16 * 4 + NTHR - 1) / NTHR;      // patch quads per thread (P16 <= 448)
+    constexpr int MAXQ = (PSEG * 16 * 4 + NTHR - 1) / NTHR;    // patch quads per thread (P16 <= 16 PSEG)
     constexpr int L0 = (MAXQ + 1) / 2;                         // quads loaded in stage 0 (the rest in stage 1)
     constexpr int SB = 18 * BN * 16;                           // bytes of one weight stage (3 taps x 3 planes x 2 halves)
     constexpr int NBI = SB / 1024;                             // DMA wave-instructions per stage
@@ -1405,10 +1408,19 @@ __global__ __launch_bounds__(256 * WN, K32 ? 2 / WN : 1) void conv3x3_bf16_v2_ke
             TSTAMP();   // stage: MFMAs issued
             if (ky < 2) {
                 // (the register operands pin the split of these quads behind the wait)
-                if (MAXQ == 7)
+                if (MAXQ == 9)
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                                 : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]), "+v"(araw[4]), "+v"(araw[5]),
+                                   "+v"(araw[6]), "+v"(araw[MAXQ > 7 ? 7 : 0]), "+v"(araw[MAXQ > 8 ? 8 : 0])
+                                 :: "memory");
+                else if (MAXQ == 7)
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
                                  : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]), "+v"(araw[4]), "+v"(araw[5]),
                                    "+v"(araw[6])
+                                 :: "memory");
+                else if (MAXQ == 5)
+                    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
+                                 : "+v"(araw[0]), "+v"(araw[1]), "+v"(araw[2]), "+v"(araw[3]), "+v"(araw[MAXQ - 1])
                                  :: "memory");
                 else
                     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)"
@@ -1606,9 +1618,11 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     else { if (WT != W || TR % H != 0) return false; nf = TR / H; TR = H; if (d.F % nf != 0) return false; }
     const int P = nf * (TR + 2) * (WT + 2);
     const int P16 = (P + 15) / 16 * 16;
-    if (P16 > 448) return false;
     const bool timing = ((policy_of(d) >> 16) & 15) == 8;
     const bool k32 = !nine && (policy_of(d) & 0x1000000);
+    // (the 36-segment instantiation exists for the shipped form only: 16 x 16 x 32, six cross terms)
+    const bool big_patch = P16 > 448;
+    if (P16 > 576 || (big_patch && !k32)) return false;
     const size_t lds = (size_t)6 * (P16 * 16 + 128) + (size_t)2 * 18 * BN * 16 + (timing || k32 ? 512 : 0);   // (+ the GroupNorm exchange)
     if (lds > 160 * 1024) return false;
     const int nwg = (int)(M / BM) * (d.N / BN);
@@ -1631,6 +1645,10 @@ bool try_launch_bf16_v2(const dawn_conv_desc& d, long M, hipStream_t s, bool nin
     // the chip busy (power-limited), +4..6 % on the four under-filled launches of the deepest level (100 workgroups;
     // profiles/r3_k32_shapes.txt).  Chosen by the policy alone, never by the grid size: a frame computes the same bits whatever
     // the batch it is launched in
+    else if (big_patch) {
+        (void)hipFuncSetAttribute((const void*)conv3x3_bf16_v2_kernel<WN, 6, 0, true, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipLaunchKernelGGL((conv3x3_bf16_v2_kernel<WN, 6, 0, true, 36>), dim3(nwg), dim3(256 * WN), lds, s, d, remap, TR, nf, P16, WT, stagger);
+    }
     else if (policy_of(d) & 0x1000000) LAUNCH_V2K(6, 0, true);
 #ifdef DAWN_ABLATION
     else if (timing) LAUNCH_V2(6, 8);
@@ -2360,14 +2378,19 @@ static int dawn_ncu() {
     return ncu;
 }
 
+// smallest M the split-operand 1x1 kernels take.  12,800 (the deepest level of the 256 x 256 / 200-frame clip) until round 6: at BASELINE
+// configs[1] the deepest level has 6,400 rows and every projection there ran on the fp32-MFMA kernel at 42..62 TF/s
+// (profiles/r6_config1_insitu_shapes.txt)
+constexpr long GEMM1X1_SPLIT_MIN_M = 6400;
+
 static bool gemm1x1_rowreg_ok(long M, int N, int C0, int C1) {
     const int K = C0 + C1;
-    return (K == 64 || K == 128) && C0 % 16 == 0 && C1 % 16 == 0 && N % 64 == 0 && M % 256 == 0 && M >= 12800;
+    return (K == 64 || K == 128) && C0 % 16 == 0 && C1 % 16 == 0 && N % 64 == 0 && M % 256 == 0 && M >= GEMM1X1_SPLIT_MIN_M;
 }
 
 static bool gemm1x1_rowacc_ok(long M, int N, int C0, int C1) {
     const int K = C0 + C1;
-    return K >= 256 && K % 128 == 0 && C0 % 16 == 0 && C1 % 16 == 0 && N % 64 == 0 && N <= 192 && M % 256 == 0 && M >= 12800;
+    return K >= 256 && K % 128 == 0 && C0 % 16 == 0 && C1 % 16 == 0 && N % 64 == 0 && N <= 192 && M % 256 == 0 && M >= GEMM1X1_SPLIT_MIN_M;
 }
 
 template <int MODE>
@@ -2463,7 +2486,7 @@ void launch_gemm1x1_bf16_small(const dawn_conv_desc& d, long M, hipStream_t s) {
 // half of the CUs idle with 128-wide tiles; the thin N = 64 GEMMs and the short (M < 51200) 128..255-tile cases stay on
 // the fp32 kernel (many small workgroups hide HBM latency better than one 126 KB-LDS workgroup per CU).
 int gemm1x1_split_plan(long M, int N, int C0, int C1) {
-    if (C0 % 32 != 0 || C1 % 32 != 0 || N % 64 != 0 || M % 256 != 0 || M < 12800) return 0;
+    if (C0 % 32 != 0 || C1 % 32 != 0 || N % 64 != 0 || M % 256 != 0 || M < GEMM1X1_SPLIT_MIN_M) return 0;
     int plan;
     if (N % 128 == 0) {
         const long t2 = (M / 256) * (N / 128);

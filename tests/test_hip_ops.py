@@ -81,6 +81,10 @@ CONV_CASES = [
     ("c3x3_halo_cat_W32_N128", 2, 32, 32, 64, 64, 128, 3, 1, 1, {"bias": True}),
     ("c3x3_halo_multiframe_tile", 8, 4, 4, 64, 0, 128, 3, 1, 1, {}),
     ("c3x3_halo_N192_ragged_ntile", 4, 8, 8, 32, 0, 192, 3, 1, 1, {"bias": True}),
+    # 4 x 4-pixel frames (BASELINE configs[1]'s deepest level): 16 frames per 256-row tile = a 576-pixel halo patch, the 36-segment
+    # instantiations of the v2 kernel (round 6): four-wave / 64-column tiles, and eight-wave / 128-column tiles (more than 128 tiles)
+    ("c3x3_4x4_frames_cat_N128", 32, 4, 4, 64, 64, 128, 3, 1, 1, {"bias": True}),
+    ("c3x3_4x4_frames_manytiles_N128", 2064, 4, 4, 16, 0, 128, 3, 1, 1, {"bias": True}),
 ]
 
 
@@ -423,7 +427,7 @@ def test_conv_wino4_is_fp32_accurate(hip, ref):
 
 
 @pytest.mark.parametrize("F,H,W,C0,N", [(3, 16, 16, 64, 64), (2, 8, 8, 128, 256), (5, 8, 8, 16, 16), (1, 40, 37, 32, 128),
-                                       (12, 8, 8, 16, 32), (12, 4, 4, 64, 32), (12, 8, 8, 48, 16)])
+                                       (12, 8, 8, 16, 32), (12, 4, 4, 64, 32), (12, 8, 8, 48, 16), (48, 4, 4, 32, 64)])
 def test_conv_gemm_fused_gn_stats(hip, ref, F, H, W, C0, N):
     """GroupNorm partial sums emitted by the conv epilogue == statistics pass over the conv output."""
     rows = F * H * W
