@@ -410,6 +410,8 @@ def main():
     ap.add_argument("--event-every", type=int, default=5,
                     help="record the per-launch HIP events of the roofline measurement on every n-th DDIM step of the timed "
                          "region (every step costs ~2.5 %% of the run: two marker packets per conv launch)")
+    ap.add_argument("--one-process-group", action="store_true",
+                    help="T-shard: halo P2P and all-reduces on ONE process group (default: two groups = two RCCL communicators)")
     ap.add_argument("--no-overlap", action="store_true", help="disable the two-stream overlap inside ResBlocks")
     ap.add_argument("--no-fuse-h1", action="store_true",
                     help="A/B only: separate h_cond tensor + GroupNorm-apply pass instead of the cross-attention kernels' fused h1 epilogue")
@@ -474,7 +476,12 @@ def main():
             from dawn_pytorch_amd.tshard import TShardComm
             # halo P2P on one process group, the tiny all-reduces on another: two RCCL communicators = two streams, so a 128-byte
             # GroupNorm all-reduce does not queue behind a 186 MB halo transfer in flight (tshard.TShardComm)
-            groups = TShardComm.two_groups(dist)
+            # (--one-process-group / DAWN_TSHARD_ONE_GROUP=1: everything on the default group -- the fallback should two concurrent
+            #  communicators on one device ever misbehave on a node; `process_groups` in the JSON line says which one ran)
+            if args.one_process_group or os.environ.get("DAWN_TSHARD_ONE_GROUP", "0") == "1":
+                groups = (None, None)
+            else:
+                groups = TShardComm.two_groups(dist)
         if mode == "tshard":
             try:
                 mode = resolve_mode(mode, tshard_preflight(dist, rank, world, device, groups), args.allow_fallback)
@@ -581,9 +588,10 @@ def main():
     # (`roofline`); the others are listed beside it (`roofline_other`).
     if prof:
         torch.cuda.synchronize()
-        tp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"))
+        tp = next((q for q in (os.path.join(ROOT, "profiles", n) for n in ("r6_pmc_traffic.json", "r5_pmc_traffic.json", "r4_pmc_traffic.json", "r3_pmc_traffic.json", "r2_pmc_traffic.json", "r1_pmc_traffic.json"))
                    if os.path.exists(q)), None)
         pmc = json.load(open(tp)) if (tp and (T, args.res) == (200, 256)) else None
+        traffic_refused = None
         sampled = diff.use_graph and getattr(ops, "graph_error", None) is None
         timing = (f"HIP events around every conv_gemm launch of every {args.eager_every}th DDIM step "
                   "(those steps run eagerly inside the timed region; the others replay a HIP graph)"
@@ -674,12 +682,28 @@ def main():
         groups = {}
         for pr in prof:
             groups.setdefault(kind_of(pr[3]), []).append(pr)
+        # the PMC traffic file is quoted only if it describes THIS build's launches: the same kernel classes, each with the same share
+        # of the conv_gemm launches (a profile taken before a kernel was replaced or re-gated would be silently wrong otherwise)
+        if pmc is not None:
+            want = pmc.get("launch_share_by_kind")
+            have = {k: len(v) / len(prof) for k, v in groups.items()}
+            if want is None:
+                traffic_refused = f"{os.path.relpath(tp, ROOT)} carries no launch_share_by_kind (made before round 6): not checkable against this run"
+            elif set(want) != set(have) or any(abs(want[k] - have[k]) > 0.005 for k in have):
+                traffic_refused = (f"{os.path.relpath(tp, ROOT)} describes other launches than this run's: shares by kernel class profile "
+                                   f"{ {k: round(v, 3) for k, v in sorted(want.items())} } vs run { {k: round(v, 3) for k, v in sorted(have.items())} }")
+            if traffic_refused:
+                pmc = None
         roofs = {k: roof(v, k) for k, v in groups.items() if v}
         t_all = sum(t for _, t in roofs.values())
         for r, t in roofs.values():
             r["share_of_conv_time"] = t / t_all
         order = sorted(roofs, key=lambda k: -roofs[k][1])
         result["roofline"] = roofs[order[0]][0]                     # the dominant kernel
+        result["roofline"]["traffic_profile"] = os.path.relpath(tp, ROOT) if tp else None
+        result["roofline"]["traffic_profile_head"] = pmc.get("head") if pmc is not None else None
+        if traffic_refused:
+            result["roofline"]["traffic_refused"] = traffic_refused
         if len(order) > 1:
             result["roofline_other"] = [roofs[k][0] for k in order[1:]]
         # the split kernels are POWER-limited (same instruction stream, zero-filled tensors: 28-38 % faster; profiles/

@@ -153,8 +153,8 @@ __global__ __launch_bounds__(256) void xattn_ln_sum_kernel(const float* __restri
 template <int L, int MAXQ>
 __global__ __launch_bounds__(256) void xattn_sigma_out_kernel(const float* __restrict__ q, long rows, int HW,
                                                               const float* __restrict__ xtab, const float* __restrict__ g3,
-                                                              int Co, float eps, float* __restrict__ out,
-                                                              const float* __restrict__ gn_x, const float* __restrict__ gn_a,
+                                                              int Co, float eps, float* out,
+                                                              const float* gn_x /* may alias `out` (h1 over c1) */, const float* __restrict__ gn_a,
                                                               const float* __restrict__ gn_b) {
     constexpr int RPB = 256 / L, R = 4;
     const int sub = threadIdx.x % L;

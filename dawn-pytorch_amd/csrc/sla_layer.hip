@@ -207,10 +207,10 @@ __device__ __forceinline__ void stage_store(const f32x4 v, int n0, int HW, float
 }
 
 // one block per (frame, split): LDS = Wq for all heads [16][256][4] (64 KB) + the frame's M [8][8][64][4] (64 KB)
-__global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* __restrict__ x, int HW,
+__global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* x /* may alias `out` */, int HW,
                                                             const float* __restrict__ wqkv,
                                                             const float* __restrict__ Mg, const float* __restrict__ bias,
-                                                            float eps, float* __restrict__ out, int nsplit) {
+                                                            float eps, float* out, int nsplit) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float* Wq = smem;                   // [16][256][4]
     float* Ms = smem + 16 * 256 * 4;    // [64][64][4]  (h*8 + d/4, n)
@@ -321,10 +321,10 @@ __global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* __restr
 // same number of tiles (the (frame, half) grid of the fp32 kernel was 400 one-per-CU blocks on 256 CUs = 1.56 rounds).
 typedef dawn_bf16x8 bf16x8a;
 
-__global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* __restrict__ x, int HW, int F,
+__global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* x /* may alias `out` */, int HW, int F,
                                                                  const unsigned short* __restrict__ wqkv_s,
                                                                  const float* __restrict__ Mg, const float* __restrict__ bias,
-                                                                 float eps, float* __restrict__ out, int tiles_per_block) {
+                                                                 float eps, float* out, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
     unsigned char* Wq = smem_b;                                     // [kc 4][plane 3][k-half 2][256 features] x 16 B
     float* Ms = reinterpret_cast<float*>(smem_b + 24 * 256 * 16);   // [64][64][4]  (h*8 + d/4, n)

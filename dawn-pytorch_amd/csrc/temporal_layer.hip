@@ -122,9 +122,9 @@ __device__ __forceinline__ void proj_T_split(const __amdgpu_buffer_rsrc_t rw, un
 // ahead through registers, so no MFMA waits on an L2 round trip (used when the LDS budget allows: F <= 224).
 template <int NKT, int WMODE>
 __global__ __launch_bounds__(512) void temporal_layer_c64_kernel(
-    const float* __restrict__ x, int Fext, int HW, int q0, int Fq, int win, const float* __restrict__ wqkv,
+    const float* x /* may alias `out` (in-place layer): no __restrict__ on the pair */, int Fext, int HW, int q0, int Fq, int win, const float* __restrict__ wqkv,
     const unsigned short* __restrict__ wqkv_s, const float* __restrict__ wout, const float* __restrict__ rcos, const float* __restrict__ rsin,
-    const float* __restrict__ band, float eps, float* __restrict__ out, int nrt) {
+    const float* __restrict__ band, float eps, float* out, int nrt) {
 #if __HIP_DEVICE_COMPILE__   // (buffer-resource builtins are device-only; the host pass only needs the launch stub)
     extern __shared__ __attribute__((aligned(16))) float smem[];
     constexpr bool WLDS = WMODE == 1;
@@ -617,9 +617,9 @@ __device__ __forceinline__ f32x16 proj_Q_split(const __amdgpu_buffer_rsrc_t rw, 
 // (tile, head) against 2 x 1536 here).  No X planes: K planes + V^T + bias table = 86 KB at Fext = 200.
 template <int NKT, int SCHED, bool HL, bool OB, int FAC, bool KVI, bool EXT = false>
 __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
-    const float* __restrict__ x, int Fext, int HW, int q0, int Fq, int win, const unsigned short* __restrict__ wqkv_s,
+    const float* x /* may alias `out` */, int Fext, int HW, int q0, int Fq, int win, const unsigned short* __restrict__ wqkv_s,
     const float* __restrict__ wout, const unsigned short* __restrict__ wout_sp, const float* __restrict__ rcos,
-    const float* __restrict__ rsin, const float* __restrict__ band, float eps, float* __restrict__ out, int nrt, int delta) {
+    const float* __restrict__ rsin, const float* __restrict__ band, float eps, float* out, int nrt, int delta) {
 #if __HIP_DEVICE_COMPILE__
     extern __shared__ __attribute__((aligned(16))) float smem[];
     // row capacity (= stride) of the X / K planes; reads clamp to Fext - 1.  FAC != 0: compile-time capacity, so that every

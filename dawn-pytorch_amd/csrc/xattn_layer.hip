@@ -50,7 +50,7 @@ __global__ __launch_bounds__(512, (CIN == 64 && !SPLIT) ? 4 : 2) void xattn_c64_
                                                         const float* __restrict__ wq, const unsigned short* __restrict__ wq_s,
                                                         const float* __restrict__ g3,
                                                         const float* __restrict__ xtab, float eps,
-                                                        float* __restrict__ out, long ntiles, const float* __restrict__ gn_x,
+                                                        float* out, long ntiles, const float* gn_x /* may alias `out` (h1 over c1) */,
                                                         const float* __restrict__ gn_a, const float* __restrict__ gn_b) {
     constexpr int NC = CIN / 8;
     constexpr int WQF = SPLIT ? CIN * 1152 / 4 : (CIN / 4) * 192 * 4;       // floats of LDS taken by the to_q weights

@@ -283,7 +283,9 @@ class PackedUNet:
         """bias by offset d = j - i in [-win, win] -> (2*win+1, 8) (MT:111-119 inside the window).  Cached per window: a clip
         costs no torch index / copy kernels for it (read-only table)."""
         cache = self.__dict__.setdefault("_band_cache", {})
-        key = (win, self.rel_emb.data_ptr(), self.rel_emb._version)
+        # (no `_version` in the key: packing runs under torch.inference_mode() -- GaussianDiffusion.sample -- and an inference tensor,
+        #  e.g. the converted copy of an fp16 checkpoint's table, has no version counter; a repack builds a new PackedUNet anyway)
+        key = (win, self.rel_emb.data_ptr())
         if key not in cache:
             cache.clear()
             d = torch.arange(-win, win + 1, device=self.rel_emb.device)
@@ -294,11 +296,15 @@ class PackedUNet:
         """cos/sin (n,16) of rotary-embedding-torch 0.3.x: angle = pos * freqs (interleaved pairs).  Cached per length (the tables
         depend on the clip length only): no host trigonometry and no host-to-device copies per clip."""
         cache = self.__dict__.setdefault("_rot_cache", {})
-        fr = self.rot_freqs.detach().float().cpu()
-        key = (n, str(self.rel_emb.device), tuple(fr.tolist()))
+        key = (n, str(self.rel_emb.device), self.rot_freqs.data_ptr())      # (no device-to-host copy of the frequencies per clip)
         if key not in cache:
             if len(cache) > 8:
                 cache.clear()
+            fr = self.__dict__.get("_rot_freqs_host")
+            if fr is None or fr[0] != self.rot_freqs.data_ptr():
+                fr = (self.rot_freqs.data_ptr(), self.rot_freqs.detach().float().cpu())
+                self.__dict__["_rot_freqs_host"] = fr
+            fr = fr[1]
             pos = torch.arange(n, dtype=torch.float32)
             ang = pos[:, None] * fr[None, :]
             dev = self.rel_emb.device

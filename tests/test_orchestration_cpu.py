@@ -220,3 +220,18 @@ def test_launch_preconditions_raise_not_assert():
         assert not [n.lineno for n in ast.walk(tree) if isinstance(n, ast.Assert)], name
     with pytest.raises(_lib.DawnHipError, match="precondition"):
         ops._need(False, "x.is_contiguous()")
+
+
+def test_band_and_rotary_tables_under_inference_mode_with_fp16_checkpoint(tiny):
+    """packing runs lazily inside GaussianDiffusion.sample(), i.e. under torch.inference_mode(); with a checkpoint that needs
+    a conversion (fp16 weights) the packed tables are inference tensors, which have no version counter -- band() must not ask for one.
+    rotary_tables() must not copy the frequencies device -> host on every call."""
+    g, sd = tiny
+    with torch.inference_mode():
+        P = pack_unet({k: v.half() for k, v in sd.items()}, 3, "cpu")
+        b1 = P.band(3)
+        assert b1.shape == (7, 8) and P.band(3) is b1                          # cached
+        c1, s1 = P.rotary_tables(12)
+        assert P.rotary_tables(12)[0] is c1 and c1.shape == (12, P.rot_freqs.numel())
+    P32 = pack_unet(sd, 3, "cpu")
+    assert torch.allclose(P32.band(3), b1, atol=2e-3) and torch.allclose(P32.rotary_tables(12)[0], c1, atol=2e-3)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Build profiles/*_pmc_traffic.json from the two PMC passes of tools/pmc_bench.sh:
-    python tools/pmc_traffic_json.py <fetch_results.db> <write_results.db> [out.json]
+    python tools/pmc_traffic_json.py <fetch_results.db> <write_results.db> [out.json] [commit the passes ran on]
 Sums FETCH_SIZE / WRITE_SIZE (KiB) over every dawn_conv_gemm kernel (conv_gemm_kernel, conv_gemm_glds_kernel,
 conv3x3_halo_kernel), applies the gfx950 x2 FETCH_SIZE correction (calibrated, see `calibration`), and reports
 HBM bytes per conv launch -- the `traffic` figure bench.py attaches to the roofline object."""
@@ -20,6 +20,23 @@ def sums(path, counter):
         per[kn][0] += 1
         per[kn][1] += float(r[ci["value"]])
     return per
+
+
+def kernel_kind(k):
+    """kernel name -> the kernel class bench.py's roofline uses (bench.py kind_of)"""
+    if k.startswith("conv3x3_wino4"):
+        return "conv3x3_wino4"
+    if k.startswith("conv3x3_wino"):
+        return "conv3x3_wino"
+    if k.startswith("conv3x3_bf16") or k.startswith("conv3x3_halo_bf16"):
+        return "conv3x3"
+    if k.startswith("gemm1x1_rowreg"):
+        return "gemm1x1_rowreg"
+    if k.startswith("gemm1x1_rowacc"):
+        return "gemm1x1_rowacc"
+    if k.startswith("gemm1x1_"):
+        return "gemm1x1"
+    return "fp32"
 
 
 def main():
@@ -58,6 +75,14 @@ def main():
                            "write_kib_avg": (write[k][1] / write[k][0]) if k in write else None}
                        for k in sorted(fetch) if is_conv(k)},
     }
+    # what bench.py checks before it quotes this file (a stale profile is silently wrong otherwise): the share of the conv_gemm
+    # launches each kernel class takes, and the commit the passes ran on (the GPU box has no .git: passed in by the caller)
+    kinds = collections.Counter()
+    for k, v in fetch.items():
+        if is_conv(k):
+            kinds[kernel_kind(k)] += v[0]
+    out["launch_share_by_kind"] = {k: v / n for k, v in sorted(kinds.items())}
+    out["head"] = sys.argv[4] if len(sys.argv) > 4 else None
     txt = json.dumps(out, indent=1)
     if len(sys.argv) > 3:
         open(sys.argv[3], "w").write(txt)
