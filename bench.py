@@ -689,7 +689,7 @@ def main():
             have = {k: len(v) / len(prof) for k, v in groups.items()}
             if want is None:
                 traffic_refused = f"{os.path.relpath(tp, ROOT)} carries no launch_share_by_kind (made before round 6): not checkable against this run"
-            elif set(want) != set(have) or any(abs(want[k] - have[k]) > 0.005 for k in have):
+            elif any(abs(want.get(k, 0.0) - have.get(k, 0.0)) > 0.01 for k in set(want) | set(have)):      # (1 %: the profiled command also runs the once-per-clip fea conv)
                 traffic_refused = (f"{os.path.relpath(tp, ROOT)} describes other launches than this run's: shares by kernel class profile "
                                    f"{ {k: round(v, 3) for k, v in sorted(want.items())} } vs run { {k: round(v, 3) for k, v in sorted(have.items())} }")
             if traffic_refused:

@@ -360,6 +360,12 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
     };
     request_head(0);
     REGION();
+#ifdef TL16_PRIO_YOUNG
+    if (wv >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef TL16_PRIO_OLD
+    if (wv < 4) __builtin_amdgcn_s_setprio(1);
+#endif
 
     __syncthreads();
     TSTAMP();   // phase 0 done

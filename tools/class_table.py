@@ -12,7 +12,7 @@ CLASSES = [("3x3 ResBlock convs (Winograd F(2x2), F(4x4), direct)", ("conv3x3_",
            ("GroupNorm apply / LayerNorm statistics", ("gn_", "ln_rowstats")),
            ("init conv, heads, mid spatial attention, linear", ("init_conv", "head_out", "frame_attn", "linear_kernel", "sinusoidal")),
            ("sampler (x0, quantile select, update, noise)", ("ddim_", "select_", "philox", "cfg_combine")),
-           ("torch elementwise / cat / copies inside the timed region", ("at::native", "__amd_rocclr", "Cijk_"))]
+           ("torch / rocBLAS / copy kernels of weight packing and clip preparation (whole process, outside the timed loop; per evaluation here)", ("at::native", "__amd_rocclr", "Cijk_"))]
 
 
 def load(path):
