@@ -1235,6 +1235,9 @@ __global__ __launch_bounds__(512) void temporal_layer_c64_bf16_kernel(
 bool dawn_temporal_layer16_try(const float* x, int Fext, int HW, int q0, int Fq, int win, const void* wqkv_bf3,
                                const void* wout_bf3p, const float* rot_cos, const float* rot_sin, const float* band, float eps,
                                float* out, hipStream_t s);   // temporal_layer16.hip
+bool dawn_temporal_layer13_try(const float* x, int Fext, int HW, int q0, int Fq, int win, const void* wqkv_bf3,
+                               const void* wout_bf3p, const float* rot_cos, const float* rot_sin, const float* band, float eps,
+                               float* out, hipStream_t s);   // temporal_layer16.hip
 
 extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
                                           const void* wqkv_bf3, const float* wout, const void* wout_bf3p,
@@ -1248,6 +1251,14 @@ extern "C" int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int 
     if (nkt > 4) return dawn_set_error_msg(-35, "dawn_temporal_layer_c64: win > 48 not supported (use the unfused path)");
     const int force = flags & 7;                       // 0 = automatic, m + 1 = WMODE m (A/B measurements, tests)
     // WMODE 4 (round 6): the window-tiled 16-query kernel of temporal_layer16.hip wherever its instantiation covers the shape
+    // WMODE 5 (round 6): the window-tiled kernel with ONE query tile per wave (13 waves) wherever the query range is at most 13 tiles
+    if ((force == 0 && !(flags & 256)) || force == 6) {
+        if (dawn_temporal_layer13_try(x, Fext, HW, q0, Fq, win, wqkv_bf3, wout_bf3p, rot_cos, rot_sin, band, eps, out, (hipStream_t)stream)) {
+            DAWN_LAUNCH_CHECK();
+            return 0;
+        }
+        if (force == 6) return dawn_set_error_msg(-38, "dawn_temporal_layer_c64: WMODE 5 does not cover this shape (win <= 40, Fext <= 208, <= 13 query tiles, both split weight images)");
+    }
     if ((force == 0 && !(flags & 256)) || force == 5) {
         if (dawn_temporal_layer16_try(x, Fext, HW, q0, Fq, win, wqkv_bf3, wout_bf3p, rot_cos, rot_sin, band, eps, out, (hipStream_t)stream)) {
             DAWN_LAUNCH_CHECK();

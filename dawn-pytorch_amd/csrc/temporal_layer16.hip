@@ -650,6 +650,382 @@ __global__ __launch_bounds__(NT) void temporal_layer16_kernel(
 #endif
 }
 
+
+// =====================================================================================================================================
+// ONE TILE PER WAVE (round 6, second form): 13 waves (832 threads: 4 / 3 / 3 / 3 per SIMD, 128 registers each).  In the 8-wave kernel above
+// five waves own two query tiles and run them one after the other -- S, softmax, P.V, out-projection of a tile form one dependent chain,
+// and once the one-tile partner of a SIMD is through, the two-tile wave runs alone: ~45 % of phase B has one wave per SIMD, nothing to fill
+// its latencies with.  Here every query tile is a wave of its own (13 tiles at 200 frames), 3..4 waves per SIMD drift apart by themselves,
+// and the K / V projection is cut into (combination, row range) groups per wave as before.  The price is the register budget: 128 instead
+// of 256 -- fragments are requested a region (not a stage) ahead and in halves (three key blocks, one block pair, two 16-channel blocks).
+struct tl13_sched { unsigned w[16]; };        // per wave: bits 0..4 query tile (31 = none), 5..7 K / V group (7 = none), 8..12 / 13..17 its row tiles [t0, t1)
+constexpr int NW13 = 13, NT13 = NW13 * 64;
+
+__global__ __launch_bounds__(NT13) void temporal_layer13_kernel(
+    const float* x, int Fext, int HW, int q0, int Fq, int win, const unsigned short* __restrict__ wqkv_s,
+    const unsigned short* __restrict__ wout_sp, const float* __restrict__ rcos, const float* __restrict__ rsin,
+    const float* __restrict__ band, float eps, float* out, int delta, const tl13_sched sched) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    unsigned char* Xp = smem16;
+    unsigned char* Kp = Xp + XP_BYTES;
+    unsigned char* Vp = Kp + KP_BYTES;
+    float* band4 = reinterpret_cast<float*>(Vp + VP_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const long p = blockIdx.x;
+#define REGION() __builtin_amdgcn_sched_barrier(0)
+
+    // ---- phase 0 (as above; 52 rows per pass, four passes)
+    {
+        const int sub = tid & 15;
+        constexpr int RPP = NT13 / 16, MAXR = FA / RPP;
+        static_assert(RPP * MAXR == FA, "row passes");
+        f32x4 xv[MAXR];
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int j = (tid >> 4) + RPP * i;
+            xv[i] = zero4();
+            if (j < Fext) xv[i] = *reinterpret_cast<const f32x4*>(x + ((long)j * HW + p) * C + sub * 4);
+        }
+#pragma unroll
+        for (int i = 0; i < MAXR; ++i) {
+            const int j = (tid >> 4) + RPP * i;
+            const f32x4 v = xv[i];
+            float sm = v.x + v.y + v.z + v.w;
+            sm = row16_sum(sm);
+            const float mu = sm * (1.0f / C);
+            const f32x4 dl = v - mu;
+            float ss = dl.x * dl.x + dl.y * dl.y + dl.z * dl.z + dl.w * dl.w;
+            ss = row16_sum(ss);
+            const float rs = 1.0f / sqrtf(ss * (1.0f / C) + eps);
+            const f32x4 o = dl * rs;
+            typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+            bf16x4 h1, h2, h3;
+            f32x4 r;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h1[e] = (__bf16)o[e]; r[e] = o[e] - (float)h1[e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { h2[e] = (__bf16)r[e]; r[e] = r[e] - (float)h2[e]; }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) h3[e] = (__bf16)r[e];
+            unsigned char* dst = Xp + ((size_t)(sub >> 1) * FA + j) * 16 + (sub & 1) * 8;
+            *reinterpret_cast<uint2*>(dst) = __builtin_bit_cast(uint2, h1);
+            *reinterpret_cast<uint2*>(dst + (size_t)8 * FA * 16) = __builtin_bit_cast(uint2, h2);
+            *reinterpret_cast<uint2*>(dst + (size_t)16 * FA * 16) = __builtin_bit_cast(uint2, h3);
+        }
+    }
+
+    const unsigned winfo = sched.w[wv];
+    const int qt = (int)(winfo & 31u);
+    const int kvc = (int)((winfo >> 5) & 7u);
+    const int kt0 = (int)((winfo >> 8) & 31u), kt1 = (int)((winfo >> 13) & 31u);
+    const int nblk = (Fext + 15) >> 4;
+    const int nkb = (16 + 2 * win + 15) >> 4;
+    const bool has_q = qt != 31;
+    const bool isV = (kvc & 2) != 0;
+    const int kmb = kvc & 1;
+
+    const __amdgpu_buffer_rsrc_t rsw = __builtin_amdgcn_make_buffer_rsrc((void*)wqkv_s, 0, 4 * 3 * 2 * 768 * 16, 0x00020000);
+    const unsigned wlane = (unsigned)(((6 * (g >> 1) + (g & 1)) * 768 + n) * 16);
+    const unsigned wlane_v = (unsigned)(((6 * (g >> 1) + (g & 1)) * 768 + 16 * (n >> 3) + (n & 7)) * 16);
+    const __amdgpu_buffer_rsrc_t rso = __builtin_amdgcn_make_buffer_rsrc((void*)wout_sp, 0, 16 * 3 * 2 * C * 16, 0x00020000);
+    const unsigned wolane = (unsigned)(((6 * (g >> 1) + (g & 1)) * C + n) * 16);
+    const __amdgpu_buffer_rsrc_t rsc = __builtin_amdgcn_make_buffer_rsrc((void*)rcos, 0, Fext * 64, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rss = __builtin_amdgcn_make_buffer_rsrc((void*)rsin, 0, Fext * 64, 0x00020000);
+    typedef int i32x2_t __attribute__((ext_vector_type(2)));
+    auto rot_load = [&](const __amdgpu_buffer_rsrc_t r, int row, int mb) {
+        return __builtin_bit_cast(float2, (i32x2_t)__builtin_amdgcn_raw_buffer_load_b64(r, (unsigned)(row * 64 + 8 * g), 32 * mb, 0));
+    };
+    auto wq_load = [&](int hh, int mb, bf16x8t (&w)[2][3]) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int pl = 0; pl < 3; ++pl)
+                w[s][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rsw, wlane, ((12 * s + 2 * pl) * 768 + 32 * hh + 16 * mb) * 16, 0));
+    };
+
+    const int i0 = q0 - delta + 16 * qt;
+    const int iq = i0 + n;
+    const int iqc = max(0, min(iq, Fext - 1));
+    f32x4 outT[4];
+#pragma unroll
+    for (int cm = 0; cm < 4; ++cm) outT[cm] = zero4();
+    bf16x8t qp[3];
+
+    const int bidx = (tid & 127) + (tid >> 7) - 15;
+    const bool bok = bidx >= 0 && bidx <= 2 * win;
+    bf16x8t wq0[2][3];          // Wq fragments of feature half 0, requested across the closing barrier
+    float2 qcs[2], qsn[2];
+    float bandv;
+    auto request_next = [&](int hh) {
+        wq_load(hh, 0, wq0);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            qcs[mb] = rot_load(rsc, iqc, mb);
+            qsn[mb] = rot_load(rss, iqc, mb);
+        }
+        bandv = band[max(0, min(bidx, 2 * win)) * HEADS + hh];
+    };
+    request_next(0);
+    REGION();
+    __syncthreads();
+
+    for (int h = 0; h < HEADS; ++h) {
+        // ---- phase A
+        if (tid < 512) band4[(tid >> 7) * BLD + (tid & 127)] = bok ? bandv * LOG2E : NEG;
+        if (has_q) {
+            bf16x8t xfq[2][3];
+            const unsigned char* xr = Xp + ((size_t)g * FA + iqc) * 16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int pl = 0; pl < 3; ++pl)
+                    xfq[s][pl] = *reinterpret_cast<const bf16x8t*>(xr + (size_t)((pl * 8 + 4 * s) * FA) * 16);
+            REGION();
+            f32x4 d2[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) d2[s] = mfma16(wq0[s][PA6[u]], xfq[s][PB6[u]], d2[s]);
+            const f32x4 d0 = d2[0] + d2[1];
+            asm volatile("" :: "v"(d0[0]), "v"(d0[1]), "v"(d0[2]), "v"(d0[3]));
+            REGION();
+            bf16x8t wq1[2][3];
+            wq_load(h, 1, wq1);
+            REGION();
+            f32x4 e2[2] = {zero4(), zero4()};
+#pragma unroll
+            for (int u = 0; u < 6; ++u)
+#pragma unroll
+                for (int s = 0; s < 2; ++s) e2[s] = mfma16(wq1[s][PA6[u]], xfq[s][PB6[u]], e2[s]);
+            const f32x4 d1 = e2[0] + e2[1];
+            const float sl = 0.17677669529663687f * LOG2E;
+            float qr[8];
+            {
+                const float2 cs = {qcs[0].x * sl, qcs[0].y * sl}, sn = {qsn[0].x * sl, qsn[0].y * sl};
+                qr[0] = d0[0] * cs.x - d0[1] * sn.x; qr[1] = d0[1] * cs.x + d0[0] * sn.x;
+                qr[2] = d0[2] * cs.y - d0[3] * sn.y; qr[3] = d0[3] * cs.y + d0[2] * sn.y;
+            }
+            {
+                const float2 cs = {qcs[1].x * sl, qcs[1].y * sl}, sn = {qsn[1].x * sl, qsn[1].y * sl};
+                qr[4] = d1[0] * cs.x - d1[1] * sn.x; qr[5] = d1[1] * cs.x + d1[0] * sn.x;
+                qr[6] = d1[2] * cs.y - d1[3] * sn.y; qr[7] = d1[3] * cs.y + d1[2] * sn.y;
+            }
+            dawn_split3_oct(qr, qp[0], qp[1], qp[2]);
+            asm volatile("" :: "v"(qp[0]), "v"(qp[1]), "v"(qp[2]));
+        }
+        REGION();
+        if (kvc < 4) {
+            bf16x8t wkv[2][3];
+            {
+                const unsigned lo = isV ? wlane_v : wlane;
+                const int col0 = isV ? (512 + 32 * h + 8 * kmb) : (256 + 32 * h + 16 * kmb);
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        wkv[s][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rsw, lo, ((12 * s + 2 * pl) * 768 + col0) * 16, 0));
+            }
+            for (int rt = kt0; rt < kt1; ++rt) {
+                REGION();
+                const int row = 16 * rt + n;
+                const int rc_ = min(row, Fext - 1);
+                const float2 cs = rot_load(rsc, rc_, kmb), sn = rot_load(rss, rc_, kmb);
+                const unsigned char* xr = Xp + ((size_t)g * FA + row) * 16;
+                bf16x8t xf[2][3];
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        xf[s][pl] = *reinterpret_cast<const bf16x8t*>(xr + (size_t)((pl * 8 + 4 * s) * FA) * 16);
+                REGION();
+                f32x4 d2[2] = {zero4(), zero4()};
+                uint2 p1, p2, p3;
+                if (!isV) {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) d2[s] = mfma16(wkv[s][PA6[u]], xf[s][PB6[u]], d2[s]);
+                    const f32x4 d = d2[0] + d2[1];
+                    const f32x4 kr = {d[0] * cs.x - d[1] * sn.x, d[1] * cs.x + d[0] * sn.x, d[2] * cs.y - d[3] * sn.y, d[3] * cs.y + d[2] * sn.y};
+                    split3_quad(kr, p1, p2, p3);
+                    unsigned char* dst = Kp + ((size_t)g * FA + row) * 16 + kmb * 8;
+                    *reinterpret_cast<uint2*>(dst) = p1;
+                    *reinterpret_cast<uint2*>(dst + (size_t)4 * FA * 16) = p2;
+                    *reinterpret_cast<uint2*>(dst + (size_t)8 * FA * 16) = p3;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int s = 0; s < 2; ++s) d2[s] = mfma16(xf[s][PB6[u]], wkv[s][PA6[u]], d2[s]);
+                    split3_quad(d2[0] + d2[1], p1, p2, p3);
+                    unsigned char* dst = Vp + ((size_t)(kmb * 64 + lane) * NB + rt) * 8;
+                    *reinterpret_cast<uint2*>(dst) = p1;
+                    *reinterpret_cast<uint2*>(dst + (size_t)NB * 2 * 512) = p2;
+                    *reinterpret_cast<uint2*>(dst + (size_t)2 * NB * 2 * 512) = p3;
+                }
+            }
+        }
+        REGION();
+        __syncthreads();
+
+        // ---- phase B: the own tile
+        if (has_q) {
+            const int B0 = (i0 - win) >> 4;
+            const int blo = max(0, -B0), bhi = min(nkb, nblk - B0);
+            const int Bf = B0 + blo;
+            const int sh = (15 - n) & 3;
+            const float* bb = band4 + sh * BLD + ((15 - n) - sh) + 4 * g + 16 * blo;
+            const unsigned char* kbase = Kp + ((size_t)g * FA + 16 * Bf + n) * 16;
+            const unsigned char* vbase = Vp + ((size_t)lane * NB + Bf) * 8;
+            const int klast = Fext - 16 * (Bf + (bhi - blo) - 1) - 4 * g;
+            f32x4 o[2] = {zero4(), zero4()};
+            float l = 0.f;
+            auto body = [&](auto nv_) {
+                constexpr int NV = decltype(nv_)::value;
+                constexpr int NP = (NV + 1) / 2;
+                constexpr int H1 = (NV + 1) / 2;                                   // slots of the first S half
+                f32x4 st[NV];
+                REGION();
+                {
+                    bf16x8t kf[H1][3];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) st[j] = *reinterpret_cast<const f32x4*>(bb + 16 * j);
+#pragma unroll
+                    for (int j = 0; j < H1; ++j)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            kf[j][pl] = *reinterpret_cast<const bf16x8t*>(kbase + (size_t)j * 256 + (size_t)pl * 4 * FA * 16);
+                    REGION();
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int j = 0; j < H1; ++j) st[j] = mfma16(kf[j][PA6[u]], qp[PB6[u]], st[j]);
+                }
+                float m = NEG;
+#pragma unroll
+                for (int j = 0; j < H1; ++j)
+                    if (j != NV - 1)
+                        m = max3_nc(m, __builtin_amdgcn_fmed3f(st[j][0], st[j][1], __builtin_inff()), __builtin_amdgcn_fmed3f(st[j][2], st[j][3], __builtin_inff()));
+                asm volatile("" :: "v"(m), "v"(st[H1 - 1][0]), "v"(st[H1 - 1][3]));
+                REGION();
+                if constexpr (NV > H1) {
+                    bf16x8t kf[NV - H1][3];
+#pragma unroll
+                    for (int j = H1; j < NV; ++j)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            kf[j - H1][pl] = *reinterpret_cast<const bf16x8t*>(kbase + (size_t)j * 256 + (size_t)pl * 4 * FA * 16);
+                    REGION();
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int j = H1; j < NV; ++j) st[j] = mfma16(kf[j - H1][PA6[u]], qp[PB6[u]], st[j]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[NV - 1][r] = r < klast ? st[NV - 1][r] : NEG;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (j >= H1 || j == NV - 1)
+                        m = max3_nc(m, __builtin_amdgcn_fmed3f(st[j][0], st[j][1], __builtin_inff()), __builtin_amdgcn_fmed3f(st[j][2], st[j][3], __builtin_inff()));
+                asm volatile("" :: "v"(m));
+                REGION();
+                auto v_fetch = [&](int kk, bf16x8t (&v)[2][3]) {
+                    const int jb = 2 * kk + 1 < NV ? 2 * kk + 1 : 2 * kk;
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const uint2 lo = *reinterpret_cast<const uint2*>(vbase + (size_t)(2 * kk) * 8 + (size_t)(pl * 2 + mb) * NB * 512);
+                            const uint2 hi = *reinterpret_cast<const uint2*>(vbase + (size_t)jb * 8 + (size_t)(pl * 2 + mb) * NB * 512);
+                            v[mb][pl] = join8(lo, hi);
+                        }
+                };
+                bf16x8t vf[2][3];
+                v_fetch(0, vf);
+                m = rows4_max(m);
+                REGION();
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(st[j][r] - m);
+                        st[j][r] = pv;
+                        l += pv;
+                    }
+#pragma unroll
+                for (int kk = 0; kk < NP; ++kk) {
+                    float pr[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pr[r] = st[2 * kk][r]; pr[4 + r] = 2 * kk + 1 < NV ? st[2 * kk + 1 < NV ? 2 * kk + 1 : 0][r] : 0.f; }
+                    bf16x8t pp[3];
+                    dawn_split3_oct(pr, pp[0], pp[1], pp[2]);
+                    REGION();
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) o[mb] = mfma16(vf[mb][PA6[u]], pp[PB6[u]], o[mb]);
+                    float cl = o[0][0] + o[1][0];
+                    asm volatile("" :: "v"(cl));
+                    REGION();
+                    if (kk + 1 < NP) v_fetch(kk + 1, vf);
+                }
+            };
+            switch (bhi - blo) {
+                case 6: body(std::integral_constant<int, 6>{}); break;
+                case 5: body(std::integral_constant<int, 5>{}); break;
+                case 4: body(std::integral_constant<int, 4>{}); break;
+                case 3: body(std::integral_constant<int, 3>{}); break;
+                case 2: body(std::integral_constant<int, 2>{}); break;
+                default: body(std::integral_constant<int, 1>{}); break;
+            }
+            l = rows4_sum(l);
+            const float inv = 1.0f / l;
+            float orr[8];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { orr[r] = o[0][r] * inv; orr[4 + r] = o[1][r] * inv; }
+            bf16x8t op[3];
+            dawn_split3_oct(orr, op[0], op[1], op[2]);
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                REGION();
+                bf16x8t wo[2][3];
+#pragma unroll
+                for (int c2 = 0; c2 < 2; ++c2)
+#pragma unroll
+                    for (int pl = 0; pl < 3; ++pl)
+                        wo[c2][pl] = __builtin_bit_cast(bf16x8t, __builtin_amdgcn_raw_buffer_load_b128(rso, wolane, ((12 * h + 2 * pl) * C + 16 * (2 * hf + c2)) * 16, 0));
+                REGION();
+#pragma unroll
+                for (int u = 0; u < 6; ++u)
+#pragma unroll
+                    for (int c2 = 0; c2 < 2; ++c2) outT[2 * hf + c2] = mfma16(wo[c2][PA6[u]], op[PB6[u]], outT[2 * hf + c2]);
+                float sink = outT[2 * hf][0] + outT[2 * hf + 1][0];
+                asm volatile("" :: "v"(sink));
+            }
+        }
+        REGION();
+        request_next(h + 1 < HEADS ? h + 1 : h);
+        REGION();
+        __syncthreads();
+    }
+#undef REGION
+
+    if (has_q && iq >= q0 && iq < q0 + Fq) {
+        const float* xr = x + ((long)iq * HW + p) * C + 4 * g;
+        float* orow = out + ((long)(iq - q0) * HW + p) * C + 4 * g;
+        f32x4 xv[4];
+#pragma unroll
+        for (int cm = 0; cm < 4; ++cm) xv[cm] = *reinterpret_cast<const f32x4*>(xr + 16 * cm);
+#pragma unroll
+        for (int cm = 0; cm < 4; ++cm) *reinterpret_cast<f32x4*>(orow + 16 * cm) = outT[cm] + xv[cm];
+    }
+#endif
+}
+
 }  // namespace
 
 // ---- the launcher's schedule: who projects which K / V rows and who owns which query tile, balanced per SIMD (waves w, w + 4, w + 8
@@ -800,6 +1176,108 @@ extern "C" int dawn_tl16_schedule(int Fext, int q0, int Fq, int win, dawn_tl16_s
             simd_units[4 + s] = loadB[s];
         }
     return 1;
+}
+
+// ---- one tile per wave: tile -> wave and K / V group -> wave for the 13-wave kernel.  Waves w, w + 4, w + 8 (, 12) share a SIMD: SIMD 0
+// hosts four waves, the others three; the tiles are spread so that the SIMDs' attention loads are even (the clip-end tiles, which cost
+// less, go to the four-wave SIMD), wave w projects (K | V, feature half) combination w & 3 for an equal share of the row tiles.
+static bool tl13_make_schedule(int Fext, int q0, int Fq, int win, tl13_sched& sc) {
+    if (Fext < 1 || Fext > TL16_ROWS || q0 < 0 || Fq < 1 || q0 + Fq > Fext || win < 0) return false;
+    const int nkb = (16 + 2 * win + 15) / 16;
+    if (nkb > TL16_KEY_BLOCKS) return false;
+    const int delta = (((q0 - win) % 16) + 16) % 16;
+    const int nqt = (Fq + delta + 15) / 16, nblk = (Fext + 15) / 16;
+    if (nqt > NW13) return false;
+    int cost[NW13], order[NW13];
+    for (int t = 0; t < nqt; ++t) {
+        const int a = q0 - delta + 16 * t - win;
+        const int B0 = a / 16 - ((a % 16) < 0 ? 1 : 0);
+        const int lo = B0 < 0 ? -B0 : 0, hi = nkb < nblk - B0 ? nkb : nblk - B0;
+        int nb = 0, np = 0;
+        for (int kk = 0; kk < TL16_KEY_BLOCKS / 2; ++kk) {
+            const int va = 2 * kk >= lo && 2 * kk < hi, vb = 2 * kk + 1 >= lo && 2 * kk + 1 < hi;
+            nb += va + vb;
+            np += (va || vb);
+        }
+        cost[t] = 6 * nb + 12 * np + 24 + 24;                  // S, P.V, out-projection, Q projection
+        order[t] = t;
+    }
+    for (int a = 0; a < nqt; ++a)
+        for (int b = a + 1; b < nqt; ++b)
+            if (cost[order[b]] > cost[order[a]]) { const int t = order[a]; order[a] = order[b]; order[b] = t; }
+    const int cap[4] = {4, 3, 3, 3};
+    int bins[4][4], nb_[4] = {0, 0, 0, 0}, load[4] = {0, 0, 0, 0};
+    for (int a = 0; a < nqt; ++a) {
+        int best = -1;
+        for (int s = 0; s < 4; ++s)
+            if (nb_[s] < cap[s] && (best < 0 || load[s] < load[best])) best = s;
+        bins[best][nb_[best]++] = order[a];
+        load[best] += cost[order[a]];
+    }
+    for (int it = 0; it < 64; ++it) {                            // moves / swaps while the sum of squared loads falls
+        long bestgain = 0;
+        int bs = -1, bd = -1, bi = -1, bj = -1;
+        for (int s = 0; s < 4; ++s)
+            for (int d = 0; d < 4; ++d) {
+                if (s == d) continue;
+                for (int i = 0; i < nb_[s]; ++i)
+                    for (int j = -1; j < nb_[d]; ++j) {
+                        if (j < 0 && nb_[d] >= cap[d]) continue;
+                        const int ci = cost[bins[s][i]], cj = j < 0 ? 0 : cost[bins[d][j]];
+                        const long ls = load[s] - ci + cj, ld = load[d] + ci - cj;
+                        const long gain = (long)load[s] * load[s] + (long)load[d] * load[d] - ls * ls - ld * ld;
+                        if (gain > bestgain) { bestgain = gain; bs = s; bd = d; bi = i; bj = j; }
+                    }
+            }
+        if (bs < 0) break;
+        const int ti = bins[bs][bi];
+        if (bj < 0) {
+            bins[bd][nb_[bd]++] = ti;
+            bins[bs][bi] = bins[bs][--nb_[bs]];
+            load[bs] -= cost[ti];
+            load[bd] += cost[ti];
+        } else {
+            const int tj = bins[bd][bj];
+            bins[bs][bi] = tj;
+            bins[bd][bj] = ti;
+            load[bs] += cost[tj] - cost[ti];
+            load[bd] += cost[ti] - cost[tj];
+        }
+    }
+    int wq_[NW13];
+    for (int w = 0; w < NW13; ++w) wq_[w] = 31;
+    for (int s = 0; s < 4; ++s)
+        for (int a = 0; a < nb_[s]; ++a) wq_[s + 4 * a] = bins[s][a];
+    // K / V: the waves of combination c = w & 3 share the row tiles evenly (contiguous ranges)
+    int t0[NW13], t1[NW13];
+    for (int c = 0; c < 4; ++c) {
+        int nw = 0;
+        for (int w = c; w < NW13; w += 4) ++nw;
+        int at = 0, k = 0;
+        for (int w = c; w < NW13; w += 4, ++k) {
+            const int sz = nblk / nw + (k < nblk % nw ? 1 : 0);
+            t0[w] = at;
+            t1[w] = at + sz;
+            at += sz;
+        }
+    }
+    for (int w = 0; w < 16; ++w) sc.w[w] = 31u | (7u << 5);
+    for (int w = 0; w < NW13; ++w)
+        sc.w[w] = (unsigned)wq_[w] | ((unsigned)(t0[w] == t1[w] ? 7 : (w & 3)) << 5) | ((unsigned)t0[w] << 8) | ((unsigned)t1[w] << 13);
+    return true;
+}
+
+bool dawn_temporal_layer13_try(const float* x, int Fext, int HW, int q0, int Fq, int win, const void* wqkv_bf3,
+                               const void* wout_bf3p, const float* rot_cos, const float* rot_sin, const float* band, float eps,
+                               float* out, hipStream_t s) {
+    if (!wqkv_bf3 || !wout_bf3p) return false;
+    tl13_sched sc;
+    if (!tl13_make_schedule(Fext, q0, Fq, win, sc)) return false;
+    const int delta = (((q0 - win) % 16) + 16) % 16;
+    (void)hipFuncSetAttribute((const void*)temporal_layer13_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    hipLaunchKernelGGL(temporal_layer13_kernel, dim3(HW), dim3(NT13), LDS_BYTES, s, x, Fext, HW, q0, Fq, win,
+                       (const unsigned short*)wqkv_bf3, (const unsigned short*)wout_bf3p, rot_cos, rot_sin, band, eps, out, delta, sc);
+    return true;
 }
 
 // Launch the window-tiled layer when the shape is inside its instantiation (win <= 40, Fext <= 208, both split weight images);

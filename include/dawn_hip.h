@@ -215,7 +215,10 @@ int dawn_temporal_layer_c64(const float* x, int Fext, int HW, int q0, int Fq, in
  * Round 6 (ABI 8): WMODE 4 = the WINDOW-tiled kernel (csrc/temporal_layer16.hip): 16-query tiles against the 16 + 2 win <= 96 keys
  * of their window (only the key blocks that exist at the clip ends) on v_mfma_f32_16x16x32_bf16, 12 waves, the head's work split
  * into two SIMD-balanced phases by dawn_tl16_schedule.  Automatic (flags & 7 == 0) whenever both split weight images are given,
- * win <= 40 and Fext <= 208; flags & 7 == 5 forces it (error if the shape is outside), flags & 256 keeps the 32 x 32 kernel. */
+ * win <= 40 and Fext <= 208; flags & 7 == 5 forces it (error if the shape is outside), flags & 256 keeps the 32 x 32 kernel.
+ * WMODE 5 = the same window tiling with ONE query tile per wave (13 waves of 128 registers instead of 8 of 256: no wave runs two tiles one
+ * after the other): taken first by the automatic choice whenever the query range has at most 13 tiles (208 - delta frames); flags & 7 == 6
+ * forces it. */
 int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int q0, int Fq, int win, const float* wqkv,
                                const void* wqkv_bf3, const float* wout, const void* wout_bf3p, const float* rot_cos,
                                const float* rot_sin, const float* band, float eps, float* out, int flags, void* stream);

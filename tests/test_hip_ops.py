@@ -881,9 +881,11 @@ def test_temporal_layer_c64(hip, ref, Fext, HW, q0, Fq, win):
     # every kernel family explicitly (flags: m + 1 forces WMODE m; 16 = WMODE 3 without the interleave hints)
     try:
         for flags, name in ((1, "wmode0"), (2, "wmode1"), (3, "wmode2"), (4, "wmode3"), (4 | 16, "wmode3_hints"),
-                            (4 | 32, "wmode3_out_fp32"), (5, "wmode4_window_tiled"), (256, "auto_without_wmode4")):
-            if flags == 5 and (win > 40 or Fext > 208):
-                continue                                         # outside the window-tiled kernel's instantiation
+                            (4 | 32, "wmode3_out_fp32"), (5, "wmode4_window_tiled"), (6, "wmode5_tile_per_wave"), (256, "auto_without_wmode4")):
+            if flags in (5, 6) and (win > 40 or Fext > 208):
+                continue                                         # outside the window-tiled kernels' instantiation
+            if flags == 6 and (Fq + (q0 - win) % 16 + 15) // 16 > 13:
+                continue                                         # more than 13 query tiles
             if flags & 7 == 4 and (Fext * 576 + ((Fext + 31) // 32) * 6144 + 8 * (32 * ((32 + 2 * win + 31) // 32) + 32) * 4 > 163840
                                    or Fq + (q0 - win) % 16 > 256):
                 continue                                         # WMODE 3 does not fit this shape (LDS)
@@ -913,7 +915,7 @@ def test_temporal_attention_trained_weight_like_range(hip, ref):
     want = ref.temporal_layer_c64(x, Fext, HW, q0, Fq, win, wqkv, wout, rc, rs, band)
     wsplit, wosp = pack_bf3(unpack_kn(wqkv)).cuda(), pack_bf3_temporal_out(unpack_kn(wout)).cuda()
     try:
-        for flags, name in ((0, "default"), (1, "wmode0"), (3, "wmode2"), (4, "wmode3"), (5, "wmode4_window_tiled")):
+        for flags, name in ((0, "default"), (1, "wmode0"), (3, "wmode2"), (4, "wmode3"), (5, "wmode4_window_tiled"), (6, "wmode5_tile_per_wave")):
             hip.temporal_flags = flags
             got = hip.temporal_layer_c64(*gpu(x), Fext, HW, q0, Fq, win, *gpu(wqkv, wout, rc, rs, band), wqkv_bf3=wsplit,
                                          wout_bf3p=wosp)
@@ -943,12 +945,13 @@ def test_temporal_layer16_is_run_to_run_deterministic(hip, F):
     try:
         hip.temporal_flags = 4
         want = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
-        hip.temporal_flags = 5
-        first = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
-        check(f"temporal_layer16_vs_wmode3/F{F}", first, want.cpu(), 3e-5)
-        for rep in range(7):
-            again = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
-            assert torch.equal(again, first), f"run {rep + 1} differs from run 0 in {int((again != first).sum())} elements"
+        for flags in (5, 6):
+            hip.temporal_flags = flags
+            first = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
+            check(f"temporal_layer16_vs_wmode3/F{F}_flags{flags}", first, want.cpu(), 3e-5)
+            for rep in range(7):
+                again = hip.temporal_layer_c64(x, F, HW, 0, F, win, *gpu(wqkv, wout), rc, rs, band, **kw)
+                assert torch.equal(again, first), f"flags {flags}: run {rep + 1} differs from run 0 in {int((again != first).sum())} elements"
     finally:
         hip.temporal_flags = 0
 

@@ -18,7 +18,7 @@ for HW in (4096, 1024):
     x = torch.randn(F * HW, 64, generator=g).cuda()
     out = torch.empty_like(x)
     for rep in range(3):
-        for flags, name in ((4, "wmode3 32x32 tiles"), (5, "wmode4 window-tiled")):
+        for flags, name in ((4, "wmode3 32x32 tiles"), (5, "wmode4 window-tiled"), (6, "wmode5 tile per wave")):
             ops.temporal_flags = flags
             for _ in range(2):
                 ops.temporal_layer_c64(x, F, HW, 0, F, win, wqkv, wout, rc, rs, band, wqkv_bf3=ws, wout_bf3p=wo, out=out)
@@ -33,7 +33,7 @@ for HW in (4096, 1024):
 HW = 1024
 x = torch.randn(F * HW, 64, generator=g).cuda()
 out = torch.empty(120 * HW, 64, device="cuda")
-for flags, name in ((4, "wmode3 32x32 tiles"), (5, "wmode4 window-tiled")):
+for flags, name in ((4, "wmode3 32x32 tiles"), (5, "wmode4 window-tiled"), (6, "wmode5 tile per wave")):
     ops.temporal_flags = flags
     for _ in range(2):
         ops.temporal_layer_c64(x, F, HW, 40, 120, win, wqkv, wout, rc, rs, band, wqkv_bf3=ws, wout_bf3p=wo, out=out)
