@@ -120,6 +120,12 @@ __device__ __forceinline__ float max3_nc(float a, float b, float c) {
     asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
     return r;
 }
+// Wait until MFMA results may be read by INLINE-ASM vector instructions (the compiler pads only the reads it can see: 7 wait states for this
+// shape on gfx950 -- it emits `s_nop 6` behind a chain's last MFMA; 11 here), tied to up to three accumulators.  Behind it v_max3 in asm may
+// read them: `fmaxf` / `fmed3(a, b, inf)` would quiet every operand first (v_max x, x: +24 vector instructions per tile)
+__device__ __forceinline__ void mfma_settle(f32x4& a) { asm volatile("s_nop 7\n\ts_nop 2" : "+v"(a)); }
+__device__ __forceinline__ void mfma_settle(f32x4& a, f32x4& b) { asm volatile("s_nop 7\n\ts_nop 2" : "+v"(a), "+v"(b)); }
+__device__ __forceinline__ void mfma_settle(f32x4& a, f32x4& b, f32x4& c) { asm volatile("s_nop 7\n\ts_nop 2" : "+v"(a), "+v"(b), "+v"(c)); }
 // max / sum over the four lanes {n, n + 16, n + 32, n + 48} that share a query column, result in all four: two gfx950 row swaps
 // (v_permlane16_swap / v_permlane32_swap: vector instructions) instead of two ds_bpermute round trips; the pairing of the xor butterfly
 __device__ __forceinline__ float rows4_max(float v) {
@@ -906,11 +912,13 @@ __global__ __launch_bounds__(NT13) void temporal_layer13_kernel(
                         for (int j = 0; j < H1; ++j) st[j] = mfma16(kf[j][PA6[u]], qp[PB6[u]], st[j]);
                 }
                 float m = NEG;
+                if constexpr (H1 == 3) mfma_settle(st[0], st[1], st[2]);
+                else if constexpr (H1 == 2) mfma_settle(st[0], st[1]);
+                else mfma_settle(st[0]);
 #pragma unroll
                 for (int j = 0; j < H1; ++j)
-                    if (j != NV - 1)
-                        m = max3_nc(m, __builtin_amdgcn_fmed3f(st[j][0], st[j][1], __builtin_inff()), __builtin_amdgcn_fmed3f(st[j][2], st[j][3], __builtin_inff()));
-                asm volatile("" :: "v"(m), "v"(st[H1 - 1][0]), "v"(st[H1 - 1][3]));
+                    if (j != NV - 1) m = max3_nc(max3_nc(m, st[j][0], st[j][1]), st[j][2], st[j][3]);
+                asm volatile("" :: "v"(m));
                 REGION();
                 if constexpr (NV > H1) {
                     bf16x8t kf[NV - H1][3];
@@ -925,12 +933,14 @@ __global__ __launch_bounds__(NT13) void temporal_layer13_kernel(
 #pragma unroll
                         for (int j = H1; j < NV; ++j) st[j] = mfma16(kf[j - H1][PA6[u]], qp[PB6[u]], st[j]);
                 }
+                if constexpr (NV - H1 == 3) mfma_settle(st[H1], st[H1 + 1], st[NV - 1]);
+                else if constexpr (NV - H1 == 2) mfma_settle(st[H1], st[NV - 1]);
+                else if constexpr (NV - H1 == 1) mfma_settle(st[NV - 1]);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) st[NV - 1][r] = r < klast ? st[NV - 1][r] : NEG;
 #pragma unroll
                 for (int j = 0; j < NV; ++j)
-                    if (j >= H1 || j == NV - 1)
-                        m = max3_nc(m, __builtin_amdgcn_fmed3f(st[j][0], st[j][1], __builtin_inff()), __builtin_amdgcn_fmed3f(st[j][2], st[j][3], __builtin_inff()));
+                    if (j >= H1 || j == NV - 1) m = max3_nc(max3_nc(m, st[j][0], st[j][1]), st[j][2], st[j][3]);
                 asm volatile("" :: "v"(m));
                 REGION();
                 auto v_fetch = [&](int kk, bf16x8t (&v)[2][3]) {
