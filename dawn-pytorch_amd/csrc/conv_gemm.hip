@@ -15,6 +15,7 @@
 // float4 per operand tile for four MFMAs.  Workgroups are remapped so that each XCD (private L2) walks a
 // contiguous range of M tiles: the +-1 row halos of a 3x3 conv then hit in that XCD's L2.
 #include <algorithm>
+#include <type_traits>
 
 #include "dawn_common.h"
 #include "../../include/dawn_hip.h"
@@ -54,6 +55,8 @@ namespace {
 // split 3x3 kernel; 0x40000000, read from dawn_conv_desc.policy directly: the row-stationary GEMM kernels fetch their rows in a
 // line-coalesced pattern -- the right bytes in the wrong lanes, profiles/r5_row_fetch_pattern_ablation.txt) exist only in
 // -DDAWN_ABLATION builds (tools/build_timing_lib.sh), never in the shipped library.
+// 0x80000 (A/B, round 6; read from dawn_conv_desc.policy directly, same bits out): the split 1x1 tile GEMM deals its tiles to the XCDs in
+// launch order instead of one contiguous range of row panels per XCD (see gemm1x1_bf16_kernel).
 constexpr int DAWN_CONV_POLICY_DEFAULT = 0x2B00580D;
 #ifdef DAWN_ABLATION
 constexpr int DAWN_CONV_POLICY_MASK = 0x3F0FFFFF;
@@ -1684,6 +1687,7 @@ __global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(cons
     constexpr int WNN = CFG ? 2 : WN;                          // waves along N
     constexpr int TM = 2, TN = CFG ? 1 : 2;
     constexpr int NQ = BM * 8 / NTHR;                          // A quads per thread per stage (4 or 8)
+    static_assert(NQ == 4 || NQ == 8, "the stage wait below names NQ as an immediate");
     constexpr int HPS = BM * 16 + 128;                         // half-plane stride (bytes)
     constexpr int PSZ = 2 * 6 * HPS;                           // planes of one stage (2 sub-chunks of 16 channels)
     constexpr int BSZ = 2 * 6 * BN * 16;                       // weights of one stage
@@ -1700,7 +1704,15 @@ __global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(cons
     const int K = d.C0 + d.C1;
     const int nS = K / 32, nS0 = d.C0 / 32;
     const int nNt = d.N / BN;
-    const int mt = blockIdx.x / nNt, nt = blockIdx.x - mt * nNt;
+    // workgroups are dealt round-robin to the 8 XCDs, each with its own L2: the tiles of one row panel (all nNt column tiles read
+    // the same A rows) go to ONE XCD -- XCD x walks the contiguous tile range [x q + min(x, r), ...) of the row-major tile order
+    // (q = tiles / 8, r = tiles % 8), so a row panel comes over the fabric once instead of once per XCD that holds a column tile
+    int tile = blockIdx.x;
+    if (!(d.policy & 0x80000)) {
+        const int nT = gridDim.x, q = nT >> 3, r = nT & 7, x = tile & 7, j = tile >> 3;
+        tile = x * q + (x < r ? x : r) + j;
+    }
+    const int mt = tile / nNt, nt = tile - mt * nNt;
     const long m0 = (long)mt * BM;
     const int n0 = nt * BN;
     const int ld1 = d.in1 ? d.ld1 : d.ld0;
@@ -1734,8 +1746,10 @@ __global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(cons
         rrs[i] = norm ? d.row_rstd[row] : 1.f;
     }
     auto splitq = [&](int slot, int qi) {
+#pragma clang fp contract(off)          // the normalised value is ROUNDED before its split (as dawn_ln_rows stores it)
         f32x4 v = slot ? araw[1][qi] : araw[0][qi];
-        if (norm) v = (v - rmu[qi]) * rrs[qi];
+        v = (v - rmu[qi]) * rrs[qi];                           // (without a prologue: mean 0, rstd 1 -- exact)
+        asm volatile("" : "+v"(v));                         // (split3's first residual must not fuse with the product either)
         split3(v, ap[qi][0], ap[qi][1], ap[qi][2]);
     };
     auto loadA = [&](int s, int slot) {
@@ -1779,59 +1793,100 @@ __global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(cons
 
     issueB(0, 0);
     loadA(0, 0);
-    if (nS > 1) loadA(1, 1);
+    loadA(nS > 1 ? 1 : 0, 1);
 #pragma unroll
     for (int i = 0; i < NQ; ++i) splitq(0, i);
     writeA(0);
-    for (int s = 0; s < nS; ++s) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // One stage = ONE basic block (round 6): every fetch / split / plane write of a stage is unconditional -- past the end of K the
+    // stage index is clamped, so the last stages re-fetch valid bytes into buffers nobody reads again -- and the register slot of
+    // the A rows is a compile-time constant of the stage's parity.  Before, `if (s + 1 < nS)` around the splits put them into a
+    // basic block of their own BEHIND the stage's MFMAs: a wave issued 12 MFMAs (its issue port blocked for 12 x 32 cycles), then
+    // ~70 vector instructions with the matrix pipe idle (SQ counters of the M = 12,800 launches: matrix pipe 21 % busy, vector ALU
+    // 26 %, LDS 28 %, 1.4 waves per SIMD -- the three in sequence, profiles/r6_gemm1x1_deep_pmc.md).  Now the scheduling groups
+    // below put the split arithmetic BETWEEN the MFMAs of the same wave.
+    auto stage = [&](auto PARC, const int s) {
+        constexpr int PAR = decltype(PARC)::value;           // s & 1: plane / weight buffer of this stage, register slot of stage s + 2
+        // the weights of stage s (LDS-DMA) must have landed; the A rows of stage s+1 -- the NQ youngest loads, issued after that DMA --
+        // may stay in flight (vmcnt retires in order): they are first read by the splits between this stage's MFMAs
+        if constexpr (NQ == 4) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();       // planes(s) + weights(s) complete; buffers of stage s-1 are free
-        const int cur = s & 1;
-        if (s + 1 < nS) issueB(s + 1, cur ^ 1);
-        // araw[(s+1)&1] holds stage s+1 (landed: waited above); stage s+2 goes into the slot stage s used
-        const unsigned char* Pb = planes + (size_t)cur * PSZ;
-        const unsigned char* Bb = Bs + (size_t)cur * BSZ;
-#pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            bf16x8 fa[TM][3], fb[TN][3];
+        issueB(s + 1 < nS ? s + 1 : nS - 1, PAR ^ 1);
+        // stage s+2's rows go into the register slot stage s used (split during stage s-1): a stage and a half ahead of their split
+        loadA(s + 2 < nS ? s + 2 : nS - 1, PAR);
+        __builtin_amdgcn_sched_barrier(0);  // (the fetches stay at the top of the stage)
+        const unsigned char* Pb = planes + (size_t)PAR * PSZ;
+        const unsigned char* Bb = Bs + (size_t)PAR * BSZ;
+        bf16x8 fa[2][TM][3], fb[2][TN][3];
+        auto read_frags = [&](const int sub) {
             constexpr int RA[3] = {2, 0, 1}, RB[3] = {0, 2, 1};
 #pragma unroll
             for (int g = 0; g < 3; ++g) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[i][RA[g]] = *reinterpret_cast<const bf16x8*>(Pb + (size_t)sub * 6 * HPS + (size_t)(RA[g] * 2 + half) * HPS +
-                                                                     (wm * 64 + i * 32 + l31) * 16);
+                    fa[sub][i][RA[g]] = *reinterpret_cast<const bf16x8*>(Pb + (size_t)sub * 6 * HPS + (size_t)(RA[g] * 2 + half) * HPS +
+                                                                          (wm * 64 + i * 32 + l31) * 16);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    fb[j][RB[g]] = *reinterpret_cast<const bf16x8*>(
+                    fb[sub][j][RB[g]] = *reinterpret_cast<const bf16x8*>(
                         Bb + ((size_t)((sub * 6 + RB[g] * 2 + half) * BN + wn * (32 * TN) + j * 32 + l31)) * 16);
             }
-            constexpr int PA9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
-            constexpr int PB9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+        };
+        // the split of one PAIR of A values in three steps of 5 / 5 / 3 vector instructions (the arithmetic of split3, in its order):
+        // one step goes behind each MFMA, so the vector ALU works while the matrix pipe runs that MFMA (8 issue slots)
+        constexpr int NMF = NT * TM * TN, NSTEP = 3 * NQ;       // per half stage: MFMAs; split steps (NQ pairs: NQ / 2 quads)
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        f32x2 px[NQ], pe[NQ];
+        auto split_step = [&](const int sub, const int k) {
+#pragma clang fp contract(off)      // the normalised value is ROUNDED before its split (as dawn_ln_rows stores it): no fma of the product into the residual
+            typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+            const int pr = k / 3, st = k - 3 * pr;
+            const int qi = sub * (NQ / 2) + (pr >> 1), e = pr & 1;
+            bf16x2 h;
+            if (st == 0) {
+                const f32x4 q4 = (PAR ^ 1) ? araw[1][qi] : araw[0][qi];
+                f32x2 x = {q4[2 * e], q4[2 * e + 1]};
+                x = (x - rmu[qi]) * rrs[qi];                      // (without a prologue: mean 0, rstd 1 -- exact)
+                h[0] = (__bf16)x[0]; h[1] = (__bf16)x[1];
+                px[pr] = x;
+                pe[pr][0] = (float)h[0]; pe[pr][1] = (float)h[1];
+            } else if (st == 1) {
+                const f32x2 x = px[pr] - pe[pr];
+                h[0] = (__bf16)x[0]; h[1] = (__bf16)x[1];
+                px[pr] = x;
+                pe[pr][0] = (float)h[0]; pe[pr][1] = (float)h[1];
+            } else {
+                const f32x2 x = px[pr] - pe[pr];
+                h[0] = (__bf16)x[0]; h[1] = (__bf16)x[1];
+            }
+            const unsigned hb = __builtin_bit_cast(unsigned, h);
+            if (e == 0) ap[qi][st].x = hb; else ap[qi][st].y = hb;
+        };
+        constexpr int PA9[9] = {2, 2, 1, 2, 0, 1, 1, 0, 0};
+        constexpr int PB9[9] = {2, 1, 2, 0, 2, 1, 0, 1, 0};
+        // fences: MFMA and vector ALU instructions keep the order written here; LDS / global / scalar instructions may cross
+        constexpr int FENCE = 0x4 | 0x10 | 0x20 | 0x40 | 0x80 | 0x100 | 0x200;
+        read_frags(0);
 #pragma unroll
-            for (int t = 9 - NT; t < 9; ++t)
+        for (int sub = 0; sub < 2; ++sub) {
 #pragma unroll
-                for (int i = 0; i < TM; ++i)
+            for (int m = 0; m < NMF; ++m) {
+                const int t = 9 - NT + m / (TM * TN), i = (m / TN) % TM, j = m % TN;
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[sub][j][PB9[t]], fa[sub][i][PA9[t]], acc[i][j], 0, 0, 0);
 #pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[j][PB9[t]], fa[i][PA9[t]], acc[i][j], 0, 0, 0);
-            // split half of the next stage's quads in the shadow of these MFMAs
-            if (s + 1 < nS) {
-#pragma unroll
-                for (int i = 0; i < NQ / 2; ++i) {
-                    const int qi = sub * (NQ / 2) + i;
-                    if ((s + 1) & 1) splitq(1, qi);
-                    else splitq(0, qi);
-                }
+                for (int k = 0; k < NSTEP; ++k)
+                    if (k * NMF / NSTEP == m) split_step(sub, k);
+                if (sub == 0 && m == NMF / 2) read_frags(1);
+                __builtin_amdgcn_sched_barrier(FENCE);
             }
         }
-        if (s + 1 < nS) {
-            writeA(cur ^ 1);                // readers of that buffer (stage s-1) passed the barrier above
-            if (s + 2 < nS) {
-                if (s & 1) loadA(s + 2, 1); else loadA(s + 2, 0);
-            }
-        }
+        writeA(PAR ^ 1);                    // readers of that buffer (stage s-1) passed the barrier above
+    };
+    for (int s = 0; s < nS; s += 2) {
+        stage(std::integral_constant<int, 0>{}, s);
+        if (s + 1 < nS) stage(std::integral_constant<int, 1>{}, s + 1);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // (the clamped weight DMA of the last stage still targets this workgroup's LDS)
 
     // ---- epilogue (lane = row, registers 4g..4g+3 = columns 8g + 4*half + {0..3})
 #pragma unroll
