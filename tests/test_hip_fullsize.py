@@ -3,7 +3,9 @@
 (tools/gen_goldens_fullsize.py -> tests/golden/full_*.npz; the reference `Unet3D` itself, not the oracle):
 
     T96 : T=96,  h=32                 + 2-step DDIM trajectory (injected noise, reference quantiles)
-    C2  : T=400, h=32 = BASELINE configs[1] (128x128, 400 frames): Fext > 288 -> the unfused 64-channel temporal path
+    C2  : T=400, h=32 = BASELINE configs[1] (128x128, 400 frames): more rows than one launch of the fused 64-channel temporal layer holds ->
+          balanced query segments (<= 120 queries + 2 x 40 window rows each) through the same fused kernel (temporal_layer13_kernel since round 6);
+          the deepest level has 4 x 4-pixel frames (6,400 rows): the 36-segment 3x3 instantiations and the split 1x1 GEMMs from 6,400 rows
     C3  : T=200, h=64 = BASELINE configs[2] (256x256, 200 frames): the benchmark shape with the benchmark kernels
 
 Weights / inputs are rebuilt from seeds (fixture checksums prove they are the same tensors).
