@@ -319,21 +319,32 @@ __global__ __launch_bounds__(512) void sla_c64_apply_kernel(const float* x /* ma
 // (22.5 k pipe cycles) instead of 512 fp32 ones (32.8 k).
 // Work split: `tiles_per_block` consecutive (frame, 32-pixel tile) units per block, grid = number of CUs: every CU gets the
 // same number of tiles (the (frame, half) grid of the fp32 kernel was 400 one-per-CU blocks on 256 CUs = 1.56 rounds).
+// OUTB (round 6): the out^T = M^T q^T product on the bf16 pipe too.  It was the larger half of the kernel's matrix time (32 fp32 MFMAs of 64 pipe
+// cycles per head against 24 bf16 ones of 32 for the projection: 2048 of 2816 cycles).  The frame's M is split into its three bf16 planes while it
+// is staged (once per 128 tiles), laid out as the A fragments of a 32x32x16 MFMA whose k index runs over the d rows the q accumulator holds in
+// registers 8j..8j+7 (k-step j; the k order is a free permutation): 24 MFMAs of 32 cycles per head.  LDS: the M planes take 96 KB, so only the
+// two upper planes of Wq stay in LDS (64 KB) and the third -- used by one cross term of six -- is fetched from global memory (32 KB for all heads:
+// L1 / L2 hits), a head ahead.  Exact as before: q (fp32) and M are split into three bf16 each without loss, six cross terms, fp32 accumulation.
 typedef dawn_bf16x8 bf16x8a;
 
+template <bool OUTB>
 __global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* x /* may alias `out` */, int HW, int F,
                                                                  const unsigned short* __restrict__ wqkv_s,
                                                                  const float* __restrict__ Mg, const float* __restrict__ bias,
                                                                  float eps, float* out, int tiles_per_block) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_b[];
-    unsigned char* Wq = smem_b;                                     // [kc 4][plane 3][k-half 2][256 features] x 16 B
-    float* Ms = reinterpret_cast<float*>(smem_b + 24 * 256 * 16);   // [64][64][4]  (h*8 + d/4, n)
+    constexpr int NPL = OUTB ? 2 : 3;                               // Wq planes kept in LDS
+    unsigned char* Wq = smem_b;                                     // [kc 4][plane NPL][k-half 2][256 features] x 16 B
+    float* Ms = reinterpret_cast<float*>(smem_b + 8 * NPL * 256 * 16);   // !OUTB: [64][64][4]  (h*8 + d/4, n)
+    unsigned char* Mp = smem_b + 8 * NPL * 256 * 16;                // OUTB: [h 8][j 2][plane 3][k-half 2][64 channels] x 16 B
     const int tid = threadIdx.x;
     const int wave = tid >> 6, lane = tid & 63;
     const int l31 = lane & 31, half = lane >> 5;
-    for (int i = tid; i < 24 * 256; i += 512) {
-        const int row = i >> 8, n = i & 255;
-        *reinterpret_cast<uint4*>(Wq + (size_t)i * 16) = *reinterpret_cast<const uint4*>(wqkv_s + ((size_t)row * QKVN + n) * 8);
+    for (int i = tid; i < 8 * NPL * 256; i += 512) {
+        const int row = i >> 8, n = i & 255;                        // row = (kc * NPL + pl) * 2 + half
+        const int kc = row / (2 * NPL), pl = (row >> 1) % NPL, hf = row & 1;
+        *reinterpret_cast<uint4*>(Wq + (size_t)i * 16) =
+            *reinterpret_cast<const uint4*>(wqkv_s + ((size_t)((kc * 3 + pl) * 2 + hf) * QKVN + n) * 8);
     }
     const int ntiles = (HW + 31) >> 5;
     const long total = (long)F * ntiles;
@@ -346,8 +357,25 @@ __global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* x 
         const int tB = (long)ntiles - tA < g1 - g ? ntiles : tA + (int)(g1 - g);
         __syncthreads();                                            // the previous frame's M is no longer read (and Wq is written)
         const float* mf = Mg + (long)f * (HEADS * 8 * C * 4);
-        for (int i = tid; i < 64 * 64; i += 512)
-            *reinterpret_cast<f32x4*>(Ms + i * 4) = *reinterpret_cast<const f32x4*>(mf + (size_t)i * 4);
+        if constexpr (OUTB) {
+            // unit (h, j, half, ch): the 8 k-values d = 16 j + 4 half + {0..3, 8..11} of channel ch -- the d rows registers 8j..8j+7 of the
+            // q accumulator hold in lanes of this half -- from the packed M ([h*8 + d/4][ch][d%4]), split into the three planes
+            for (int u = tid; u < HEADS * 2 * 2 * C; u += 512) {
+                const int ch = u & 63, hf = (u >> 6) & 1, j = (u >> 7) & 1, h = u >> 8;
+                const f32x4 a = *reinterpret_cast<const f32x4*>(mf + ((size_t)(h * 8 + 4 * j + hf) * C + ch) * 4);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(mf + ((size_t)(h * 8 + 4 * j + hf + 2) * C + ch) * 4);
+                const float m8[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+                bf16x8a p0, p1, p2;
+                dawn_split3_oct(m8, p0, p1, p2);
+                unsigned char* dst = Mp + ((size_t)(((h * 2 + j) * 3) * 2 + hf) * C + ch) * 16;
+                *reinterpret_cast<bf16x8a*>(dst) = p0;
+                *reinterpret_cast<bf16x8a*>(dst + 2 * C * 16) = p1;
+                *reinterpret_cast<bf16x8a*>(dst + 4 * C * 16) = p2;
+            }
+        } else {
+            for (int i = tid; i < 64 * 64; i += 512)
+                *reinterpret_cast<f32x4*>(Ms + i * 4) = *reinterpret_cast<const f32x4*>(mf + (size_t)i * 4);
+        }
         __syncthreads();
         // B operand of the transposed projection: lane = pixel, 8 consecutive channels 16 kc + 8 half + {0..7} per k-step; the
         // rows of the wave's next tile are requested before this tile's matrix work (latency hidden under ~20 k cycles)
@@ -396,17 +424,32 @@ __global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* x 
             f32x16 oT[2];
             oT[0] = z16();
             oT[1] = z16();
+            // (OUTB) the third Wq plane of a head straight from global memory, a head ahead
+            bf16x8a wg[4];
+            auto request_w = [&](int h) {
+#pragma unroll
+                for (int kc = 0; kc < 4; ++kc)
+                    wg[kc] = *reinterpret_cast<const bf16x8a*>(wqkv_s + ((size_t)((kc * 3 + 2) * 2 + half) * QKVN + h * DH + l31) * 8);
+            };
+            if constexpr (OUTB) request_w(0);
 #pragma unroll 1
             for (int h = 0; h < HEADS; ++h) {
                 // Q^T (32 d x 32 px): A = Wq_h plane fragments (LDS, lane = feature d), B = the pixel's split channels
                 f32x16 qT = z16();
                 constexpr int PW[6] = {2, 0, 1, 1, 0, 0}, PX[6] = {0, 2, 1, 0, 1, 0};   // smallest cross terms first
+                bf16x8a wc[4];
+                if constexpr (OUTB) {
+#pragma unroll
+                    for (int kc = 0; kc < 4; ++kc) wc[kc] = wg[kc];
+                    request_w(h + 1 < HEADS ? h + 1 : h);
+                }
 #pragma unroll
                 for (int kc = 0; kc < 4; ++kc) {
                     bf16x8a wa[3];
 #pragma unroll
-                    for (int pl = 0; pl < 3; ++pl)
-                        wa[pl] = *reinterpret_cast<const bf16x8a*>(Wq + ((size_t)(((kc * 3 + pl) * 2 + half) * 256 + h * DH + l31)) * 16);
+                    for (int pl = 0; pl < NPL; ++pl)
+                        wa[pl] = *reinterpret_cast<const bf16x8a*>(Wq + ((size_t)(((kc * NPL + pl) * 2 + half) * 256 + h * DH + l31)) * 16);
+                    if constexpr (OUTB) wa[2] = wc[kc];
 #pragma unroll
                     for (int u = 0; u < 6; ++u)
                         qT = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wa[PW[u]], xs[kc][PX[u]], qT, 0, 0, 0);
@@ -423,15 +466,36 @@ __global__ __launch_bounds__(512) void sla_c64_apply_bf16_kernel(const float* x 
                 }
                 l += __shfl_xor(l, 32, 64);
                 const float inv = scale * __builtin_amdgcn_rcpf(l);
+                if constexpr (OUTB) {
 #pragma unroll
-                for (int nt = 0; nt < 2; ++nt)
+                    for (int j = 0; j < 2; ++j) {
+                        float q8[8];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) {
-                        const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ms + ((h * 8 + 2 * c + half) * C + 32 * nt + l31) * 4);
+                        for (int i = 0; i < 8; ++i) q8[i] = qT[8 * j + i] * inv;
+                        bf16x8a qb[3];
+                        dawn_split3_oct(q8, qb[0], qb[1], qb[2]);
 #pragma unroll
-                        for (int s2 = 0; s2 < 4; ++s2)
-                            oT[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s2], qT[4 * c + s2] * inv, oT[nt], 0, 0, 0);
+                        for (int nt = 0; nt < 2; ++nt) {
+                            bf16x8a ma[3];
+#pragma unroll
+                            for (int pl = 0; pl < 3; ++pl)
+                                ma[pl] = *reinterpret_cast<const bf16x8a*>(Mp + ((size_t)((((h * 2 + j) * 3 + pl) * 2 + half) * C + 32 * nt + l31)) * 16);
+#pragma unroll
+                            for (int u = 0; u < 6; ++u)
+                                oT[nt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ma[PW[u]], qb[PX[u]], oT[nt], 0, 0, 0);
+                        }
                     }
+                } else {
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const f32x4 a4 = *reinterpret_cast<const f32x4*>(Ms + ((h * 8 + 2 * c + half) * C + 32 * nt + l31) * 4);
+#pragma unroll
+                            for (int s2 = 0; s2 < 4; ++s2)
+                                oT[nt] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s2], qT[4 * c + s2] * inv, oT[nt], 0, 0, 0);
+                        }
+                }
             }
             if (n < HW) {
                 const float* xrow = x + ((long)f * HW + n) * C;
@@ -700,9 +764,15 @@ extern "C" int dawn_sla_layer_c64(const float* x, int F, int HW, const float* wq
         const long total = (long)F * ntiles;
         const int per = (int)((total + ncu - 1) / ncu);
         const int nblk = (int)((total + per - 1) / per);
-        const int lds = 24 * 256 * 16 + 64 * 64 * 4 * 4;    // 96 KB of Wq planes + 64 KB of M = 160 KB
-        (void)hipFuncSetAttribute((const void*)sla_c64_apply_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-        hipLaunchKernelGGL(sla_c64_apply_bf16_kernel, dim3(nblk), dim3(512), lds, s, x, HW, F, (const unsigned short*)wqkv_bf3,
+        // 96 KB of Wq planes + 64 KB of fp32 M, or (shipped) 64 KB of Wq planes + 96 KB of M planes: 160 KB either way
+#ifdef DAWN_SLA_OUT_FP32
+        constexpr bool OUTB = false;        // A/B build (tools/build_variant_lib.sh): the out product on the fp32 pipe as in rounds 2-5
+#else
+        constexpr bool OUTB = true;
+#endif
+        const int lds = 160 * 1024;
+        (void)hipFuncSetAttribute((const void*)sla_c64_apply_bf16_kernel<OUTB>, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        hipLaunchKernelGGL(sla_c64_apply_bf16_kernel<OUTB>, dim3(nblk), dim3(512), lds, s, x, HW, F, (const unsigned short*)wqkv_bf3,
                            M_ws, bias, eps, out, per);
     } else {
         const int nsplit = (ntiles >= 64) ? 2 : 1;
