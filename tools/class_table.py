@@ -4,7 +4,7 @@ class.   python tools/class_table.py <summary A.md> <evaluations A> <frames A> <
 import re, sys
 
 CLASSES = [("3x3 ResBlock convs (Winograd F(2x2), F(4x4), direct)", ("conv3x3_",)),
-           ("fused temporal layer, 64 channels", ("temporal_layer16_kernel", "temporal_layer_c64_bf16_kernel<4, 0, true, true", "temporal_layer_c64_kernel")),
+           ("fused temporal layer, 64 channels", ("temporal_layer13_kernel", "temporal_layer16_kernel", "temporal_layer_c64_bf16_kernel<4, 0, true, true", "temporal_layer_c64_kernel")),
            ("temporal attention core, C >= 128 (EXT form, fp32 form)", ("temporal_layer_c64_bf16_kernel", "temporal_attn_kernel")),
            ("1x1 projections / resampling convs (gemm1x1_*, conv_gemm_*)", ("gemm1x1_", "conv_gemm_")),
            ("spatial linear attention (64-channel fused + core)", ("sla_",)),
