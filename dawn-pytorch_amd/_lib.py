@@ -76,6 +76,7 @@ SIGNATURES = {
     "dawn_temporal_layer_c64": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f, c_f, _f, c_f, c_f],
     "dawn_temporal_layer_c64_ex": [c_f, _i, _i, _i, _i, _i, c_f, c_f, c_f, c_f, c_f, c_f, c_f, _f, c_f, _i, c_f],
     "dawn_tl16_schedule": [_i, _i, _i, _i, c_f, c_f],
+    "dawn_tl13_schedule": [_i, _i, _i, _i, c_f],
     "dawn_sla_context": [c_f, _i, _i, c_f, c_f],
     "dawn_sla_apply": [c_f, c_f, _i, _i, c_f, c_f],
     "dawn_sla_ws_floats": [_i, _i, _i],

@@ -1277,6 +1277,14 @@ static bool tl13_make_schedule(int Fext, int q0, int Fq, int win, tl13_sched& sc
     return true;
 }
 
+// The 13-wave kernel's work split for a binding / a CPU test (tests/test_tl16_schedule_cpu.py): 16 words, layout of tl13_sched.
+extern "C" int dawn_tl13_schedule(int Fext, int q0, int Fq, int win, unsigned* words16) {
+    tl13_sched sc;
+    if (!words16 || !tl13_make_schedule(Fext, q0, Fq, win, sc)) return 0;
+    for (int w = 0; w < 16; ++w) words16[w] = sc.w[w];
+    return 1;
+}
+
 bool dawn_temporal_layer13_try(const float* x, int Fext, int HW, int q0, int Fq, int win, const void* wqkv_bf3,
                                const void* wout_bf3p, const float* rot_cos, const float* rot_sin, const float* band, float eps,
                                float* out, hipStream_t s) {

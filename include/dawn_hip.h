@@ -229,6 +229,12 @@ int dawn_temporal_layer_c64_ex(const float* x, int Fext, int HW, int q0, int Fq,
  * MFMA count per SIMD and head of phase A (projections) and phase B (attention).  Returns 0 when the shape is outside the kernel. */
 typedef struct dawn_tl16_sched { unsigned w[12]; } dawn_tl16_sched;
 int dawn_tl16_schedule(int Fext, int q0, int Fq, int win, dawn_tl16_sched* sched, int* simd_units);
+/* The work split of the 13-wave form (WMODE 5; host code, no GPU): 16 words, one per wave slot (13 used) -- bits 0..4 the wave's ONE query
+ * tile (31 = none), 5..7 its K / V projection group (as above; 7 = none), 8..12 / 13..17 the group's 16-row tiles [t0, t1).  Wave w runs on
+ * SIMD w & 3 (SIMD 0 holds four waves, the others three): the tiles are dealt so that the per-SIMD sums of the tile costs balance, the row
+ * tiles of a group evenly over the waves of its SIMD.  Returns 0 when the shape is outside the kernel (more than 13 query tiles, win > 40,
+ * more than 208 rows). */
+int dawn_tl13_schedule(int Fext, int q0, int Fq, int win, unsigned* words16);
 
 /* ---- A8 SpatialLinearAttention core (MT:611-627) ---------------------------------------------- */
 int dawn_sla_context(const float* qkv, int F, int HW, float* ctx, void* stream);     /* ctx (F,8,32,32) */

@@ -78,3 +78,60 @@ def test_schedule_is_balanced_at_the_benchmark_shape():
 @pytest.mark.parametrize("Fext,q0,Fq,win", [(209, 0, 200, 40), (200, 0, 200, 41), (150, 0, 150, 48), (100, 90, 20, 40), (0, 0, 0, 40)])
 def test_schedule_refuses_shapes_outside_the_kernel(Fext, q0, Fq, win):
     assert schedule(Fext, q0, Fq, win)[0] == 0
+
+
+# ---- the 13-wave form (WMODE 5, temporal_layer13_kernel): one query tile per wave, wave w on SIMD w & 3 ------------------------------
+
+def schedule13(Fext, q0, Fq, win):
+    L = _lib.lib()
+    f = L.dawn_tl13_schedule
+    f.argtypes = [ctypes.c_int] * 4 + [ctypes.c_void_p]
+    f.restype = ctypes.c_int
+    w = (ctypes.c_uint * 16)()
+    ok = f(Fext, q0, Fq, win, ctypes.byref(w))
+    return ok, [(x & 31, (x >> 5) & 7, (x >> 8) & 31, (x >> 13) & 31) for x in w]
+
+
+def tile_cost13(Fext, q0, win, t):
+    return tile_cost(Fext, q0, win, t) + 24          # + the Q projection of the tile (the wave's own)
+
+
+SHAPES13 = [s for s in SHAPES if (s[2] + (s[1] - s[3]) % 16 + 15) // 16 <= 13]
+
+
+@pytest.mark.parametrize("Fext,q0,Fq,win", SHAPES13)
+def test_schedule13_partitions_the_work(Fext, q0, Fq, win):
+    ok, waves = schedule13(Fext, q0, Fq, win)
+    assert ok == 1
+    delta = (q0 - win) % 16
+    nqt, nblk = (Fq + delta + 15) // 16, (Fext + 15) // 16
+    assert sorted(t for (t, _, _, _) in waves if t != 31) == list(range(nqt))          # every query tile exactly once
+    assert all(w == (31, 7, 0, 0) for w in waves[13:])                                  # 13 waves run
+    for combo in range(4):                                                              # every row tile of every (K | V, half) exactly once
+        rows = sorted(r for (_, c, t0, t1) in waves[:13] if c == combo for r in range(t0, t1))
+        assert rows == list(range(nblk)), (combo, rows)
+    for w, (_, c, t0, t1) in enumerate(waves[:13]):
+        assert (c == 7 and t0 == t1) or c == (w & 3)                                    # a SIMD's waves project ONE combination
+    # SIMD 0 holds 4 waves, the others 3
+    assert sum(t != 31 for (t, _, _, _) in waves[0:13:4]) <= 4
+    for s in (1, 2, 3):
+        assert sum(t != 31 for (t, _, _, _) in waves[s:13:4]) <= 3
+
+
+def test_schedule13_balances_the_benchmark_clip():
+    """200 frames, window 40: thirteen tiles of 90 / 96 / 114 / 8 x 120 / 114 / 96 MFMA units (S + P.V + out-projection + the tile's Q
+    projection) on SIMDs that hold 4 / 3 / 3 / 3 waves.  The best any assignment can do is the four CHEAPEST tiles on SIMD 0 (396 units
+    against 354..360 on the others: a 4-tile SIMD cannot go below 90 + 96 + 96 + 114); the schedule must find exactly that."""
+    ok, waves = schedule13(200, 0, 200, 40)
+    assert ok == 1
+    cost = [tile_cost13(200, 0, 40, t) for t in range(13)]
+    assert cost == [90, 96, 114] + [120] * 8 + [114, 96]
+    load = [sum(cost[t] for (t, _, _, _) in waves[s:13:4] if t != 31) for s in range(4)]
+    assert load[0] == 396 and sorted(load[1:]) == [354, 360, 360], load
+    assert sorted(t for (t, _, _, _) in waves[0:13:4]) in ([0, 1, 2, 12], [0, 1, 11, 12])
+
+
+@pytest.mark.parametrize("Fext,q0,Fq,win", [(300, 0, 300, 40), (209, 0, 209, 40), (208, 1, 208, 40), (200, 0, 200, 41), (224, 0, 224, 8), (0, 0, 0, 40), (50, 10, 50, 4)])
+def test_schedule13_refuses_shapes_outside_the_kernel(Fext, q0, Fq, win):
+    ok, _ = schedule13(Fext, q0, Fq, win)
+    assert ok == 0
