@@ -52,6 +52,7 @@ class ConvDesc(C.Structure):
 # name -> argtypes (every function returns int; `stream` is the trailing void*)
 SIGNATURES = {
     "dawn_conv_gemm": [C.POINTER(ConvDesc), c_f],
+    "dawn_conv3x3_form": [C.POINTER(ConvDesc)],
     "dawn_conv_gemm_nblocks": [_l, _i],
     "dawn_conv3x3_wino_ok": [_i, _i, _i, _i, _i, _i],
     "dawn_conv3x3_wino4_ok": [_i, _i, _i, _i, _i, _i],

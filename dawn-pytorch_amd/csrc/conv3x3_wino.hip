@@ -646,7 +646,7 @@ extern "C" int dawn_conv3x3_wino_ok(int F, int H, int W, int C0, int C1, int N) 
 }
 
 // host-side geometry test + launch; 0 = the shape does not fit (the caller falls back to the direct split kernel)
-int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows) {
+int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows, int dry /* 1: decide only, launch nothing */) {
     (void)M;
     if ((policy & 0x4000000) && d.C0 + d.C1 < 128) return 0;      // per-shape policy bit: short-K convs on the direct kernel
     if (!d.w_wino || d.tr || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.mode != 0) return 0;
@@ -655,6 +655,7 @@ int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream
     if (!wino_geometry(d.F, d.Hi, d.Wi, d.C0, d.C1, d.N, g)) return 0;
     // one DMA offset table serves both sources; a tile's descriptor (its frame(s)) stays below the table's "outside the patch" mark
     if ((d.in1 && d.ld1 != d.ld0) || (long)g.nf * d.Hi * d.Wi * d.ld0 * 4 >= (1L << 30)) return 0;
+    if (dry) return 1;
     const int ntiles = g.ntiles, TR = g.TR, nf = g.nf, PI = g.PI, RAWB = g.RAWB;
     const size_t lds = g.lds;
     const int grid = ntiles < wino_ncu() ? ntiles : wino_ncu();

@@ -600,7 +600,7 @@ static bool wino4_geometry(int F, int H, int W, int C0, int C1, int N) {
 extern "C" int dawn_conv3x3_wino4_ok(int F, int H, int W, int C0, int C1, int N) { return wino4_geometry(F, H, W, C0, C1, N) ? 1 : 0; }
 
 // host-side geometry test + launch; 0 = the shape does not fit (the caller falls back to the F(2x2) / direct kernels)
-int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows) {
+int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows, int dry /* 1: decide only, launch nothing */) {
     // per-shape choice (measured in situ, profiles/r5_insitu_shapes_wino4_everywhere_vs_gated.txt): the F(4x4) form is bound by its weight
     // stream (221 KB of fragments per 16-channel chunk and workgroup) and beats F(2x2) where a tile has few chunks and the epilogue weighs
     // most -- 64 input channels at the 64-pixel-wide latent (-9 %), up to 128 at the 32-pixel-wide one (-3.5..-7 %); slower at 128 / 256 input
@@ -610,6 +610,7 @@ int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStrea
     if (!d.w_wino4 || d.tr || d.KH != 3 || d.KW != 3 || d.stride != 1 || d.pad != 1 || d.mode != 0) return 0;
     if ((d.ld0 & 3) || (d.in1 && (d.ld1 & 3)) || (d.ld_out & 3) || (d.res && (d.ld_res & 3))) return 0;
     if (!wino4_geometry(d.F, d.Hi, d.Wi, d.C0, d.C1, d.N)) return 0;
+    if (dry) return 1;
     const int ntiles = (int)(M / 256) * (d.N / 64);
     const int grid = ntiles < wino4_ncu() ? ntiles : wino4_ncu();
     // start stagger: 4 units by default where a workgroup walks >= 4 tiles (-5 % at the shipped shape, profiles/r5_wino4_stagger.txt);

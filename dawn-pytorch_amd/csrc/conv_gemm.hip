@@ -2670,8 +2670,8 @@ void launch(const dawn_conv_desc& d, long M, hipStream_t s) {
 #ifdef DAWN_WITH_STREAMK
 int dawn_conv3x3_sk_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows);   // tools/ubench/conv3x3_sk.hip (experimental build)
 #endif
-int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows); // conv3x3_wino.hip
-int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows); // conv3x3_wino4.hip
+int dawn_conv3x3_wino_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows, int dry); // conv3x3_wino.hip
+int dawn_conv3x3_wino4_try(const dawn_conv_desc& d, long M, int policy, hipStream_t s, int* nrows, int dry); // conv3x3_wino4.hip
 
 #ifdef DAWN_ABLATION
 extern "C" int dawn_conv_set_debug(void* p) {
@@ -2695,6 +2695,25 @@ extern "C" int dawn_conv_gemm_nblocks(long M, int N) {
     if (N <= 64) return std::max(sk, dawn_cdiv(M, 128));   // upper bound (the 256-row tile variants launch fewer blocks; the
                                              // caller zero-fills the buffer)
     return std::max(sk, dawn_cdiv(M, 128) * dawn_cdiv(N, 128));
+}
+
+// the split-operand 3x3 family serves this descriptor (the condition dawn_conv_gemm dispatches on)
+static bool conv3x3_split_path(const dawn_conv_desc& d) {
+    return (policy_of(d) & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 && d.Ho == d.Hi &&
+           d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean;
+}
+
+/* Which form of the 3x3 conv dawn_conv_gemm would run for this descriptor (host code, launches nothing): 2 = Winograd F(4x4,3x3),
+ * 1 = Winograd F(2x2,3x3), 0 = anything else (direct split kernel, fp32 kernels, not a 3x3 conv).  The SAME decision code as the
+ * launch -- for profiling labels and tests, instead of mirroring the policy bits and per-shape gates in the caller. */
+extern "C" int dawn_conv3x3_form(const dawn_conv_desc* dp) {
+    if (!dp) return 0;
+    const dawn_conv_desc& d = *dp;
+    if (!conv3x3_split_path(d) || (policy_of(d) & 0x2000)) return 0;
+    const long M = (long)d.F * d.Ho * d.Wo;
+    if ((policy_of(d) & 0x8000000) && d.w_wino4 && dawn_conv3x3_wino4_try(d, M, policy_of(d), nullptr, nullptr, 1)) return 2;
+    if ((policy_of(d) & 0x2000000) && d.w_wino && dawn_conv3x3_wino_try(d, M, policy_of(d), nullptr, nullptr, 1)) return 1;
+    return 0;
 }
 
 extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
@@ -2730,13 +2749,12 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         DAWN_LAUNCH_CHECK();
         return 0;
     }
-    if ((policy_of(d) & 0x1000) && d.w_bf3 && d.mode == 0 && d.KH == 3 && d.KW == 3 && d.stride == 1 && d.pad == 1 &&
-        d.Ho == d.Hi && d.Wo == d.Wi && !d.ch_a && !d.pro_act && !d.pro_add && !d.row_mean) {
+    if (conv3x3_split_path(d)) {
         const bool nine = (policy_of(d) & 0x2000) != 0;
         bool ok = false;
         if ((policy_of(d) & 0x8000000) && !nine && d.w_wino4) {  // Winograd F(4x4,3x3) form (conv3x3_wino4.hip; opt-in)
             int rows = 0;
-            if (dawn_conv3x3_wino4_try(d, M, policy_of(d), s, &rows)) {
+            if (dawn_conv3x3_wino4_try(d, M, policy_of(d), s, &rows, 0)) {
                 if (d.gn_rows) *d.gn_rows = rows;
                 DAWN_LAUNCH_CHECK();
                 return 0;
@@ -2744,7 +2762,7 @@ extern "C" int dawn_conv_gemm(const dawn_conv_desc* dp, void* stream) {
         }
         if ((policy_of(d) & 0x2000000) && !nine && d.w_wino) {   // Winograd F(2x2,3x3) form (conv3x3_wino.hip)
             int rows = 0;
-            if (dawn_conv3x3_wino_try(d, M, policy_of(d), s, &rows)) {
+            if (dawn_conv3x3_wino_try(d, M, policy_of(d), s, &rows, 0)) {
                 if (d.gn_rows) *d.gn_rows = rows;
                 DAWN_LAUNCH_CHECK();
                 return 0;

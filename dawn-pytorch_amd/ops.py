@@ -200,8 +200,7 @@ class HipOps:
                               f"pro={'r' if row_stats else ('n' if ln_eps else '')}{'c' if ch_ab else ''}{'a' if pro_add is not None else ''}"
                               + (" split-bf16" if self._runs_split_kernel(w_bf3, KH, KW, stride, mode, rows_out, N, d.C0, d.C1, tr,
                                                                           gn_part) else "")
-                              + (" winograd4" if self._runs_winograd4(w_wino4, KH, KW, stride, mode, F, Hi, Wi, N, d.C0, d.C1, tr)
-                                 else (" winograd" if self._runs_winograd(w_wino, KH, KW, stride, mode, F, Hi, Wi, N, d.C0, d.C1, tr) else "")),
+                              + ("", " winograd", " winograd4")[self.conv3x3_form(d)],
                               4.0 * (F * Hi * Wi * (d.C0 + d.C1) + rows_out * N + KH * KW * (d.C0 + d.C1) * N * (4 if mode else 1))))
             return out
         check(self.L.dawn_conv_gemm(C.byref(d), self._stream()), "dawn_conv_gemm")
@@ -223,23 +222,10 @@ class HipOps:
             return True
         return KH == 1 and KW == 1 and gn_part is None and self.split_gemm_ok(rows, N, C0, C1)
 
-    def _runs_winograd4(self, w_wino4, KH, KW, stride, mode, F, H, W, N, C0, C1, tr) -> bool:
-        """Profiling label only: does this 3x3 launch take the Winograd F(4x4,3x3) form (the library's predicate + its per-shape policy)?"""
-        pol = self.conv_policy or 0x2B00580D
-        if w_wino4 is None or tr is not None or not (pol & 0x8000000) or not (pol & 0x1000) or (pol & 0x2000):
-            return False
-        if not (pol & 0x10000000) and not ((W == 64 and C0 + C1 == 64) or (W == 32 and C0 + C1 <= 128)):
-            return False
-        return KH == 3 and KW == 3 and stride == 1 and mode == 0 and bool(self.L.dawn_conv3x3_wino4_ok(F, H, W, C0, C1, N))
-
-    def _runs_winograd(self, w_wino, KH, KW, stride, mode, F, H, W, N, C0, C1, tr) -> bool:
-        """Profiling label only: does this 3x3 launch take the Winograd form (the library's own predicate + the policy bit)?"""
-        pol = self.conv_policy or 0x2B00580D
-        if w_wino is None or tr is not None or not (pol & 0x2000000) or not (pol & 0x1000) or (pol & 0x2000):
-            return False
-        if (pol & 0x4000000) and C0 + C1 < 128:
-            return False
-        return KH == 3 and KW == 3 and stride == 1 and mode == 0 and bool(self.L.dawn_conv3x3_wino_ok(F, H, W, C0, C1, N))
+    def conv3x3_form(self, d) -> int:
+        """Which form dawn_conv_gemm runs this descriptor in: 2 = Winograd F(4x4,3x3), 1 = Winograd F(2x2,3x3), 0 = anything else.  The library's
+        own launch decision (dawn_conv3x3_form: policy bits, per-shape gates, stride / alignment fallbacks), not a mirror of it."""
+        return int(self.L.dawn_conv3x3_form(C.byref(d)))
 
     def ln_inline_ok(self, rows: int, N: int, C0: int, C1: int = 0) -> bool:
         """May the projection compute the LayerNorm of its input rows itself (conv_gemm(ln_eps=...): the row-stationary

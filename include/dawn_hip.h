@@ -102,6 +102,9 @@ int dawn_conv3x3_wino_ok(int F, int H, int W, int C0, int C1, int N);
 /* the same question for the F(4x4,3x3) form (dawn_conv_desc.w_wino4, policy bit 0x8000000): image width 64 or 32, H a multiple of
  * 256 / W, an even number of 16-channel chunks, N a multiple of 64 */
 int dawn_conv3x3_wino4_ok(int F, int H, int W, int C0, int C1, int N);
+/* Which form of the 3x3 conv dawn_conv_gemm would run for this descriptor (host code, launches nothing; the launch's own decision
+ * code): 2 = Winograd F(4x4,3x3), 1 = Winograd F(2x2,3x3), 0 = anything else. */
+int dawn_conv3x3_form(const dawn_conv_desc* d);
 /* upper bound on the thread blocks (= rows of gn_part) dawn_conv_gemm launches for an (M rows, N columns) output;
  * the launch reports the exact count through dawn_conv_desc.gn_rows */
 int dawn_conv_gemm_nblocks(long M, int N);
