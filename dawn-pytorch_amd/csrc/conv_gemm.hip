@@ -1689,7 +1689,10 @@ __global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(cons
     constexpr int NQ = BM * 8 / NTHR;                          // A quads per thread per stage (4 or 8)
     static_assert(NQ == 4 || NQ == 8, "the stage wait below names NQ as an immediate");
     constexpr int HPS = BM * 16 + 128;                         // half-plane stride (bytes)
-    constexpr int PSZ = 2 * 6 * HPS;                           // planes of one stage (2 sub-chunks of 16 channels)
+    // a sub-chunk's six half planes + 64 bytes: a wave's plane write covers 8 rows x (2 sub-chunks x 2 k-halves x 8 + 8 bytes); with the k-halves
+    // 128 B apart modulo the 256 B of the banks (HPS) and the sub-chunks 64 B apart (SPS) the 32 lanes of a write pass hit 64 different banks
+    constexpr int SPS = 6 * HPS + 64;
+    constexpr int PSZ = 2 * SPS;                               // planes of one stage (2 sub-chunks of 16 channels)
     constexpr int BSZ = 2 * 6 * BN * 16;                       // weights of one stage
     constexpr int NBI = BSZ / 1024;                            // DMA wave-instructions per stage: 3 per wave
     static_assert(NBI == 3 * NW, "weight DMA split");
@@ -1768,7 +1771,7 @@ __global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(cons
         for (int i = 0; i < NQ; ++i) {
             const int q = tid + NTHR * i;
             const int row = q >> 3, quad = q & 7;               // quad: sub-chunk = quad >> 2, k-half = (quad >> 1) & 1
-            unsigned char* dst = planes + (size_t)buf * PSZ + (size_t)(quad >> 2) * 6 * HPS + (size_t)((quad >> 1) & 1) * HPS +
+            unsigned char* dst = planes + (size_t)buf * PSZ + (size_t)(quad >> 2) * SPS + (size_t)((quad >> 1) & 1) * HPS +
                                  row * 16 + (quad & 1) * 8;
             *reinterpret_cast<uint2*>(dst) = ap[i][0];
             *reinterpret_cast<uint2*>(dst + 2 * HPS) = ap[i][1];
@@ -1824,7 +1827,7 @@ __global__ __launch_bounds__(256 * (CFG ? 1 : WN)) void gemm1x1_bf16_kernel(cons
             for (int g = 0; g < 3; ++g) {
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
-                    fa[sub][i][RA[g]] = *reinterpret_cast<const bf16x8*>(Pb + (size_t)sub * 6 * HPS + (size_t)(RA[g] * 2 + half) * HPS +
+                    fa[sub][i][RA[g]] = *reinterpret_cast<const bf16x8*>(Pb + (size_t)sub * SPS + (size_t)(RA[g] * 2 + half) * HPS +
                                                                           (wm * 64 + i * 32 + l31) * 16);
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
@@ -2515,7 +2518,7 @@ bool try_launch_gemm1x1_rowreg(const dawn_conv_desc& d, long M, hipStream_t s) {
 template <int WN>
 void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
     constexpr int BN = 64 * WN;
-    const size_t lds = (size_t)2 * 2 * 6 * (256 * 16 + 128) + (size_t)2 * 2 * 6 * BN * 16;
+    const size_t lds = (size_t)2 * 2 * (6 * (256 * 16 + 128) + 64) + (size_t)2 * 2 * 6 * BN * 16;
     const int nwg = (int)(M / 256) * (d.N / BN);
     if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     if (policy_of(d) & 0x2000) {
@@ -2528,7 +2531,7 @@ void launch_gemm1x1_bf16(const dawn_conv_desc& d, long M, hipStream_t s) {
 }
 
 void launch_gemm1x1_bf16_small(const dawn_conv_desc& d, long M, hipStream_t s) {
-    const size_t lds = (size_t)2 * 2 * 6 * (128 * 16 + 128) + (size_t)2 * 2 * 6 * 64 * 16;      // 76.8 KB: two per CU
+    const size_t lds = (size_t)2 * 2 * (6 * (128 * 16 + 128) + 64) + (size_t)2 * 2 * 6 * 64 * 16;      // 77 KB: two per CU
     const int nwg = (int)(M / 128) * (d.N / 64);
     if (d.gn_rows) *d.gn_rows = nwg;   // rows of gn_part this launch writes
     (void)hipFuncSetAttribute((const void*)gemm1x1_bf16_kernel<6, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
