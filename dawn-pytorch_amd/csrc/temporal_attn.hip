@@ -189,10 +189,26 @@ __global__ __launch_bounds__(256) void temporal_attn_kernel(const float* __restr
 bool dawn_temporal_attn_bf16_try(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos,
                                  const float* rot_sin, const float* band, float* out, bool force, hipStream_t s);
 
+// (temporal_layer16.hip) the same in the window-tiled 13-wave form (16-query tiles against the key blocks of their window); false = not covered
+bool dawn_temporal_attn13_try(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos, const float* rot_sin,
+                              const float* band, float* out, hipStream_t s);
+
 extern "C" int dawn_temporal_attn_ex(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos,
                                      const float* rot_sin, const float* band, float* out, int flags, void* stream) {
     if (Fq <= 0) return 0;
     if (q0 < 0 || q0 + Fq > Fext || win < 0) return dawn_set_error_msg(-30, "dawn_temporal_attn: bad frame range");
+    // round 6: the window-tiled 13-wave kernel (temporal_attn13_kernel), OPT-IN through flags bit 2 (error if the shape is outside: win <= 40,
+    // <= 208 buffer rows, <= 13 query tiles).  Measured and not made the automatic choice: isolated it takes 4..9 % off the 32 x 32 kernel
+    // (371..392 vs 409 us at 1024 pixel columns, 79 vs 86 at 256), inside the benchmark it is 0.3 % SLOWER end to end (174.9 / 176.0 / 176.0 vs
+    // 175.5 / 176.2 / 176.8 frames/s alternating on one box, profiles/r6_temporal_attn13_ab.txt): at these levels the core is bound by how it
+    // reads the (rows, 768) tensor -- 128-byte pieces 3 KB apart -- not by its arithmetic
+    if (flags & 4) {
+        if (dawn_temporal_attn13_try(qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, (hipStream_t)stream)) {
+            DAWN_LAUNCH_CHECK();
+            return 0;
+        }
+        return dawn_set_error_msg(-39, "dawn_temporal_attn: the 13-wave kernel does not cover this shape (win <= 40, Fext <= 208, <= 13 query tiles)");
+    }
     // flags bit 0: the fp32-MFMA kernel below even where the split-operand kernel covers the shape; bit 1: the split-operand kernel
     // also on grids too small for it to pay (tests, A/B)
     if (!(flags & 1) &&

@@ -1036,6 +1036,275 @@ __global__ __launch_bounds__(NT13) void temporal_layer13_kernel(
 #endif
 }
 
+
+// =====================================================================================================================================
+// THE ATTENTION CORE ALONE in the 13-wave form (round 6): dawn_temporal_attn for the levels whose to_qkv / to_out projections are separate
+// GEMMs (C >= 128).  Phase B (S, softmax, P.V per wave and query tile) is the fused kernel's, word for word; phase A reads the projected q / k / v
+// rows of the pixel column from the (Fext*HW, 768) tensor instead of projecting them: K and V in 4 x nblk (combination, 16-row tile) units, four
+// per wave (no weights in registers tie a combination to a SIMD here), requested a head ahead at the start of phase B and held in 16 registers --
+// the out-projection accumulators and the Wq fragments of the fused kernel are not there to need them.  The rotary tables of the buffer rows sit in
+// LDS (no X planes: 26 KB of the 80 KB they leave).  V features in natural order (lane n of a half = feature 16 mb + n): a lane of the P.V result
+// then holds 4 consecutive features of its query and stores them as 16 bytes.
+constexpr int ROT_BYTES = FA * 128;            // [row][cos 16 | sin 16] floats
+constexpr int LDS_ATTN13 = KP_BYTES + VP_BYTES + BAND_BYTES + ROT_BYTES;
+
+__global__ __launch_bounds__(NT13) void temporal_attn13_kernel(
+    const float* __restrict__ qkv, int Fext, int HW, int q0, int Fq, int win, const float* __restrict__ rcos,
+    const float* __restrict__ rsin, const float* __restrict__ band, float* __restrict__ out, int delta, const tl13_sched sched) {
+#if __HIP_DEVICE_COMPILE__
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem16[];
+    unsigned char* Kp = smem16;
+    unsigned char* Vp = Kp + KP_BYTES;
+    float* band4 = reinterpret_cast<float*>(Vp + VP_BYTES);
+    float* rot = reinterpret_cast<float*>(Vp + VP_BYTES + BAND_BYTES);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n = lane & 15, g = lane >> 4;
+    const long p = blockIdx.x;
+#define REGION() __builtin_amdgcn_sched_barrier(0)
+
+    for (int i = tid; i < FA * 16; i += NT13) {                  // (rows past the buffer: zeros -- their K rows are zeros too)
+        const int r = i >> 4, a = i & 15;
+        rot[r * 32 + a] = i < Fext * 16 ? rcos[i] : 0.f;
+        rot[r * 32 + 16 + a] = i < Fext * 16 ? rsin[i] : 0.f;
+    }
+
+    const unsigned winfo = sched.w[wv];
+    const int qt = (int)(winfo & 31u);
+    const int nblk = (Fext + 15) >> 4;
+    const int nkb = (16 + 2 * win + 15) >> 4;
+    const bool has_q = qt != 31;
+    const int i0 = q0 - delta + 16 * qt;
+    const int iq = i0 + n;
+    const int iqc = max(0, min(iq, Fext - 1));
+
+    // this wave's K / V units: u = 4 wv + i -> combination u / nblk (0, 1: K feature halves; 2, 3: V), row tile u % nblk
+    int urt[4], ukmb[4];
+    bool uV[4], uok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int u = 4 * wv + i;
+        uok[i] = u < 4 * nblk;
+        const int uc = uok[i] ? u : 4 * nblk - 1;
+        const int c = uc / nblk;
+        urt[i] = uc - c * nblk;
+        uV[i] = c >= 2;
+        ukmb[i] = c & 1;
+    }
+    // rows past the buffer (the tail of the last 16-row tile) are out of the descriptor's range: the hardware returns zeros -- the K / V of the
+    // fused kernel's zero rows.  One vector offset per role; the row tile, the head and the feature half travel in the scalar offset.
+    const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, Fext * HW * 3072, 0x00020000);
+    const unsigned rowb = (unsigned)HW * 3072u;
+    const unsigned pcol = (unsigned)(p * 3072);
+    const unsigned vo_q = (unsigned)iqc * rowb + pcol + (unsigned)(16 * g);
+    const unsigned vo_k = (unsigned)n * rowb + pcol + (unsigned)(16 * g);
+    const unsigned vo_v = (unsigned)(4 * g) * rowb + pcol + (unsigned)(4 * n);
+    f32x4 kvraw[4], qraw[2];
+    float bandv;
+    const int bidx = (tid & 127) + (tid >> 7) - 15;
+    const bool bok = bidx >= 0 && bidx <= 2 * win;
+    auto request_next = [&](int hh) {
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+            qraw[mb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, vo_q, (32 * hh + 16 * mb) * 4, 0));
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int so = (int)((unsigned)(16 * urt[i]) * rowb) + ((uV[i] ? 512 : 256) + 32 * hh + 16 * ukmb[i]) * 4;      // (scalar)
+            if (uV[i]) {                                             // (wave-uniform)
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    kvraw[i][r] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsq, vo_v, so + (int)((unsigned)r * rowb), 0));
+            } else
+                kvraw[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, vo_k, so, 0));
+        }
+        bandv = band[max(0, min(bidx, 2 * win)) * HEADS + hh];
+    };
+    request_next(0);
+    bf16x8t qp[3];
+    REGION();
+    __syncthreads();
+
+    for (int h = 0; h < HEADS; ++h) {
+        // ---- phase A: the head's bias table, the wave's query tile, its four K / V units (all from registers requested a head ago)
+        if (tid < 512) band4[(tid >> 7) * BLD + (tid & 127)] = bok ? bandv * LOG2E : NEG;
+        {
+            const float sl = 0.17677669529663687f * LOG2E;
+            const float* rr = rot + iqc * 32 + 2 * g;
+            float qr[8];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) {
+                const float2 cs0 = *reinterpret_cast<const float2*>(rr + 8 * mb), sn0 = *reinterpret_cast<const float2*>(rr + 16 + 8 * mb);
+                const float2 cs = {cs0.x * sl, cs0.y * sl}, sn = {sn0.x * sl, sn0.y * sl};
+                const f32x4 d = qraw[mb];
+                qr[4 * mb + 0] = d[0] * cs.x - d[1] * sn.x; qr[4 * mb + 1] = d[1] * cs.x + d[0] * sn.x;
+                qr[4 * mb + 2] = d[2] * cs.y - d[3] * sn.y; qr[4 * mb + 3] = d[3] * cs.y + d[2] * sn.y;
+            }
+            dawn_split3_oct(qr, qp[0], qp[1], qp[2]);
+            asm volatile("" :: "v"(qp[0]), "v"(qp[1]), "v"(qp[2]));
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            uint2 p1, p2, p3;
+            if (uV[i]) {
+                split3_quad(kvraw[i], p1, p2, p3);
+                if (uok[i]) {
+                    unsigned char* dst = Vp + ((size_t)(ukmb[i] * 64 + lane) * NB + urt[i]) * 8;
+                    *reinterpret_cast<uint2*>(dst) = p1;
+                    *reinterpret_cast<uint2*>(dst + (size_t)NB * 2 * 512) = p2;
+                    *reinterpret_cast<uint2*>(dst + (size_t)2 * NB * 2 * 512) = p3;
+                }
+            } else {
+                const int row = 16 * urt[i] + n;
+                const float* rr = rot + row * 32 + 8 * ukmb[i] + 2 * g;
+                const float2 cs = *reinterpret_cast<const float2*>(rr), sn = *reinterpret_cast<const float2*>(rr + 16);
+                const f32x4 d = kvraw[i];
+                const f32x4 kr = {d[0] * cs.x - d[1] * sn.x, d[1] * cs.x + d[0] * sn.x, d[2] * cs.y - d[3] * sn.y, d[3] * cs.y + d[2] * sn.y};
+                split3_quad(kr, p1, p2, p3);
+                if (uok[i]) {
+                    unsigned char* dst = Kp + ((size_t)g * FA + row) * 16 + ukmb[i] * 8;
+                    *reinterpret_cast<uint2*>(dst) = p1;
+                    *reinterpret_cast<uint2*>(dst + (size_t)4 * FA * 16) = p2;
+                    *reinterpret_cast<uint2*>(dst + (size_t)8 * FA * 16) = p3;
+                }
+            }
+        }
+        REGION();
+        __syncthreads();
+        // the next head's rows: in flight during this head's attention
+        request_next(h + 1 < HEADS ? h + 1 : h);
+        REGION();
+
+        // ---- phase B: the own tile (the fused kernel's)
+        if (has_q) {
+            const int B0 = (i0 - win) >> 4;
+            const int blo = max(0, -B0), bhi = min(nkb, nblk - B0);
+            const int Bf = B0 + blo;
+            const int sh = (15 - n) & 3;
+            const float* bb = band4 + sh * BLD + ((15 - n) - sh) + 4 * g + 16 * blo;
+            const unsigned char* kbase = Kp + ((size_t)g * FA + 16 * Bf + n) * 16;
+            const unsigned char* vbase = Vp + ((size_t)lane * NB + Bf) * 8;
+            const int klast = Fext - 16 * (Bf + (bhi - blo) - 1) - 4 * g;
+            f32x4 o[2] = {zero4(), zero4()};
+            float l = 0.f;
+            auto body = [&](auto nv_) {
+                constexpr int NV = decltype(nv_)::value;
+                constexpr int NP = (NV + 1) / 2;
+                constexpr int H1 = (NV + 1) / 2;                                   // slots of the first S half
+                f32x4 st[NV];
+                REGION();
+                {
+                    bf16x8t kf[H1][3];
+#pragma unroll
+                    for (int j = 0; j < NV; ++j) st[j] = *reinterpret_cast<const f32x4*>(bb + 16 * j);
+#pragma unroll
+                    for (int j = 0; j < H1; ++j)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            kf[j][pl] = *reinterpret_cast<const bf16x8t*>(kbase + (size_t)j * 256 + (size_t)pl * 4 * FA * 16);
+                    REGION();
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int j = 0; j < H1; ++j) st[j] = mfma16(kf[j][PA6[u]], qp[PB6[u]], st[j]);
+                }
+                float m = NEG;
+                if constexpr (H1 == 3) mfma_settle(st[0], st[1], st[2]);
+                else if constexpr (H1 == 2) mfma_settle(st[0], st[1]);
+                else mfma_settle(st[0]);
+#pragma unroll
+                for (int j = 0; j < H1; ++j)
+                    if (j != NV - 1) m = max3_nc(max3_nc(m, st[j][0], st[j][1]), st[j][2], st[j][3]);
+                asm volatile("" :: "v"(m));
+                REGION();
+                if constexpr (NV > H1) {
+                    bf16x8t kf[NV - H1][3];
+#pragma unroll
+                    for (int j = H1; j < NV; ++j)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl)
+                            kf[j - H1][pl] = *reinterpret_cast<const bf16x8t*>(kbase + (size_t)j * 256 + (size_t)pl * 4 * FA * 16);
+                    REGION();
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int j = H1; j < NV; ++j) st[j] = mfma16(kf[j - H1][PA6[u]], qp[PB6[u]], st[j]);
+                }
+                if constexpr (NV - H1 == 3) mfma_settle(st[H1], st[H1 + 1], st[NV - 1]);
+                else if constexpr (NV - H1 == 2) mfma_settle(st[H1], st[NV - 1]);
+                else if constexpr (NV - H1 == 1) mfma_settle(st[NV - 1]);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st[NV - 1][r] = r < klast ? st[NV - 1][r] : NEG;
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+                    if (j >= H1 || j == NV - 1) m = max3_nc(max3_nc(m, st[j][0], st[j][1]), st[j][2], st[j][3]);
+                asm volatile("" :: "v"(m));
+                REGION();
+                auto v_fetch = [&](int kk, bf16x8t (&v)[2][3]) {
+                    const int jb = 2 * kk + 1 < NV ? 2 * kk + 1 : 2 * kk;
+#pragma unroll
+                    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                        for (int pl = 0; pl < 3; ++pl) {
+                            const uint2 lo = *reinterpret_cast<const uint2*>(vbase + (size_t)(2 * kk) * 8 + (size_t)(pl * 2 + mb) * NB * 512);
+                            const uint2 hi = *reinterpret_cast<const uint2*>(vbase + (size_t)jb * 8 + (size_t)(pl * 2 + mb) * NB * 512);
+                            v[mb][pl] = join8(lo, hi);
+                        }
+                };
+                bf16x8t vf[2][3];
+                v_fetch(0, vf);
+                m = rows4_max(m);
+                REGION();
+#pragma unroll
+                for (int j = 0; j < NV; ++j)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float pv = __builtin_amdgcn_exp2f(st[j][r] - m);
+                        st[j][r] = pv;
+                        l += pv;
+                    }
+#pragma unroll
+                for (int kk = 0; kk < NP; ++kk) {
+                    float pr[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { pr[r] = st[2 * kk][r]; pr[4 + r] = 2 * kk + 1 < NV ? st[2 * kk + 1 < NV ? 2 * kk + 1 : 0][r] : 0.f; }
+                    bf16x8t pp[3];
+                    dawn_split3_oct(pr, pp[0], pp[1], pp[2]);
+                    REGION();
+#pragma unroll
+                    for (int u = 0; u < 6; ++u)
+#pragma unroll
+                        for (int mb = 0; mb < 2; ++mb) o[mb] = mfma16(vf[mb][PA6[u]], pp[PB6[u]], o[mb]);
+                    float cl = o[0][0] + o[1][0];
+                    asm volatile("" :: "v"(cl));
+                    REGION();
+                    if (kk + 1 < NP) v_fetch(kk + 1, vf);
+                }
+            };
+            switch (bhi - blo) {
+                case 6: body(std::integral_constant<int, 6>{}); break;
+                case 5: body(std::integral_constant<int, 5>{}); break;
+                case 4: body(std::integral_constant<int, 4>{}); break;
+                case 3: body(std::integral_constant<int, 3>{}); break;
+                case 2: body(std::integral_constant<int, 2>{}); break;
+                default: body(std::integral_constant<int, 1>{}); break;
+            }
+            l = rows4_sum(l);
+            const float inv = 1.0f / l;
+            if (iq >= q0 && iq < q0 + Fq) {
+                float* orow = out + ((long)(iq - q0) * HW + p) * 256 + 32 * h + 4 * g;
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+                    *reinterpret_cast<f32x4*>(orow + 16 * mb) = f32x4{o[mb][0] * inv, o[mb][1] * inv, o[mb][2] * inv, o[mb][3] * inv};
+            }
+        }
+        REGION();
+        __syncthreads();
+    }
+#undef REGION
+#endif
+}
+
 }  // namespace
 
 // ---- the launcher's schedule: who projects which K / V rows and who owns which query tile, balanced per SIMD (waves w, w + 4, w + 8
@@ -1295,6 +1564,19 @@ bool dawn_temporal_layer13_try(const float* x, int Fext, int HW, int q0, int Fq,
     (void)hipFuncSetAttribute((const void*)temporal_layer13_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
     hipLaunchKernelGGL(temporal_layer13_kernel, dim3(HW), dim3(NT13), LDS_BYTES, s, x, Fext, HW, q0, Fq, win,
                        (const unsigned short*)wqkv_bf3, (const unsigned short*)wout_bf3p, rot_cos, rot_sin, band, eps, out, delta, sc);
+    return true;
+}
+
+// The attention core of the unfused levels in the 13-wave form; false = nothing launched (more than 13 query tiles, win > 40, more than 208
+// buffer rows, offsets beyond 31 bits): the caller takes the 32 x 32 EXT kernel / the fp32 kernel.
+bool dawn_temporal_attn13_try(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos, const float* rot_sin,
+                              const float* band, float* out, hipStream_t s) {
+    tl13_sched sc;
+    if (!tl13_make_schedule(Fext, q0, Fq, win, sc)) return false;
+    if ((long)Fext * HW * 3072 >= (1L << 31)) return false;
+    const int delta = (((q0 - win) % 16) + 16) % 16;
+    (void)hipFuncSetAttribute((const void*)temporal_attn13_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ATTN13);
+    hipLaunchKernelGGL(temporal_attn13_kernel, dim3(HW), dim3(NT13), LDS_ATTN13, s, qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, delta, sc);
     return true;
 }
 

@@ -191,7 +191,9 @@ int dawn_temporal_attn(const float* qkv, int Fext, int HW, int q0, int Fq, int w
                        float* out, void* stream);
 /* the same with flags: 0 = automatic (S and P.V on the bf16 matrix pipe with exactly split operands where the shape is covered:
  * win <= 48, at most 256 queries, K / V planes of the buffer in LDS, >= 128 pixel columns; the fp32-MFMA kernel otherwise), bit 0 = the
- * fp32-MFMA kernel, bit 1 = the split-operand kernel whatever the number of pixel columns */
+ * fp32-MFMA kernel, bit 1 = the split-operand 32 x 32 kernel whatever the number of pixel columns.  Round 6: bit 2 = the window-tiled 13-wave kernel
+ * (16-query tiles, csrc/temporal_layer16.hip: temporal_attn13_kernel; win <= 40, Fext <= 208, at most 13 query tiles: error -39 outside).  Opt-in:
+ * 4..9 % faster than the 32 x 32 kernel in isolation, 0.3 % slower inside the benchmark (the core is bound by its reads of the (rows, 768) tensor) */
 int dawn_temporal_attn_ex(const float* qkv, int Fext, int HW, int q0, int Fq, int win,
                           const float* rot_cos, const float* rot_sin, const float* band,
                           float* out, int flags, void* stream);

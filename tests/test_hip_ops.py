@@ -855,6 +855,38 @@ def test_temporal_attn(hip, ref, Fext, HW, q0, Fq, win):
         hip.temporal_attn_flags = 0
     check(f"temporal_attn_fp32/F{Fext}_q{q0}_{Fq}_w{win}", got32, want, 2e-5)
     check(f"temporal_attn_split/F{Fext}_q{q0}_{Fq}_w{win}", got16, want, 2e-5)
+    if win <= 40 and Fext <= 208 and (Fq + (q0 - win) % 16 + 15) // 16 <= 13:      # the window-tiled 13-wave kernel, on any grid
+        try:
+            hip.temporal_attn_flags = 4
+            got13 = hip.temporal_attn(qkv.cuda(), Fext, HW, q0, Fq, win, rc.cuda(), rs.cuda(), band.cuda())
+        finally:
+            hip.temporal_attn_flags = 0
+        check(f"temporal_attn_13wave/F{Fext}_q{q0}_{Fq}_w{win}", got13, want, 2e-5)
+
+
+@pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(200, 256, 0, 200, 40), (200, 130, 47, 120, 40), (184, 128, 0, 184, 40), (120, 128, 31, 70, 24),
+                                                 (208, 128, 0, 208, 40), (200, 128, 40, 120, 40)])
+def test_temporal_attn_13wave_at_chip_filling_grids(hip, ref, Fext, HW, q0, Fq, win):
+    """temporal_attn13_kernel (opt-in, flags bit 2) at chip-filling grids (>= 128 pixel columns: the 128- / 256-channel levels of the benchmark,
+    the 120-query segments of longer clips and T-shard ranks): against the oracle and the 32 x 32 kernel, and eight runs bit-identical (the kernel
+    keeps the fused layer's load / compute regions: a load that lands in the registers of an MFMA still in flight shows up as a different tile
+    every run)."""
+    qkv = rnd(Fext * HW, 768, seed=11)
+    ang = torch.arange(Fext).float()[:, None] * (1.0 / (10000 ** (torch.arange(0, 32, 2).float() / 32)))[None]
+    rc, rs = ang.cos().contiguous(), ang.sin().contiguous()
+    band = rnd(2 * win + 1, 8, seed=12)
+    want = ref.temporal_attn(qkv, Fext, HW, q0, Fq, win, rc, rs, band)
+    args = (qkv.cuda(), Fext, HW, q0, Fq, win, rc.cuda(), rs.cuda(), band.cuda())
+    old = hip.temporal_attn(*args)                                   # automatic: the 32 x 32 split kernel
+    try:
+        hip.temporal_attn_flags = 4
+        got = hip.temporal_attn(*args)
+        check(f"temporal_attn_13wave/F{Fext}_HW{HW}_q{q0}_{Fq}_w{win}", got, want, 2e-5)
+        check(f"temporal_attn_13wave_vs_32x32/F{Fext}_HW{HW}", got, old, 2e-5)
+        for _ in range(7):
+            assert torch.equal(hip.temporal_attn(*args), got)
+    finally:
+        hip.temporal_attn_flags = 0
 
 
 @pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(12, 5, 0, 12, 3), (200, 3, 0, 200, 40), (280, 2, 40, 200, 40),
