@@ -865,7 +865,7 @@ def test_temporal_attn(hip, ref, Fext, HW, q0, Fq, win):
 
 
 @pytest.mark.parametrize("Fext,HW,q0,Fq,win", [(200, 256, 0, 200, 40), (200, 130, 47, 120, 40), (184, 128, 0, 184, 40), (120, 128, 31, 70, 24),
-                                                 (208, 128, 0, 208, 40), (200, 128, 40, 120, 40)])
+                                                 (208, 128, 8, 200, 40), (200, 128, 40, 120, 40)])
 def test_temporal_attn_13wave_at_chip_filling_grids(hip, ref, Fext, HW, q0, Fq, win):
     """temporal_attn13_kernel (opt-in, flags bit 2) at chip-filling grids (>= 128 pixel columns: the 128- / 256-channel levels of the benchmark,
     the 120-query segments of longer clips and T-shard ranks): against the oracle and the 32 x 32 kernel, and eight runs bit-identical (the kernel
