@@ -191,7 +191,7 @@ bool dawn_temporal_attn_bf16_try(const float* qkv, int Fext, int HW, int q0, int
 
 // (temporal_layer16.hip) the same in the window-tiled 13-wave form (16-query tiles against the key blocks of their window); false = not covered
 bool dawn_temporal_attn13_try(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos, const float* rot_sin,
-                              const float* band, float* out, hipStream_t s);
+                              const float* band, float* out, bool pixel_head_major, hipStream_t s);
 
 extern "C" int dawn_temporal_attn_ex(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos,
                                      const float* rot_sin, const float* band, float* out, int flags, void* stream) {
@@ -203,7 +203,8 @@ extern "C" int dawn_temporal_attn_ex(const float* qkv, int Fext, int HW, int q0,
     // 175.5 / 176.2 / 176.8 frames/s alternating on one box, profiles/r6_temporal_attn13_ab.txt): at these levels the core is bound by how it
     // reads the (rows, 768) tensor -- 128-byte pieces 3 KB apart -- not by its arithmetic
     if (flags & 4) {
-        if (dawn_temporal_attn13_try(qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, (hipStream_t)stream)) {
+        // (bit 4, with bit 2 only: qkv is in the (pixel, head)-major layout [pixel][head][q | k | v][buffer row][32] -- the layout experiment of DESIGN 8)
+        if (dawn_temporal_attn13_try(qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, (flags & 16) != 0, (hipStream_t)stream)) {
             DAWN_LAUNCH_CHECK();
             return 0;
         }

@@ -1048,6 +1048,9 @@ __global__ __launch_bounds__(NT13) void temporal_layer13_kernel(
 constexpr int ROT_BYTES = FA * 128;            // [row][cos 16 | sin 16] floats
 constexpr int LDS_ATTN13 = KP_BYTES + VP_BYTES + BAND_BYTES + ROT_BYTES;
 
+// PH: qkv in the (pixel, head)-major layout [pixel][head 8][q | k | v][buffer row][32] -- a pixel column's rows of one head are one contiguous
+// run of Fext x 128 bytes per operand instead of 128-byte pieces HW x 3 KB apart.
+template <bool PH>
 __global__ __launch_bounds__(NT13) void temporal_attn13_kernel(
     const float* __restrict__ qkv, int Fext, int HW, int q0, int Fq, int win, const float* __restrict__ rcos,
     const float* __restrict__ rsin, const float* __restrict__ band, float* __restrict__ out, int delta, const tl13_sched sched) {
@@ -1095,11 +1098,15 @@ __global__ __launch_bounds__(NT13) void temporal_attn13_kernel(
     // rows past the buffer (the tail of the last 16-row tile) are out of the descriptor's range: the hardware returns zeros -- the K / V of the
     // fused kernel's zero rows.  One vector offset per role; the row tile, the head and the feature half travel in the scalar offset.
     const __amdgpu_buffer_rsrc_t rsq = __builtin_amdgcn_make_buffer_rsrc((void*)qkv, 0, Fext * HW * 3072, 0x00020000);
-    const unsigned rowb = (unsigned)HW * 3072u;
-    const unsigned pcol = (unsigned)(p * 3072);
+    const unsigned rowb = PH ? 128u : (unsigned)HW * 3072u;               // bytes between consecutive buffer rows of one (pixel, head, operand)
+    const unsigned pcol = PH ? 0u : (unsigned)(p * 3072);
     const unsigned vo_q = (unsigned)iqc * rowb + pcol + (unsigned)(16 * g);
     const unsigned vo_k = (unsigned)n * rowb + pcol + (unsigned)(16 * g);
     const unsigned vo_v = (unsigned)(4 * g) * rowb + pcol + (unsigned)(4 * n);
+    // scalar offset of (head hh, operand sel, feature half mb): columns of the row in the standard layout, the operand's run in the PH one
+    auto opoff = [&](int hh, int sel, int mb) -> int {
+        return PH ? (int)(((unsigned)(p * 8 + hh) * 3u + (unsigned)sel) * (unsigned)Fext * 128u) + 64 * mb : (256 * sel + 32 * hh + 16 * mb) * 4;
+    };
     f32x4 kvraw[4], qraw[2];
     float bandv;
     const int bidx = (tid & 127) + (tid >> 7) - 15;
@@ -1107,10 +1114,10 @@ __global__ __launch_bounds__(NT13) void temporal_attn13_kernel(
     auto request_next = [&](int hh) {
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb)
-            qraw[mb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, vo_q, (32 * hh + 16 * mb) * 4, 0));
+            qraw[mb] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsq, vo_q, opoff(hh, 0, mb), 0));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int so = (int)((unsigned)(16 * urt[i]) * rowb) + ((uV[i] ? 512 : 256) + 32 * hh + 16 * ukmb[i]) * 4;      // (scalar)
+            const int so = (int)((unsigned)(16 * urt[i]) * rowb) + opoff(hh, uV[i] ? 2 : 1, ukmb[i]);      // (scalar)
             if (uV[i]) {                                             // (wave-uniform)
 #pragma unroll
                 for (int r = 0; r < 4; ++r)
@@ -1570,13 +1577,18 @@ bool dawn_temporal_layer13_try(const float* x, int Fext, int HW, int q0, int Fq,
 // The attention core of the unfused levels in the 13-wave form; false = nothing launched (more than 13 query tiles, win > 40, more than 208
 // buffer rows, offsets beyond 31 bits): the caller takes the 32 x 32 EXT kernel / the fp32 kernel.
 bool dawn_temporal_attn13_try(const float* qkv, int Fext, int HW, int q0, int Fq, int win, const float* rot_cos, const float* rot_sin,
-                              const float* band, float* out, hipStream_t s) {
+                              const float* band, float* out, bool pixel_head_major, hipStream_t s) {
     tl13_sched sc;
     if (!tl13_make_schedule(Fext, q0, Fq, win, sc)) return false;
     if ((long)Fext * HW * 3072 >= (1L << 31)) return false;
     const int delta = (((q0 - win) % 16) + 16) % 16;
-    (void)hipFuncSetAttribute((const void*)temporal_attn13_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ATTN13);
-    hipLaunchKernelGGL(temporal_attn13_kernel, dim3(HW), dim3(NT13), LDS_ATTN13, s, qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, delta, sc);
+    if (pixel_head_major) {
+        (void)hipFuncSetAttribute((const void*)temporal_attn13_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ATTN13);
+        hipLaunchKernelGGL(temporal_attn13_kernel<true>, dim3(HW), dim3(NT13), LDS_ATTN13, s, qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, delta, sc);
+    } else {
+        (void)hipFuncSetAttribute((const void*)temporal_attn13_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_ATTN13);
+        hipLaunchKernelGGL(temporal_attn13_kernel<false>, dim3(HW), dim3(NT13), LDS_ATTN13, s, qkv, Fext, HW, q0, Fq, win, rot_cos, rot_sin, band, out, delta, sc);
+    }
     return true;
 }
 

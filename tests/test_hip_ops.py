@@ -885,6 +885,10 @@ def test_temporal_attn_13wave_at_chip_filling_grids(hip, ref, Fext, HW, q0, Fq, 
         check(f"temporal_attn_13wave_vs_32x32/F{Fext}_HW{HW}", got, old, 2e-5)
         for _ in range(7):
             assert torch.equal(hip.temporal_attn(*args), got)
+        # the layout experiment (flags bit 4): the same rows in the (pixel, head)-major layout [pixel][head][q | k | v][buffer row][32]
+        hip.temporal_attn_flags = 4 | 16
+        ph = qkv.view(Fext, HW, 3, 8, 32).permute(1, 3, 2, 0, 4).contiguous().view(Fext * HW, 768).cuda()
+        assert torch.equal(hip.temporal_attn(ph, *args[1:]), got)
     finally:
         hip.temporal_attn_flags = 0
 
