@@ -19,12 +19,13 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--policy", default="0")
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--first", type=int, default=0, help="only the first N shapes")
+ap.add_argument("--only", type=int, default=-1, help="only shape i of the list")
 a = ap.parse_args()
 ops = HipOps()
 dev = "cuda"
 for pol in [int(v, 0) for v in a.policy.split(",")]:
     ops.conv_policy = pol
-    for (M, N, K, rs, res) in (SHAPES[:a.first] if a.first else SHAPES):
+    for (M, N, K, rs, res) in ([SHAPES[a.only]] if a.only >= 0 else (SHAPES[:a.first] if a.first else SHAPES)):
         torch.manual_seed(0)
         x = torch.randn(M, K, device=dev)
         w_kn = torch.randn(K, N) * K ** -0.5
