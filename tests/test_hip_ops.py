@@ -526,7 +526,11 @@ def test_gemm1x1_layernorm_inside(hip, ref, M, C0, C1, N):
                                              (12800, 64, 0, 512, "strided"), (204800, 32, 96, 64, "bias"),
                                              (51200, 128, 0, 768, "rowstats"), (25600, 128, 128, 192, "rowstats"),
                                              (12800, 512, 0, 768, "rowstats"), (25600, 256, 256, 128, "res"),
-                                             (12800, 512, 512, 64, "tr"), (12800, 1024, 0, 192, "rowstats"), (51200, 192, 64, 192, "bias")])
+                                             (12800, 512, 512, 64, "tr"), (12800, 1024, 0, 192, "rowstats"), (51200, 192, 64, 192, "bias"),
+                                             # the tile kernel's stage loop at its corners (round 6: stages in pairs, fetches clamped past the end of K):
+                                             # one stage, three stages, nine stages with the source switch at an odd stage, a switch after stage 0
+                                             (12800, 32, 0, 64, "bias"), (12800, 96, 0, 128, "rowstats"), (25600, 160, 128, 256, "res"),
+                                             (12800, 32, 64, 128, "rowstats"), (6400, 96, 0, 256, "tr")])
 def test_gemm1x1_split_variants(hip, ref, M, C0, C1, N, extra):
     """The same kernel family beyond the plain case: 64-column tiles (N = 64 / 192), two channel-concatenated sources
     (res_conv / to_q of cat[x, skip]), the res_conv epilogue out += SiLU(c2*a+b), M down to 12800 rows, and strided
