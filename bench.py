@@ -521,6 +521,7 @@ def main():
         one_clip()
     if not args.no_kernel_events and not diff.use_ctx:
         ops.prof = []
+        ops.prof_layers = []
         ops.prof_every = max(1, args.event_every)
     barrier()
     clip_ev = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
@@ -533,6 +534,7 @@ def main():
     dt = time.perf_counter() - t0
     clip_ms = sorted(clip_ev[i].elapsed_time(clip_ev[i + 1]) for i in range(args.steps))
     prof, ops.prof = getattr(ops, "prof", None), None
+    prof_layers, ops.prof_layers = getattr(ops, "prof_layers", None), None
     if dist is not None:
         tt = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -706,6 +708,37 @@ def main():
             result["roofline"]["traffic_refused"] = traffic_refused
         if len(order) > 1:
             result["roofline_other"] = [roofs[k][0] for k in order[1:]]
+        # ---- the fused 64-channel temporal layer (the second largest kernel of an evaluation; not a dawn_conv_gemm launch): its own entry.
+        # Executed flops = the MFMAs the window-tiled kernel issues for the shape (the host schedule's unit counts: per head and pixel column
+        # 48 per 16-row tile of K / V projection, per 16-query tile 24 (Q projection) + 6 per existing 16-key block (S) + 12 per block pair
+        # (P.V) + 24 (out-projection)) x 16,384 flops per v_mfma_f32_16x16x32_bf16; algorithmic = LayerNorm'ed rows x (64 -> 768 projection)
+        # + windowed attention over 8 heads x 32 + the 256 -> 64 out-projection, 2 flops per multiply-add.
+        tl = [q for q in (prof_layers or []) if q[0] == "temporal_layer_c64" and q[1][5]]
+        if tl:
+            def tl_units(Fext, q0, Fq, win):
+                delta = (q0 - win) % 16
+                nqt, nblk, nkb = (Fq + delta + 15) // 16, (Fext + 15) // 16, (16 + 2 * win + 15) // 16
+                u = 48 * nblk
+                for t in range(nqt):
+                    B0 = (q0 - delta + 16 * t - win) // 16
+                    lo, hi = max(0, -B0), min(nkb, nblk - B0)
+                    ok = [lo <= b < hi for b in range(6)]
+                    u += 48 + 6 * sum(ok) + 12 * sum(ok[2 * k] or ok[2 * k + 1] for k in range(3))
+                return 8 * u
+            t_ms = sum(q[2].elapsed_time(q[3]) for q in tl)
+            ex = sum(tl_units(q[1][0], q[1][2], q[1][3], q[1][4]) * q[1][1] * 16384.0 for q in tl)
+            alg = sum(q[1][1] * (2.0 * 64 * 768 * q[1][0] + q[1][3] * (2.0 * 2 * 256 * min(2 * q[1][4] + 1, q[1][0]) + 2.0 * 256 * 64)) for q in tl)
+            result.setdefault("roofline_other", []).append({
+                "bound": "mfma", "unit": "TFLOP/s", "kernel": "temporal_layer13_kernel / temporal_layer16_kernel (fused 64-channel temporal layer: LayerNorm + to_qkv + rotary + "
+                "windowed attention with relative-position bias + to_out + residual in one launch per layer; every contraction on v_mfma_f32_16x16x32_bf16 "
+                "with exactly split operands, 6 cross terms, fp32 accumulate)",
+                "launches": len(tl), "avg_launch_us": t_ms * 1e3 / len(tl), "timing": timing.replace("conv_gemm", "fused temporal layer"),
+                "achieved": ex / (t_ms * 1e-3) / 1e12, "peak": PEAK_BF16_MFMA_TFLOPS, "frac": ex / (t_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                "frac_is": "frac_executed", "frac_executed": ex / (t_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS,
+                "algorithmic_tflops": alg / (t_ms * 1e-3) / 1e12, "frac_algorithmic_vs_fp32_mfma_peak": alg / (t_ms * 1e-3) / 1e12 / PEAK_FP32_MFMA_TFLOPS,
+                "algorithmic_bytes_per_launch_avg": sum(q[1][1] * 256.0 * (q[1][0] + q[1][3]) for q in tl) / len(tl),
+                "traffic": None, "share_of_conv_time": None,
+                "note": "not a dawn_conv_gemm launch: listed beside the conv / GEMM classes with its own launch times; counters: profiles/r6_pmc_temporal_layer.md"})
         # the split kernels are POWER-limited (same instruction stream, zero-filled tensors: 28-38 % faster; profiles/
         # r3_conv_power_by_data.txt): price the dominant kernel against what an MFMA-only loop sustains on THIS box right now
         try:

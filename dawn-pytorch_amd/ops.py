@@ -45,6 +45,7 @@ class HipOps:
         self.L = _lib.lib()          # raises if the extension is missing: no fallback by design
         self.comm = comm             # T-shard communicator (see tshard.py) or None
         self.prof = None             # list -> (algorithmic flops, start event, end event) per conv_gemm launch
+        self.prof_layers = None      # list -> (op, shape, start event, end event) per fused-layer launch (bench.py)
         self.prof_on = True          # sampling switch (the sampler records events on every n-th DDIM step only)
         self.overlap = True          # two-stream overlap of independent branches (fork_join)
         self._side_stream = None
@@ -78,6 +79,7 @@ class HipOps:
     def with_comm(self, comm):
         o = HipOps(comm)
         o.prof = self.prof
+        o.prof_layers = self.prof_layers
         o.prof_on = self.prof_on
         o.prof_every = getattr(self, "prof_every", 1)
         o.overlap = self.overlap
@@ -435,10 +437,17 @@ class HipOps:
         if out is None:
             out = self.empty(Fq * HW, 64, like=x)
         _need(out.is_contiguous() and out.shape == (Fq * HW, 64), "temporal_layer_c64: out.is_contiguous() and out.shape == (Fq * HW, 64)")
+        ev = None
+        if getattr(self, "prof_layers", None) is not None and self.prof_on:      # bench.py: HIP events around the launch (sampled steps only)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            ev[0].record()
         check(self.L.dawn_temporal_layer_c64_ex(_p(x), Fext, HW, q0, Fq, win, _p(wqkv), _p(wqkv_bf3), _p(wout), _p(wout_bf3p),
                                                 _p(rcos), _p(rsin), _p(band), eps, _p(out), self.temporal_flags,
                                                 self._stream()),
               "dawn_temporal_layer_c64")
+        if ev is not None:
+            ev[1].record()
+            self.prof_layers.append(("temporal_layer_c64", (Fext, HW, q0, Fq, win, wqkv_bf3 is not None and wout_bf3p is not None), ev[0], ev[1]))
         return out
 
     def sla(self, qkv: Tensor, F: int, HW: int) -> Tensor:
